@@ -1,0 +1,80 @@
+// Shared host/device helpers for libfldr_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "fldr_hip.h"
+
+#define FLDR_CHECK_ARG(cond) do { if (!(cond)) return FLDR_E_ARG; } while (0)
+#define FLDR_LAUNCH_RET() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 0 : (int)e_; } while (0)
+
+static inline hipStream_t fldr_s(fldr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int fldr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- bilinear sampling with F.grid_sample(align_corners=False, zeros) semantics ----------------
+// Position arithmetic follows the op sequence of DCTVFInet.bwarp (fLDRnet.py:561-565) followed by
+// PyTorch's unnormalisation ((g+1)*size/2 - 0.5) with FMA contraction disabled, so that sample
+// positions agree with the fp32 reference to the last bit wherever possible: a 1-ulp change of the
+// normalised coordinate is 1e-4 px at 4K and would show up at sharp edges and at the mask threshold.
+struct FldrTap {
+    int   x0, y0;            // north-west integer corner
+    float wnw, wne, wsw, wse;
+    bool  vnw, vne, vsw, vse; // corner in bounds
+};
+
+__device__ __forceinline__ FldrTap fldr_grid_tap(float px, float py, float fx, float fy, int W, int H,
+                                                 float inv_wm1, float inv_hm1) {
+#pragma clang fp contract(off)
+    FldrTap t;
+    float vx = px + fx;
+    float vy = py + fy;
+    float gx = (2.0f * vx) * inv_wm1 - 1.0f;
+    float gy = (2.0f * vy) * inv_hm1 - 1.0f;
+    float ix = (gx + 1.0f) * ((float)W * 0.5f) - 0.5f;
+    float iy = (gy + 1.0f) * ((float)H * 0.5f) - 0.5f;
+    float xf = floorf(ix), yf = floorf(iy);
+    float w = ix - xf, e = 1.0f - w;
+    float n = iy - yf, s = 1.0f - n;
+    t.wnw = s * e; t.wne = s * w; t.wsw = n * e; t.wse = n * w;
+    // clamp before the int conversion: wild flows must not overflow int
+    xf = fminf(fmaxf(xf, -2.0f), (float)W + 1.0f);
+    yf = fminf(fmaxf(yf, -2.0f), (float)H + 1.0f);
+    t.x0 = (int)xf; t.y0 = (int)yf;
+    bool x0v = t.x0 >= 0 && t.x0 < W, x1v = t.x0 + 1 >= 0 && t.x0 + 1 < W;
+    bool y0v = t.y0 >= 0 && t.y0 < H, y1v = t.y0 + 1 >= 0 && t.y0 + 1 < H;
+    t.vnw = x0v && y0v; t.vne = x1v && y0v; t.vsw = x0v && y1v; t.vse = x1v && y1v;
+    return t;
+}
+
+__device__ __forceinline__ float fldr_tap_mask(const FldrTap& t) {
+#pragma clang fp contract(off)
+    // grid_sample of a ones tensor: sum of the in-bounds corner weights, accumulated nw,ne,sw,se
+    float m = 0.0f;
+    if (t.vnw) m += t.wnw;
+    if (t.vne) m += t.wne;
+    if (t.vsw) m += t.wsw;
+    if (t.vse) m += t.wse;
+    return m < 0.999f ? 0.0f : 1.0f;          // fLDRnet.py:573-574
+}
+
+__device__ __forceinline__ float fldr_tap_sample(const FldrTap& t, const float* __restrict__ plane, int W) {
+#pragma clang fp contract(off)
+    const float* p = plane + (int64_t)t.y0 * W + t.x0;
+    float v = 0.0f;
+    if (t.vnw) v += p[0] * t.wnw;
+    if (t.vne) v += p[1] * t.wne;
+    if (t.vsw) v += p[W] * t.wsw;
+    if (t.vse) v += p[W + 1] * t.wse;
+    return v;
+}
+
+// ---- F.interpolate(bilinear, align_corners=False) source index / lambda -------------------------
+__device__ __forceinline__ void fldr_lin_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
+    float r = scale * ((float)o + 0.5f) - 0.5f;
+    r = r < 0.0f ? 0.0f : r;
+    int i = (int)r;
+    i0 = i < in_size - 1 ? i : in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    float l = r - (float)i0;
+    l1 = l < 0.0f ? 0.0f : (l > 1.0f ? 1.0f : l);
+}

@@ -1,0 +1,297 @@
+// Convolutions of fLDRnet (3x3 s1 p1 and 4x4 s2 p1) as implicit GEMMs on the gfx950 matrix cores.
+//
+// GEMM view: D[cout][pixel] = sum_{cin,tap} Wt[cout][cin,tap] * X[cin,tap][pixel].  The weights are the A
+// operand (rows = output channels) and the pixels the B operand (columns), so that in the MFMA result
+// layout a lane owns one PIXEL column and the registers walk the output channels: every store
+// instruction of the epilogue writes 32 (or 16) consecutive pixels of one NCHW plane per half/quarter
+// wave, i.e. full 128-B (64-B) segments, and the input tile is read from LDS with consecutive lanes on
+// consecutive addresses (conflict free).
+//
+//   precision 0: v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 — exact fp32 products, fp32
+//                accumulation (bitwise an fmaf chain), the parity path.
+//
+// A 256-thread workgroup (4 waves, one per SIMD) owns a TH x 32 output tile and ALL output channels
+// (<= 96), loops over the input channels in chunks of CC, and per chunk stages in LDS
+//   * the input tile with its halo, assembled on the fly from up to 12 sources (torch.cat is never
+//     materialised; a source may be read through nearest x2 upsampling; zero padding by predication),
+//   * the CC x taps x cout slice of the prepacked weights.
+// cout <= 16 uses the 16x16x4 shape (M = 16), otherwise 32x32x2 with ceil(cout/32) M-tiles.
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvArgs {
+    const float* src[FLDR_CONV_MAX_SRC];
+    int64_t src_bstride[FLDR_CONV_MAX_SRC];
+    int32_t src_cbegin[FLDR_CONV_MAX_SRC + 1];
+    int32_t src_up2[FLDR_CONV_MAX_SRC];
+    int32_t n_src;
+    const float* wpack;
+    const float* bias;
+    const float* residual;
+    float* out;
+    int32_t cin, cout, cout_store;
+    int32_t Hin, Win, Hout, Wout;
+    int32_t relu;
+    int32_t tiles_x;
+};
+
+constexpr int pad16mod32(int v) { return v + ((16 - (v % 32)) + 32) % 32; }
+
+template <int KS, int STRIDE, int MT, int NMT, int PT, int CC_>
+struct ConvCfg {
+    static constexpr int CC = CC_;
+    static constexpr int TW = 32;
+    static constexpr int TPR = TW / MT;                  // pixel tiles per tile row (1 or 2)
+    static constexpr int RPW = PT / TPR;                 // rows per wave
+    static constexpr int TH = 4 * RPW;
+    static constexpr int IH = (TH - 1) * STRIDE + KS;
+    static constexpr int IW = (TW - 1) * STRIDE + KS;
+    static constexpr int IWH = (IW + 1) / 2;             // stride 2: even/odd columns de-interleaved
+    static constexpr int IWP = STRIDE == 2 ? 2 * IWH : IW;
+    static constexpr int ICH = MT == 16 ? pad16mod32(IH * IWP) : IH * IWP;      // channel stride (floats)
+    static constexpr int TAPS = KS * KS;
+    static constexpr int MTOT = NMT * MT;
+    static constexpr int WCH = MT == 16 ? pad16mod32(TAPS * MTOT) : TAPS * MTOT;
+    static constexpr int LDS_FLOATS = CC * (ICH + WCH);
+    static constexpr int KG = MT == 16 ? 4 : 2;          // input channels per MFMA
+};
+
+template <int KS, int STRIDE, int MT, int NMT, int PT, int CC_>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+    using Cfg = ConvCfg<KS, STRIDE, MT, NMT, PT, CC_>;
+    constexpr int CC = Cfg::CC, IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IWH = Cfg::IWH, ICH = Cfg::ICH;
+    constexpr int TAPS = Cfg::TAPS, MTOT = Cfg::MTOT, WCH = Cfg::WCH, KG = Cfg::KG;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* in_s = smem;
+    float* w_s = smem + CC * ICH;
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = blockIdx.y;
+    const int tile_y = blockIdx.x / a.tiles_x, tile_x = blockIdx.x % a.tiles_x;
+    const int oy0 = tile_y * Cfg::TH, ox0 = tile_x * Cfg::TW;
+    const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;          // pad = 1
+
+    const int lj = lane & (MT - 1);          // pixel within pixel tile (B column) / cout within M tile (A row)
+    const int lk = lane / MT;                // k index within the MFMA (0..KG-1)
+
+    // per-pixel-tile LDS base offsets of the B operand (tap (0,0), channel lk)
+    int boff[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        int r = wave * Cfg::RPW + p / Cfg::TPR;          // output row within tile
+        int c0 = (p % Cfg::TPR) * MT;                    // output col within tile
+        boff[p] = lk * ICH + (r * STRIDE) * IWP + (c0 + lj);   // stride 2: even-column plane, col index = out col
+    }
+    const int aoff = lk * WCH + lj;
+
+    typedef typename std::conditional<MT == 32, f32x16, f32x4>::type acc_t;
+    acc_t acc[NMT][PT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[m][p][r] = 0.0f;
+
+    const int cin_pad = (a.cin + CC - 1) / CC * CC;
+    for (int c0 = 0; c0 < cin_pad; c0 += CC) {
+        // ---- stage weights: contiguous CC*TAPS*MTOT floats in wpack ----
+        {
+            const float4* g = reinterpret_cast<const float4*>(a.wpack + (int64_t)c0 * TAPS * MTOT);
+            constexpr int PER_CH4 = TAPS * MTOT / 4;
+            for (int e = tid; e < CC * PER_CH4; e += 256) {
+                int c = e / PER_CH4, r = e % PER_CH4;
+                *reinterpret_cast<float4*>(w_s + c * WCH + r * 4) = g[e];
+            }
+        }
+        // ---- stage input tile: each wave assembles whole channels (source lookup is wave-uniform) ----
+        for (int c = wave; c < CC; c += 4) {
+            const int cg = c0 + c;
+            const float* base = nullptr;
+            int up2 = 0;
+            if (cg < a.cin) {
+                int s = 0;
+                while (s + 1 < a.n_src && cg >= a.src_cbegin[s + 1]) ++s;
+                up2 = a.src_up2[s];
+                const int hs = up2 ? a.Hin >> 1 : a.Hin, ws = up2 ? a.Win >> 1 : a.Win;
+                base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(cg - a.src_cbegin[s]) * hs * ws;
+            }
+            const int ws = up2 ? a.Win >> 1 : a.Win;
+            float* dst = in_s + c * ICH;
+            for (int e = lane; e < IH * IW; e += 64) {
+                int y = e / IW, x = e % IW;
+                int gy = iy0 + y, gx = ix0 + x;
+                float v = 0.0f;
+                if (base != nullptr && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
+                    v = up2 ? base[(int64_t)(gy >> 1) * ws + (gx >> 1)] : base[(int64_t)gy * ws + gx];
+                int col = STRIDE == 2 ? (x & 1) * IWH + (x >> 1) : x;
+                dst[y * IWP + col] = v;
+            }
+        }
+        __syncthreads();
+        // ---- MFMA over the chunk ----
+#pragma unroll 1
+        for (int cg = 0; cg < CC; cg += KG) {
+            const float* wc = w_s + cg * WCH + aoff;
+            const float* ic = in_s + cg * ICH;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                const int dy = t / KS, dx = t % KS;
+                const int toff = dy * IWP + (STRIDE == 2 ? (dx & 1) * IWH + (dx >> 1) : dx);
+                float av[NMT], bv[PT];
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) av[m] = wc[t * MTOT + m * MT];
+#pragma unroll
+                for (int p = 0; p < PT; ++p) bv[p] = ic[boff[p] + toff];
+#pragma unroll
+                for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                    for (int p = 0; p < PT; ++p) {
+                        if constexpr (MT == 32) acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[p], acc[m][p], 0, 0, 0);
+                        else                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[p], acc[m][p], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: bias, ReLU, residual, store (lane = pixel column, registers = output channels) ----
+    const int64_t HWo = (int64_t)a.Hout * a.Wout;
+    float* outn = a.out + (int64_t)n * a.cout_store * HWo;
+    const float* resn = a.residual ? a.residual + (int64_t)n * a.cout_store * HWo : nullptr;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int oy = oy0 + wave * Cfg::RPW + p / Cfg::TPR;
+        const int ox = ox0 + (p % Cfg::TPR) * MT + lj;
+        const bool pix_ok = oy < a.Hout && ox < a.Wout;
+        const int64_t po = (int64_t)oy * a.Wout + ox;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+#pragma unroll
+            for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) {
+                int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                if (co < a.cout_store && pix_ok) {
+                    float v = acc[m][p][r];
+                    if (a.bias) v += a.bias[co];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    if (resn) v += resn[(int64_t)co * HWo + po];
+                    outn[(int64_t)co * HWo + po] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight prepack: [cout,cin,k,k] -> [cin_pad][taps][mtot], zero padded
+// ------------------------------------------------------------------------------------------------
+static inline void conv_geometry(int cout, int ksize, int& mt, int& nmt, int& cc) {
+    mt = cout <= 16 ? 16 : 32;
+    nmt = (cout + mt - 1) / mt;
+    cc = ksize == 4 ? 4 : 8;
+}
+
+__global__ void conv_prepack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int taps,
+                                    int mtot, int64_t total) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    int m = (int)(i % mtot);
+    int t = (int)((i / mtot) % taps);
+    int c = (int)(i / ((int64_t)mtot * taps));
+    wp[i] = (m < cout && c < cin) ? w[((int64_t)m * cin + c) * taps + t] : 0.0f;
+}
+
+extern "C" int64_t fldr_conv_prepack_size(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || (ksize != 3 && ksize != 4) || cout > 96) return FLDR_E_ARG;
+    int mt, nmt, cc;
+    conv_geometry(cout, ksize, mt, nmt, cc);
+    int cin_pad = (cin + cc - 1) / cc * cc;
+    return (int64_t)cin_pad * ksize * ksize * nmt * mt;
+}
+
+extern "C" int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(weight && wpack);
+    int64_t total = fldr_conv_prepack_size(cout, cin, ksize);
+    if (total < 0) return (int)total;
+    int mt, nmt, cc;
+    conv_geometry(cout, ksize, mt, nmt, cc);
+    hipLaunchKernelGGL(conv_prepack_kernel, dim3(fldr_cdiv(total, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin,
+                       ksize * ksize, nmt * mt, total);
+    FLDR_LAUNCH_RET();
+}
+
+template <int KS, int STRIDE, int MT, int NMT, int PT, int CC>
+static int conv_launch(const ConvArgs& a, int N, hipStream_t s) {
+    using Cfg = ConvCfg<KS, STRIDE, MT, NMT, PT, CC>;
+    ConvArgs b = a;
+    b.tiles_x = fldr_cdiv(a.Wout, Cfg::TW);
+    const int tiles_y = fldr_cdiv(a.Hout, Cfg::TH);
+    const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
+    static bool attr_done = false;
+    if (!attr_done && lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>), dim3(b.tiles_x * tiles_y, N), dim3(256), lds, s, b);
+    FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_conv2d(const fldr_conv_desc* d, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d && d->wpack && d->out && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
+    FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cout > 0 && d->cout <= 96 && d->cout_store > 0 && d->cout_store <= d->cout);
+    FLDR_CHECK_ARG((d->ksize == 3 && d->stride == 1) || (d->ksize == 4 && d->stride == 2));
+    FLDR_CHECK_ARG(d->Hin > 0 && d->Win > 0);
+    FLDR_CHECK_ARG(d->precision == 0);
+    const int Ho = d->ksize == 3 ? d->Hin : (d->Hin + 2 - 4) / 2 + 1;
+    const int Wo = d->ksize == 3 ? d->Win : (d->Win + 2 - 4) / 2 + 1;
+    if (Ho != d->Hout || Wo != d->Wout) return FLDR_E_SHAPE;
+    ConvArgs a;
+    int csum = 0;
+    for (int s = 0; s < FLDR_CONV_MAX_SRC; ++s) {
+        bool live = s < d->n_src;
+        if (live) {
+            FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0);
+            if (d->src_up2[s] && ((d->Hin | d->Win) & 1)) return FLDR_E_SHAPE;
+        }
+        a.src[s] = live ? d->src[s] : nullptr;
+        a.src_bstride[s] = live ? d->src_bstride[s] : 0;
+        a.src_up2[s] = live ? d->src_up2[s] : 0;
+        a.src_cbegin[s] = csum;
+        if (live) csum += d->src_c[s];
+    }
+    a.src_cbegin[FLDR_CONV_MAX_SRC] = csum;
+    if (csum != d->cin) return FLDR_E_SHAPE;
+    a.n_src = d->n_src;
+    a.wpack = d->wpack; a.bias = d->bias; a.residual = d->residual; a.out = d->out;
+    a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
+    a.Hin = d->Hin; a.Win = d->Win; a.Hout = d->Hout; a.Wout = d->Wout; a.relu = d->relu; a.tiles_x = 0;
+    hipStream_t s = fldr_s(stream);
+    int mt, nmt, cc;
+    conv_geometry(d->cout, d->ksize, mt, nmt, cc);
+    if (d->ksize == 3) {
+        if (mt == 16) return conv_launch<3, 1, 16, 1, 8, 8>(a, d->N, s);
+        if (nmt == 1) return conv_launch<3, 1, 32, 1, 4, 8>(a, d->N, s);
+        if (nmt == 2) return conv_launch<3, 1, 32, 2, 2, 8>(a, d->N, s);
+        return conv_launch<3, 1, 32, 3, 2, 8>(a, d->N, s);
+    } else {
+        if (mt == 16) return conv_launch<4, 2, 16, 1, 4, 4>(a, d->N, s);
+        if (nmt == 1) return conv_launch<4, 2, 32, 1, 2, 4>(a, d->N, s);
+        if (nmt == 2) return conv_launch<4, 2, 32, 2, 2, 4>(a, d->N, s);
+        return FLDR_E_ARG;
+    }
+}
+
+extern "C" int fldr_version(void) { return FLDR_VERSION; }
+
+extern "C" const char* fldr_error_string(int code) {
+    if (code == 0) return "success";
+    if (code == FLDR_E_ARG) return "fldr: bad argument";
+    if (code == FLDR_E_SHAPE) return "fldr: shape constraint violated";
+    if (code > 0) return hipGetErrorString((hipError_t)code);
+    return "fldr: unknown error";
+}

@@ -1,0 +1,131 @@
+// Low-dimensional feature projection (pca_comp.py:473-528): an 8x8 / stride-8 block projection onto K<=16
+// components in fp64, followed by a GLOBAL min/max rescale to [-1,1].
+//
+// HBM-bound: 64 fp32 pixels in, K values out per block.  One thread per 8x8 block; a wave covers 64
+// consecutive blocks of one block-row, so each of the 8 row reads of a wave is a contiguous 2-KiB
+// segment (2 x dwordx4 per lane) and each component store is a contiguous 256-B (fp32) segment.  The
+// projection matrix is read through wave-uniform (scalar) loads.  Two passes over the planes instead of
+// one pass + an fp64 intermediate: the second read of a 4K level-0 input (212 MB) is served largely from
+// the 256-MiB Infinity Cache, and no P*K*H*W/64 fp64 scratch is needed.
+#include "common.h"
+
+#define PCA_MAXK 16
+
+__device__ __forceinline__ double atomic_min_f64(double* addr, double v) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        if (__longlong_as_double(assumed) <= v) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+    return __longlong_as_double(old);
+}
+__device__ __forceinline__ double atomic_max_f64(double* addr, double v) {
+    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
+    unsigned long long old = *a, assumed;
+    do {
+        assumed = old;
+        if (__longlong_as_double(assumed) >= v) break;
+        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
+    } while (assumed != old);
+    return __longlong_as_double(old);
+}
+
+__global__ void pca_init_minmax(double* mm) { mm[0] = 1.0e300; mm[1] = -1.0e300; }
+
+// y[k] for the 8x8 block (bx,by) of plane p, fp64; same code in both passes => bit-identical values.
+template <int K>
+__device__ __forceinline__ void pca_block(const float* __restrict__ plane, int W, int bx, int by,
+                                          const double* __restrict__ ev, const double* __restrict__ mean,
+                                          const double* __restrict__ mv, double (&y)[K]) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) y[k] = 0.0;
+    const float* p = plane + (int64_t)by * 8 * W + (int64_t)bx * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float4 a = *reinterpret_cast<const float4*>(p + (int64_t)i * W);
+        float4 b = *reinterpret_cast<const float4*>(p + (int64_t)i * W + 4);
+        double d[8] = {(double)a.x, (double)a.y, (double)a.z, (double)a.w, (double)b.x, (double)b.y, (double)b.z, (double)b.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d[j] -= mean[i * 8 + j];           // pca_comp.py:502
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) y[k] = fma(d[j], ev[k * 64 + i * 8 + j], y[k]);   // :507
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) y[k] = y[k] / mv[k];                  // :511
+}
+
+template <int K, int PASS>
+__global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ planes, const double* __restrict__ ev,
+                                                  const double* __restrict__ mean, const double* __restrict__ mv,
+                                                  double* __restrict__ mm, float* __restrict__ out32,
+                                                  double* __restrict__ out64, int H, int W) {
+    const int BW = W >> 3, BH = H >> 3;
+    int bx = blockIdx.x * 64 + (threadIdx.x & 63);
+    int by = blockIdx.y * 4 + (threadIdx.x >> 6);
+    int p = blockIdx.z;
+    bool live = bx < BW && by < BH;
+    double y[K];
+    if (live) pca_block<K>(planes + (int64_t)p * H * W, W, bx, by, ev, mean, mv, y);
+    if (PASS == 0) {
+        double lo = 1.0e300, hi = -1.0e300;
+        if (live) {
+#pragma unroll
+            for (int k = 0; k < K; ++k) { lo = y[k] < lo ? y[k] : lo; hi = y[k] > hi ? y[k] : hi; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {                        // wave64 shuffle reduction
+            double ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+            lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+        }
+        __shared__ double slo[4], shi[4];
+        if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < 4; ++i) { lo = slo[i] < lo ? slo[i] : lo; hi = shi[i] > hi ? shi[i] : hi; }
+            atomic_min_f64(mm, lo);
+            atomic_max_f64(mm + 1, hi);
+        }
+    } else {
+#pragma clang fp contract(off)
+        if (!live) return;
+        const double mi = mm[0], range = mm[1] - mm[0];
+        const int64_t BHW = (int64_t)BH * BW;
+        const int64_t o = ((int64_t)p * K) * BHW + (int64_t)by * BW + bx;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            double v = ((y[k] - mi) / range) * 2.0 - 1.0;               // pca_comp.py:523-526
+            if (out32) out32[o + (int64_t)k * BHW] = (float)v;          // fLDRnet.py:146 .float()
+            if (out64) out64[o + (int64_t)k * BHW] = v;
+        }
+    }
+}
+
+template <int K>
+static void pca_launch(const float* planes, const double* ev, const double* mean, const double* mv, float* o32, double* o64,
+                       double* mm, int P, int H, int W, hipStream_t s) {
+    dim3 grid(fldr_cdiv(W / 8, 64), fldr_cdiv(H / 8, 4), P);
+    hipLaunchKernelGGL(pca_init_minmax, dim3(1), dim3(1), 0, s, mm);
+    hipLaunchKernelGGL((pca_kernel<K, 0>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W);
+    hipLaunchKernelGGL((pca_kernel<K, 1>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W);
+}
+
+extern "C" int fldr_pca_project(const float* planes, const double* ev, const double* mean, const double* meanvec,
+                                float* out_f32, double* out_f64_or_null, double* minmax_ws,
+                                int P, int K, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(planes && ev && mean && meanvec && minmax_ws && (out_f32 || out_f64_or_null) && P > 0 && H > 0 && W > 0);
+    if (H % 8 != 0 || W % 8 != 0) return FLDR_E_SHAPE;                // pca_comp.py:486-487
+    if (((uintptr_t)planes & 15) != 0) return FLDR_E_ARG;              // dwordx4 row loads
+    hipStream_t s = fldr_s(stream);
+    switch (K) {
+        case 16: pca_launch<16>(planes, ev, mean, meanvec, out_f32, out_f64_or_null, minmax_ws, P, H, W, s); break;
+        case 8:  pca_launch<8>(planes, ev, mean, meanvec, out_f32, out_f64_or_null, minmax_ws, P, H, W, s); break;
+        case 4:  pca_launch<4>(planes, ev, mean, meanvec, out_f32, out_f64_or_null, minmax_ws, P, H, W, s); break;
+        default: return FLDR_E_ARG;
+    }
+    FLDR_LAUNCH_RET();
+}

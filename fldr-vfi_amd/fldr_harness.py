@@ -1,0 +1,145 @@
+"""Host-side callers of the hot path, mirroring the reference's drivers:
+`args_config` / `prepare_model` / `run_on_images` of run_on_your_images.py (:54-73, :96-178, :183-203) and the
+body of main.test() (main.py:833-911) — argument namespace, checkpoint loading, reflect padding, bicubic
+pyramid, the model call, crop / de-normalise / round and PSNR.  No cv2 / skimage / argparse side effects.
+"""
+import math
+import os
+from argparse import Namespace
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from pca_comp import DCTParams
+from useful import getmodelconfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_WEIGHTS = os.path.join(_HERE, "weights", "fLDRnet_X4K1000FPS_exp1_best_PSNR.npz")
+
+
+def args_config(gpu=0):
+    """The namespace `run_on_your_images.args_config()` produces (--papermodel --test5scales)."""
+    from fLDRnet import DCTXVFInet
+    a = Namespace(
+        gpu=gpu, net_type='fLDRnet', exp_num=1, text_dir='./text_dir', checkpoint_dir='./checkpoint_dir',
+        dataset='X4K1000FPS', test5scales=True, parameters=-1, save_images=False,
+        softsplat=False, ownsmooth=False, forwendflowloss=False, ownoccl=False, sminterp=False, sminterpWT=False,
+        tparam=1, noResidAddup=False, cutoffUnnec=False, fixsmoothtwistup=False, impmasksoftsplat=False,
+        TOptimization=False, sminterpInpIm=False, tempAdamfix=False, simpleEVs=False, smallenrefine=False,
+        interpOrigForw=False, interpBackwForw=False, inter4k_stepsize=16, noPCA=False, tempbottomflowfix=False,
+        pcanet=False, net_object=DCTXVFInet, dctvfi_nf=16, scales=[4, 8, 16, 32, 64, 128],
+        fractions=[1, 4, 16, 64, 256, 1024], ref_feat_extrac=False, maskLess=False, imageUpInp=False, allImUp=False,
+        ExacOneEV=False, papermodel=True, validation_patch_size=512, meanVecParam=True, align_cornerse=False,
+        takeBestModel=True, oneEV=False, optimizeEV=False, noEVOptimization=False, moreTstSc=False,
+        padding="reflective", XVFIPSNR=False, continue_training=False, specificCheckpoint=-1, img_ch=3, nf=64,
+        S_trn=3, S_tst=5, timetest=False, testgetflowout=False, outMaskLess=False,
+    )
+    getmodelconfig(a)                                   # run_on_your_images.py:190-191
+    a.fractions = [4, 16, 64, 256, 1024, 4096]          # :193-203
+    a.scales = [8, 16, 32, 64, 128, 256]
+    a.moreTstSc = True
+    a.phase = "test"
+    a.S_tst = 5
+    a.dctvfi_nf = a.scales[0] ** 2 // a.fractions[0]
+    a.padding = "reflect"
+    a.takeBestModel = True
+    return a
+
+
+def npz_state_dict(path=DEFAULT_WEIGHTS):
+    """Plain-tensor re-export of the shipped checkpoint -> a state dict `load_state_dict(strict=True)` accepts:
+    restores the base_modules.* aliases and the unused (all-zero / never-read) entries."""
+    z = np.load(path)
+    sd = {k: torch.from_numpy(z[k]) for k in z.files}
+    for k in list(sd):
+        if k.startswith("rec_ctx_ds."):
+            sd["base_modules.0." + k[len("rec_ctx_ds."):]] = sd[k]
+        elif k.startswith("vfinet."):
+            sd["base_modules.1." + k[len("vfinet."):]] = sd[k]
+    return sd
+
+
+def prepare_model(device=None, weights=DEFAULT_WEIGHTS, args=None):
+    """run_on_your_images.prepare_model (:54-73) without the save_manager side effects."""
+    args = args or args_config()
+    device = device or torch.device('cuda:' + str(args.gpu))
+    model = args.net_object(args)
+    sd = npz_state_dict(weights)
+    own = model.state_dict()
+    for k, v in own.items():          # entries the export dropped: zero-filled, shape from the module
+        if k not in sd:
+            sd[k] = torch.zeros_like(v)
+    model.load_state_dict(sd, strict=True)
+    model.save_params([DCTParams(wiS=8, components_fraction=1 / 4, data_used=0.5) for _ in range(len(args.scales))])
+    model.to(device).eval()
+    return model, device, args
+
+
+def pad_frames(frames, args):
+    """[B,C,T,H,W] -> reflect-padded to multiples of 2^S_tst*8 on the [B,C*T,H,W] view (main.py:840-849)."""
+    B, C, T, H, W = frames.shape
+    div = (2 ** args.S_tst) * 8 if args.phase == "test" else (2 ** args.S_trn) * 8
+    ph = (div - H % div) % div
+    pw = (div - W % div) % div
+    x = F.pad(frames.reshape(B, C * T, H, W), (0, pw, 0, ph), args.padding)
+    return x.reshape(B, C, T, H + ph, W + pw)
+
+
+def build_pyramid(frames_padded, args):
+    """Direct (non-cascaded) bicubic downscales by 2^-i (main.py:855-856)."""
+    B, C, T, H, W = frames_padded.shape
+    flat = frames_padded.permute(0, 2, 1, 3, 4).reshape(B * T, C, H, W)
+    pyr = [frames_padded]
+    for i in range(1, args.S_tst + 1):
+        s = args.scales[0] / args.scales[i]
+        d = F.interpolate(flat, scale_factor=s, mode='bicubic', align_corners=args.align_cornerse)
+        pyr.append(d.reshape(B, T, C, int(H * s), int(W * s)).permute(0, 2, 1, 3, 4).contiguous())
+    return pyr
+
+
+def interpolate(model, args, frames, t_value, pyramid=None):
+    """One (pair, t) forward as main.test()/run_on_images do it.  frames [B,3,2,H,W] in [-1,1] on the model's
+    device; t_value [B,1].  Returns the fp64 prediction cropped to the original H x W."""
+    B, C, T, OH, OW = frames.shape
+    with torch.no_grad():
+        if pyramid is None:
+            pyramid = build_pyramid(pad_frames(frames, args), args)
+        dummy = [None] * (args.S_tst + 1)          # the reference passes zero tensors that are overwritten (fLDRnet.py:134)
+        pred, _ = model(dummy, t_value, normInput=pyramid, is_training=False, validation=False)
+    return pred[:, :, :OH, :OW]
+
+
+def to_uint8_image(pred):
+    """[3,H,W] in [-1,1] -> rounded [H,W,3] in [0,255] (main.py:885-894, utils.py:685-688)."""
+    p = np.asarray(pred.detach().cpu() if torch.is_tensor(pred) else pred, dtype=np.float64)
+    return np.around(((np.transpose(p, [1, 2, 0]) + 1.0) / 2.0).clip(0.0, 1.0) * 255.0)
+
+
+def psnr(img_true, img_pred):
+    """utils.psnr with XVFIPSNR False (utils.py:644-652): data_range 255 over all channels."""
+    err = np.mean((np.asarray(img_true, dtype=np.float64) - np.asarray(img_pred, dtype=np.float64)) ** 2)
+    return float("inf") if err == 0 else 10 * math.log10(255.0 ** 2 / err)
+
+
+def frames_from_uint8(u8):
+    """[2,3,H,W] uint8 (I0, I1) -> [1,3,2,H,W] fp32 in [-1,1] (run_on_your_images.py:84-87)."""
+    return ((u8.float() / 255) * 2 - 1).permute(1, 0, 2, 3).unsqueeze(0).contiguous()
+
+
+def synthetic_pair(H, W, seed=0, quadrant=False, device="cpu"):
+    """Seeded synthetic uint8 frame pair used by bench.py and the tests: a smooth random base
+    image; I1 is I0 shifted by (6,4) px, or by (+-12,+-8) px per quadrant to force occlusions/holes."""
+    g = torch.Generator().manual_seed(seed)
+    base = F.avg_pool2d(torch.rand(1, 3, H + 48, W + 48, generator=g), 5, 1, 2)
+    I0 = base[..., 16:H + 16, 16:W + 16]
+    if not quadrant:
+        I1 = base[..., 20:H + 20, 22:W + 22]
+    else:
+        I1 = I0.clone()
+        h2, w2 = H // 2, W // 2
+        for (ys, xs, dy, dx) in ((0, 0, 8, 12), (0, 1, -8, 12), (1, 0, 8, -12), (1, 1, -8, -12)):
+            y0, x0 = ys * h2, xs * w2
+            I1[..., y0:y0 + h2, x0:x0 + w2] = base[..., 16 + y0 + dy:16 + y0 + dy + h2, 16 + x0 + dx:16 + x0 + dx + w2]
+    u8 = lambda a: (a.clamp(0, 1) * 255).round().to(torch.uint8)
+    return torch.stack([u8(I0[0]), u8(I1[0])], 0).to(device)

@@ -1,0 +1,303 @@
+"""ctypes binding of libfldr_hip.so (C ABI: include/fldr_hip.h).
+
+This is the stub that replaces the reference's CuPy launch plumbing
+(`cupy_kernel` / `cupy_launch`, softSplat.py:160-218, correlation.py:245-289):
+no source specialisation, no JIT, kernels are enqueued on torch's current HIP
+stream.  There is NO fallback: if the shared library is missing or a tensor is
+not a CUDA(HIP) tensor the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfldr_hip.so")
+
+MAX_SRC = 12
+_c_float_p = ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("src", ctypes.c_void_p * MAX_SRC),
+        ("src_bstride", ctypes.c_int64 * MAX_SRC),
+        ("src_c", ctypes.c_int32 * MAX_SRC),
+        ("src_up2", ctypes.c_int32 * MAX_SRC),
+        ("n_src", ctypes.c_int32),
+        ("wpack", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("out", ctypes.c_void_p),
+        ("N", ctypes.c_int32), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_store", ctypes.c_int32),
+        ("Hin", ctypes.c_int32), ("Win", ctypes.c_int32), ("Hout", ctypes.c_int32), ("Wout", ctypes.c_int32),
+        ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
+    ]
+
+
+_SIGNATURES = {
+    "fldr_version": (ctypes.c_int, []),
+    "fldr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+    "fldr_softsplat_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_softsplat_fused": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_pca_project": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
+    "fldr_resize_bilinear": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
+    "fldr_zmetric": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_float, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_conv_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "fldr_conv_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fldr_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                       _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libfldr_hip.so is missing at %s — build it with `make -C fldr-vfi_amd/csrc` "
+                              "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU/eager fallback."
+                              % LIB_PATH)
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+class FldrError(RuntimeError):
+    pass
+
+
+def _check(code, what):
+    if code != 0:
+        raise FldrError("%s failed: %s (code %d)" % (what, lib().fldr_error_string(code).decode(), code))
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, dtype=torch.float32):
+    if not t.is_cuda:
+        raise NotImplementedError("%s: fldr_hip has no CPU path (the reference has none either, softSplat.py:251-252)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---------------------------------------------------------------------------------------------
+# operators
+# ---------------------------------------------------------------------------------------------
+
+def softsplat_fwd(inp, flow):
+    """_FunctionSoftsplat.forward (softSplat.py:222-258)."""
+    N, C, H, W = inp.shape
+    assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W      # softSplat.py:227-229
+    inp, flow = inp.contiguous(), flow.contiguous()
+    out = inp.new_zeros(N, C, H, W)
+    _check(lib().fldr_softsplat_fwd(_dev(inp, "input"), _dev(flow, "flow"), _dev(out, "output"), N, C, H, W, _stream()),
+           "fldr_softsplat_fwd")
+    return out
+
+
+_MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
+
+
+def softsplat_fused(img, flow, metric, mode, out=None, scratch=None):
+    """FunctionSoftsplat (softSplat.py:320-352)."""
+    N, C, H, W = img.shape
+    assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W
+    img, flow = img.contiguous(), flow.contiguous()
+    if metric is not None:
+        metric = metric.contiguous()
+    ca = C + (0 if mode == "summation" else 1)
+    if scratch is None:
+        scratch = torch.empty(N * ca * H * W, device=img.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
+    _check(lib().fldr_softsplat_fused(_dev(img, "img"), _dev(flow, "flow"),
+                                      _dev(metric, "metric") if metric is not None else None,
+                                      _dev(out, "out"), _dev(scratch, "scratch"), N, C, H, W, _MODES[mode], _stream()),
+           "fldr_softsplat_fused")
+    return out
+
+
+def correlation_fwd(a, b):
+    N, C, H, W = a.shape
+    assert b.shape == a.shape
+    out = torch.empty(N, 81, H, W, device=a.device, dtype=torch.float32)
+    _check(lib().fldr_correlation_fwd(_dev(a, "first"), _dev(b, "second"), _dev(out, "out"), N, C, H, W, _stream()),
+           "fldr_correlation_fwd")
+    return out
+
+
+def pca_project(planes, ev, mean, meanvec, want_f64=False, want_f32=True):
+    P, H, W = planes.shape
+    K = ev.shape[0]
+    planes = planes.contiguous()
+    o32 = torch.empty(P * K, H // 8, W // 8, device=planes.device, dtype=torch.float32) if want_f32 else None
+    o64 = torch.empty(P * K, H // 8, W // 8, device=planes.device, dtype=torch.float64) if want_f64 else None
+    mm = torch.empty(2, device=planes.device, dtype=torch.float64)
+    code = lib().fldr_pca_project(_dev(planes, "planes"), _dev(ev, "EV", torch.float64), _dev(mean, "mean", torch.float64),
+                                  _dev(meanvec, "mean_vec", torch.float64),
+                                  _dev(o32, "out") if want_f32 else None,
+                                  _dev(o64, "out64", torch.float64) if want_f64 else None,
+                                  _dev(mm, "minmax", torch.float64), P, K, H, W, _stream())
+    if code == -2:
+        raise Exception("in to_pca_diff the image is not padded right." + str(H) + " " + str(W))   # pca_comp.py:487
+    _check(code, "fldr_pca_project")
+    return o32, o64, mm
+
+
+def bwarp(x, flo, withmask=True):
+    N, C, H, W = x.shape
+    assert flo.shape == (N, 2, H, W)
+    x, flo = x.contiguous(), flo.contiguous()
+    out = torch.empty_like(x)
+    _check(lib().fldr_bwarp(_dev(x, "x"), _dev(flo, "flo"), _dev(out, "out"), N, C, H, W, int(bool(withmask)), _stream()),
+           "fldr_bwarp")
+    return out
+
+
+_TMODE = {None: 0, "1": 0, "t": 1, "1-t": 2}
+
+
+def bwarp_tscaled(x, flo, t, x_scale, flo_scale, withmask=True):
+    """bwarp(sx * x, sf * flo), sx/sf in {None, 't', '1-t'} per sample (fLDRnet.py:474-475)."""
+    N, C, H, W = x.shape
+    assert flo.shape == (N, 2, H, W)
+    x, flo = x.contiguous(), flo.contiguous()
+    t = t.reshape(N).contiguous().float()
+    out = torch.empty_like(x)
+    _check(lib().fldr_bwarp_tscaled(_dev(x, "x"), _dev(flo, "flo"), _dev(out, "out"), _dev(t, "t"), _TMODE[x_scale],
+                                    _TMODE[flo_scale], N, C, H, W, int(bool(withmask)), _stream()), "fldr_bwarp_tscaled")
+    return out
+
+
+def resize_bilinear(x, H, W, mul=1.0):
+    N, C, h, w = x.shape
+    x = x.contiguous()
+    out = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
+    _check(lib().fldr_resize_bilinear(_dev(x, "in"), _dev(out, "out"), N * C, h, w, H, W, float(mul), _stream()),
+           "fldr_resize_bilinear")
+    return out
+
+
+def zmetric(self_img, other_img, flow, alpha):
+    N, C, H, W = self_img.shape
+    self_img, other_img, flow = self_img.contiguous(), other_img.contiguous(), flow.contiguous()
+    z = torch.empty(N, 1, H, W, device=self_img.device, dtype=torch.float32)
+    _check(lib().fldr_zmetric(_dev(self_img, "self"), _dev(other_img, "other"), _dev(flow, "flow"), float(alpha),
+                              _dev(z, "z"), N, C, H, W, _stream()), "fldr_zmetric")
+    return z
+
+
+_PACK_CACHE = {}
+
+
+def conv_prepack(weight):
+    """Repack an nn.Conv2d weight for fldr_conv2d; cached per (storage, version)."""
+    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device.index)
+    hit = _PACK_CACHE.get(key)
+    if hit is not None:
+        return hit
+    cout, cin, k, k2 = weight.shape
+    assert k == k2
+    n = lib().fldr_conv_prepack_size(cout, cin, k)
+    if n < 0:
+        raise FldrError("unsupported convolution shape %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    _check(lib().fldr_conv_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, k, _stream()), "fldr_conv_prepack")
+    if len(_PACK_CACHE) > 256:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = wp
+    return wp
+
+
+def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=None, up2=None, out=None):
+    """conv(cat(srcs, 1)) with optional fused nearest-x2 read per source, ReLU and post-activation residual.
+
+    srcs: list of [N,c_s,H_s,W_s] fp32 tensors whose (N, c, h, w) block may be a batch-strided view
+    (e.g. feat[:, :48]) as long as each sample's [c,h,w] block is contiguous."""
+    cout, cin, k, _ = weight.shape
+    up2 = up2 or [False] * len(srcs)
+    N = srcs[0].shape[0]
+    Hin = srcs[0].shape[2] * (2 if up2[0] else 1)
+    Win = srcs[0].shape[3] * (2 if up2[0] else 1)
+    d = ConvDesc()
+    keep = []
+    csum = 0
+    for i, (s, u) in enumerate(zip(srcs, up2)):
+        if not s.is_cuda:
+            raise NotImplementedError("fldr conv2d has no CPU path")
+        if s.dtype != torch.float32:
+            raise TypeError("conv source must be float32")
+        if s[0].is_contiguous() is False:
+            s = s.contiguous()
+        keep.append(s)
+        assert s.shape[0] == N and s.shape[2] * (2 if u else 1) == Hin and s.shape[3] * (2 if u else 1) == Win
+        d.src[i] = s.data_ptr()
+        d.src_bstride[i] = s.stride(0) if N > 1 else 0
+        d.src_c[i] = s.shape[1]
+        d.src_up2[i] = int(bool(u))
+        csum += s.shape[1]
+    assert csum == cin, "concatenated channels %d != weight cin %d" % (csum, cin)
+    d.n_src = len(srcs)
+    if k == 3 and stride == 1:
+        Hout, Wout = Hin, Win
+    elif k == 4 and stride == 2:
+        Hout, Wout = (Hin + 2 - 4) // 2 + 1, (Win + 2 - 4) // 2 + 1
+    else:
+        raise FldrError("unsupported convolution k=%d stride=%d" % (k, stride))
+    cs = cout if cout_store is None else cout_store
+    if out is None:
+        out = torch.empty(N, cs, Hout, Wout, device=srcs[0].device, dtype=torch.float32)
+    wp = conv_prepack(weight)
+    d.wpack = wp.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == out.shape
+        d.residual = residual.data_ptr()
+    d.out = _dev(out, "out").value
+    d.N, d.cin, d.cout, d.cout_store = N, cin, cout, cs
+    d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
+    d.ksize, d.stride, d.relu, d.precision = k, stride, int(bool(relu)), 0
+    _check(lib().fldr_conv2d(ctypes.byref(d), _stream()), "fldr_conv2d")
+    return out
+
+
+def synth_tail(refine, cands, t, T_param, out_dtype=torch.float64):
+    N, six, H, W = refine.shape
+    assert six == 6 and len(cands) == 6
+    refine = refine.contiguous()
+    ptrs = (ctypes.c_void_p * 6)()
+    strides = (ctypes.c_int64 * 6)()
+    keep = []
+    for k, c in enumerate(cands):
+        assert c.shape == (N, 3, H, W)
+        if not c[0].is_contiguous():
+            c = c.contiguous()
+        keep.append(c)
+        ptrs[k] = _dev(c[0], "candidate").value
+        strides[k] = c.stride(0) if N > 1 else 0
+    t = t.reshape(N).contiguous().float()
+    out = torch.empty(N, 3, H, W, device=refine.device, dtype=out_dtype)
+    o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
+    o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
+    _check(lib().fldr_synth_tail(_dev(refine, "refine"), ptrs, strides, _dev(t, "t"), float(T_param), o64, o32,
+                                 N, H, W, _stream()), "fldr_synth_tail")
+    return out

@@ -1,0 +1,158 @@
+/*
+ * fldr_hip.h — C ABI of libfldr_hip.so, the MI355X (gfx950) kernels behind the
+ * fLDRnet per-frame-pair inference path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers and sizes, enqueues
+ * work on the HIP stream it is given (NULL = the null stream) and returns 0 on success or a
+ * negative FLDR_E_* / positive hipError_t code; nothing throws, nothing synchronises, nothing
+ * allocates (callers own all buffers, as in the reference: softSplat.py:231-234,
+ * correlation.py:297-305).  All tensors are contiguous NCHW fp32 unless noted.
+ *
+ * Each declaration cites the reference interface (file:line in visinf/fldr-vfi) it replaces.
+ * The reference binds its kernels through CuPy (`cupy.RawModule(...).get_function`,
+ * softSplat.py:215-218); the binding a maintainer would add instead is the ctypes stub in
+ * INTEGRATION.md (and fldr-vfi_amd/fldr_hip.py is exactly that stub).
+ */
+#ifndef FLDR_HIP_H
+#define FLDR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FLDR_VERSION 100          /* major*10000 + minor*100 + patch */
+
+#define FLDR_E_ARG   (-1)         /* bad argument (null pointer, non-positive size, unsupported shape) */
+#define FLDR_E_SHAPE (-2)         /* shape constraint violated (e.g. H,W not multiples of 8 for the PCA) */
+
+typedef void* fldr_stream_t;      /* hipStream_t; torch.cuda.current_stream().cuda_stream */
+
+int         fldr_version(void);
+const char* fldr_error_string(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Softmax splatting — replaces softSplat.py.
+ * ------------------------------------------------------------------------------------------ */
+
+/* kernel_Softsplat_updateOutput (softSplat.py:12-52) as launched by _FunctionSoftsplat.forward
+ * (softSplat.py:222-258): out[n,c,y',x'] += in[n,c,y,x] * bilinear weight of (x+fx, y+fy).
+ * `out_zeroed` must be zero on entry (the reference allocates it with new_zeros, :234).
+ * flow is [N,2,H,W], channel 0 = x displacement, 1 = y displacement, in pixels. */
+int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
+                       int N, int C, int H, int W, fldr_stream_t stream);
+
+/* FunctionSoftsplat (softSplat.py:320-352) end to end.  mode: 0 summation, 1 average, 2 linear,
+ * 3 softmax.  metric is [N,1,H,W] or NULL (softmax with NULL metric = weight 1, :335-336).
+ * scratch: N*(C+1)*H*W floats (the (C+1)-channel accumulator); contents are overwritten.
+ * out: [N,C,H,W].  Includes the reference's pre-scale (x+1)/2 (softmax only, :334), the
+ * zero-norm -> 1 rule (:346) and the post-scale (x-0.5)*2 (every mode, :349). */
+int fldr_softsplat_fused(const float* img, const float* flow, const float* metric_or_null,
+                         float* out, float* scratch, int N, int C, int H, int W, int mode,
+                         fldr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * PWC cost volume — replaces OpticalFlow/correlation.py (forward only).
+ * ------------------------------------------------------------------------------------------ */
+
+/* _FunctionCorrelation.forward (correlation.py:294-348; kernels :17-112):
+ * out[n,(dy+4)*9+(dx+4),y,x] = (1/C) sum_c a[n,c,y,x] * b[n,c,y+dy,x+dx], zero padded, dy,dx in [-4,4].
+ * a, b: [N,C,H,W]; out: [N,81,H,W].  No rearranged NHWC copies are needed (the reference's
+ * rbot0/rbot1, :297-298, exist only for its one-block-per-pixel kernel). */
+int fldr_correlation_fwd(const float* a, const float* b, float* out,
+                         int N, int C, int H, int W, fldr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Low-dimensional feature projection — replaces pca_comp.to_pca_diff (pca_comp.py:473-528).
+ * ------------------------------------------------------------------------------------------ */
+
+/* planes [P,H,W] fp32 (P = 6*B planes in the order c*2+t, fLDRnet.py:146); ev [K,64], mean [64],
+ * meanvec [K] fp64 (K <= 16).  y[p*K+k,by,bx] = sum_{i,j} (x[p,8by+i,8bx+j]-mean[8i+j])*ev[k,8i+j]/meanvec[k]
+ * in fp64; then the GLOBAL min/max over all P*K*H/8*W/8 values maps y to [-1,1] (pca_comp.py:521-526).
+ * out_f32: [P*K,H/8,W/8] (the caller's .float() of fLDRnet.py:146); out_f64_or_null: same shape in
+ * fp64 (the function's own return value) when wanted.  minmax_ws: 2 doubles of workspace; on
+ * completion it holds {min, max}.  H and W must be multiples of 8 (pca_comp.py:486-487). */
+int fldr_pca_project(const float* planes, const double* ev, const double* mean, const double* meanvec,
+                     float* out_f32, double* out_f64_or_null, double* minmax_ws,
+                     int P, int K, int H, int W, fldr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Gathers and resizes — replace DCTVFInet.bwarp and the F.interpolate calls of fLDRnet.py.
+ * ------------------------------------------------------------------------------------------ */
+
+/* DCTVFInet.bwarp (fLDRnet.py:546-581): grid = pixel + flo, normalised with 2v/max(S-1,1)-1,
+ * F.grid_sample(bilinear, zeros, align_corners=False), times the {0,1} validity mask when
+ * withmask != 0 (mask = sampled ones, <0.999 -> 0, else 1).  No grid/ones tensors are built. */
+int fldr_bwarp(const float* x, const float* flo, float* out,
+               int N, int C, int H, int W, int withmask, fldr_stream_t stream);
+
+/* flowback of fLDRnet.py:474-475: bwarp(sx*x, sf*flo) with per-sample scales chosen by x_mode / flo_mode
+ * (0: 1, 1: t[n], 2: 1-t[n]); t is a device array of N floats.  The scaled tensors are never materialised. */
+int fldr_bwarp_tscaled(const float* x, const float* flo, float* out, const float* t, int x_mode, int flo_mode,
+                       int N, int C, int H, int W, int withmask, fldr_stream_t stream);
+
+/* F.interpolate(mode='bilinear', align_corners=False) from [NC,h,w] to [NC,H,W], result multiplied
+ * by `mul` (fLDRnet.py:384-385 with mul = W/w; :419-422 with mul = upscale). */
+int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int H, int W, float mul,
+                         fldr_stream_t stream);
+
+/* Splat metric of fLDRnet.py:442-446: z[n,0,y,x] = mean_c( alpha * |self[n,c,y,x] - bwarp(other, flow)[n,c,y,x]| ).
+ * self/other: [N,C,H,W]; flow [N,2,H,W]; z [N,1,H,W]. */
+int fldr_zmetric(const float* self_img, const float* other_img, const float* flow, float alpha, float* z,
+                 int N, int C, int H, int W, fldr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolutions — replace the nn.Conv2d stacks of fLDRnet.py (:44-49, :318-345, :611-617).
+ * ------------------------------------------------------------------------------------------ */
+
+#define FLDR_CONV_MAX_SRC 12
+
+/* One convolution whose input is the channel-concatenation of up to 12 sources (torch.cat along
+ * dim 1 is never materialised: fLDRnet.py:379, :389, :480, :633, :639).  A source flagged `up2`
+ * is stored at half resolution and read through nearest-neighbour x2 upsampling
+ * (nn.UpsamplingNearest2d, fLDRnet.py:592,632,638,642).
+ * out = act(conv(cat(src...), weight) + bias) [+ residual], act = ReLU when relu != 0.
+ * Only the first cout_store output channels are written (fLDRnet.py:380, [:, :4]). */
+typedef struct fldr_conv_desc {
+    const float* src[FLDR_CONV_MAX_SRC];       /* source s, sample n at src[s] + n*src_bstride[s] */
+    int64_t      src_bstride[FLDR_CONV_MAX_SRC];/* batch stride in floats */
+    int32_t      src_c[FLDR_CONV_MAX_SRC];     /* channels of source s */
+    int32_t      src_up2[FLDR_CONV_MAX_SRC];   /* 1: stored [c, Hin/2, Win/2], read nearest x2 */
+    int32_t      n_src;
+    const float* wpack;        /* weights prepacked by fldr_conv_prepack */
+    const float* bias;         /* [cout] or NULL */
+    const float* residual;     /* [N,cout_store,Hout,Wout] added after the activation, or NULL */
+    float*       out;          /* [N,cout_store,Hout,Wout] */
+    int32_t N, cin, cout, cout_store;
+    int32_t Hin, Win;          /* input size (after any x2 upsampling) */
+    int32_t Hout, Wout;
+    int32_t ksize;             /* 3 (stride 1, pad 1) or 4 (stride 2, pad 1) */
+    int32_t stride;
+    int32_t relu;
+    int32_t precision;         /* 0: fp32 MFMA (exact fp32 products, default); 1: fp16 inputs, fp32 accumulate */
+} fldr_conv_desc;
+
+/* Number of floats fldr_conv_prepack writes for a [cout,cin,k,k] weight. */
+int64_t fldr_conv_prepack_size(int cout, int cin, int ksize);
+/* Repack nn.Conv2d weight [cout,cin,k,k] (fp32, device) into the kernel's layout. */
+int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream);
+int fldr_conv2d(const fldr_conv_desc* desc, fldr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.
+ * ------------------------------------------------------------------------------------------ */
+
+/* occ = softmax(refine[:, 0:6] / T) over channels; out = sum_k w_k occ_k cand_k / sum_k w_k occ_k with
+ * w = (1-t, t, 1-t, t, 1-t, t) and cand = (warped0, warped1, im0_tot, im1_tot, I0, I1), all in fp64
+ * (T_param is a 1-D double tensor, so the reference's tail is fp64: SURVEY F3).
+ * refine [N,6,H,W]; the six candidates [N,3,H,W] with batch strides cand_bstride[k] (floats);
+ * t: per-sample fp32 value t[n].  Exactly one of out_f64 / out_f32 may be NULL. */
+int fldr_synth_tail(const float* refine, const float* const cand[6], const int64_t cand_bstride[6],
+                    const float* t, double T_param, double* out_f64, float* out_f32,
+                    int N, int H, int W, fldr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FLDR_HIP_H */

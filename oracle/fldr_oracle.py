@@ -336,7 +336,7 @@ def synthetic_pair(H, W, seed=0, quadrant=False):
     if not quadrant:
         I1 = base[..., 20:H + 20, 22:W + 22]
     else:
-        I1 = torch.empty_like(I0)
+        I1 = I0.clone()
         h2, w2 = H // 2, W // 2
         for (ys, xs, dy, dx) in ((0, 0, 8, 12), (0, 1, -8, 12), (1, 0, 8, -12), (1, 1, -8, -12)):
             y0, x0 = ys * h2, xs * w2

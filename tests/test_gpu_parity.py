@@ -1,0 +1,362 @@
+"""Parity tests proper: every operator and the whole frame-pair forward, through the C ABI (libfldr_hip.so via
+fldr_hip.py and the reference-named host modules), against the CPU oracle and the committed golden vectors.
+
+Tolerances (fp32 path; stated per test):
+  * gather / resize / PCA / tail kernels follow the oracle's operation order -> 1e-6 .. 1e-5 absolute;
+  * the splat uses fp32 atomics (order non-deterministic, as in the reference: SURVEY F9) -> 1e-5 relative
+    to the accumulated magnitude;
+  * convolutions: exact fp32 products, fp32 accumulation in a different order than MKL-DNN -> 2e-5 * sqrt(K);
+  * whole model: the coarse-to-fine cascade amplifies rounding; bound = 2e-3 on the [-1,1] frame (1/4 of an
+    8-bit step) and >= 60 dB PSNR between the rounded 8-bit frames.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _cmp(got, ref, atol, rtol=0.0, max_outlier_frac=0.0, what=""):
+    got = got.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    assert torch.isfinite(got).all(), what + ": non-finite values"
+    err = (got - ref).abs()
+    bad = err > (atol + rtol * ref.abs())
+    frac = bad.double().mean().item()
+    assert frac <= max_outlier_frac, "%s: %.3g of elements beyond tol, max err %.3e" % (what, frac, err.max().item())
+    return err.max().item()
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import fldr_hip
+    fldr_hip.lib()
+    return fldr_hip
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    import fldr_harness as Hn
+    m, _, a = Hn.prepare_model(dev)
+    return m, a
+
+
+def _gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+# ---------------------------------------------------------------------------------------------------
+# softmax splat
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(1, 3, 64, 96), (2, 5, 37, 91), (1, 49, 18, 30), (1, 1, 1, 1)])
+def test_splat_raw_matches_oracle(hip, oracle, dev, shape):
+    N, C, H, W = shape
+    g = _gen(1)
+    x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+    flow = (torch.rand(N, 2, H, W, generator=g) - 0.5) * 12
+    flow[:, :, :2] *= 40                                         # far out-of-range rows
+    import softSplat
+    out = softSplat._FunctionSoftsplat.apply(x.to(dev), flow.to(dev))
+    _cmp(out, oracle.splat_forward(x, flow), atol=2e-5, rtol=1e-5, what="splat raw")
+
+
+@pytest.mark.parametrize("mode", ["summation", "average", "linear", "softmax"])
+def test_function_softsplat_modes(hip, oracle, dev, mode):
+    import softSplat
+    g = _gen(2)
+    x = torch.rand(2, 4, 33, 70, generator=g) * 2 - 1
+    flow = (torch.rand(2, 2, 33, 70, generator=g) - 0.5) * 9
+    z = torch.randn(2, 1, 33, 70, generator=g) if mode in ("linear", "softmax") else None
+    if mode == "linear":
+        z = z.abs() + 0.1
+    out = softSplat.FunctionSoftsplat(x.to(dev), flow.to(dev), None if z is None else z.to(dev), mode)
+    _cmp(out, oracle.function_softsplat(x, flow, z, mode), atol=3e-5, rtol=1e-5, what=mode)
+    if mode == "softmax":
+        out = softSplat.Softsplat()(x.to(dev), flow.to(dev))
+        _cmp(out, oracle.function_softsplat(x, flow, None, mode), atol=3e-5, what="softmax no metric")
+
+
+def test_splat_known_answers(hip, dev):
+    import softSplat
+    sp = softSplat.Softsplat()
+    x = (torch.rand(1, 3, 9, 11, generator=_gen(3)) * 2 - 1).to(dev)
+    _cmp(sp(x, torch.zeros(1, 2, 9, 11, device=dev)), x, atol=1e-6, what="zero flow identity")
+    flow = torch.zeros(1, 2, 9, 11, device=dev)
+    flow[:, 0], flow[:, 1] = 2.0, -1.0
+    out = sp(x, flow)
+    _cmp(out[..., :8, 2:], x[..., 1:, :9], atol=1e-6, what="integer shift")
+    assert (out[..., :, :2] == -1).all() and (out[..., 8, :] == -1).all()            # holes -> -1
+    img = torch.zeros(1, 1, 1, 4, device=dev)
+    img[0, 0, 0, 0], img[0, 0, 0, 2] = -1.0, 1.0
+    fl = torch.zeros(1, 2, 1, 4, device=dev)
+    fl[0, 0, 0, 0], fl[0, 0, 0, 2], fl[0, 0, 0, 1] = 1.0, -1.0, 2.0
+    z = torch.zeros(1, 1, 1, 4, device=dev)
+    z[0, 0, 0, 2] = math.log(3.0)
+    assert abs(sp(img, fl, z)[0, 0, 0, 1].item() - 0.5) < 1e-6                       # 1:3 softmax mix
+
+
+# ---------------------------------------------------------------------------------------------------
+# cost volume
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 16, 20, 28), (1, 81, 13, 45), (2, 196, 9, 15), (1, 3, 64, 96)])
+def test_correlation_matches_oracle(hip, oracle, dev, shape):
+    from OpticalFlow import correlation
+    g = _gen(4)
+    a = torch.randn(*shape, generator=g)
+    b = torch.randn(*shape, generator=g)
+    out = correlation.FunctionCorrelation(a.to(dev), b.to(dev))
+    _cmp(out, oracle.correlation(a, b), atol=2e-6 * math.sqrt(shape[1]) + 1e-6, rtol=1e-5, what="correlation")
+    out2 = correlation.ModuleCorrelation()(a.to(dev), a.to(dev))
+    _cmp(out2[:, 40], (a * a).mean(1), atol=1e-5, what="centre channel = mean square")
+    assert out2[0, 0, 0, 0].item() == 0.0                                           # zero padding
+
+
+# ---------------------------------------------------------------------------------------------------
+# PCA projection
+# ---------------------------------------------------------------------------------------------------
+def test_pca_matches_reference_golden_and_oracle(hip, oracle, weights, golden, dev, model):
+    import pca_comp
+    m, a = model
+    g = golden("ops")
+    pl = torch.from_numpy(g["pca_in"])
+    out64 = pca_comp.to_pca_diff(pl.to(dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8)
+    assert out64.dtype == torch.float64 and out64.shape == (96, 4, 6)
+    _cmp(out64, torch.from_numpy(g["pca_out"]), atol=1e-12, what="to_pca_diff vs reference")
+    assert out64.min().item() == -1.0 and out64.max().item() == 1.0
+    big = torch.rand(12, 72, 136, generator=_gen(5)) * 2 - 1        # B=2: one global min/max over the batch
+    ref = oracle.to_pca_diff(big, weights["Mean8"], weights["EV8"], weights["meanVec8"])
+    _cmp(pca_comp.to_pca_diff(big.to(dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8), ref, atol=1e-12, what="pca f64")
+    _cmp(pca_comp.to_pca_diff_f32(big.to(dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8), ref.float(), atol=0.0,
+         what="pca f32 (bit exact after the cast)", max_outlier_frac=1e-4)
+    with pytest.raises(Exception, match="not padded right"):
+        pca_comp.to_pca_diff(torch.zeros(6, 20, 16, device=dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8)
+
+
+# ---------------------------------------------------------------------------------------------------
+# backward warp, splat metric, resize
+# ---------------------------------------------------------------------------------------------------
+def test_bwarp_matches_reference_golden(hip, golden, dev, model):
+    m, _ = model
+    g = golden("ops")
+    x, flo = torch.from_numpy(g["bwarp_x"]).to(dev), torch.from_numpy(g["bwarp_flo"]).to(dev)
+    _cmp(m.vfinet.bwarp(x, flo, withmask=True), torch.from_numpy(g["bwarp_out"]), atol=2e-6, max_outlier_frac=2e-3,
+         what="bwarp mask")
+    _cmp(m.vfinet.bwarp(x, flo, withmask=False), torch.from_numpy(g["bwarp_out_nomask"]), atol=2e-6, what="bwarp nomask")
+
+
+def test_bwarp_tscaled_zmetric_resize(hip, oracle, dev):
+    g = _gen(6)
+    N, H, W = 2, 45, 83
+    I0 = torch.rand(N, 3, H, W, generator=g) * 2 - 1
+    I1 = torch.rand(N, 3, H, W, generator=g) * 2 - 1
+    f10 = (torch.rand(N, 2, H, W, generator=g) - 0.5) * 14
+    f01 = (torch.rand(N, 2, H, W, generator=g) - 0.5) * 14
+    t = torch.tensor([0.125, 0.7]).view(N, 1, 1, 1)
+    ref = oracle.bwarp(f10 * t, (1 - t) * f01)
+    got = hip.bwarp_tscaled(f10.to(dev), f01.to(dev), t.to(dev), "t", "1-t")
+    _cmp(got, ref, atol=1e-5, max_outlier_frac=2e-3, what="flowback_0")
+    ref = oracle.bwarp(f01 * (1 - t), t * f10)
+    _cmp(hip.bwarp_tscaled(f01.to(dev), f10.to(dev), t.to(dev), "1-t", "t"), ref, atol=1e-5, max_outlier_frac=2e-3,
+         what="flowback_1")
+    alpha = -1.894
+    zref = torch.mean(alpha * torch.abs(I0 - oracle.bwarp(I1, f01)), dim=1, keepdim=True)
+    _cmp(hip.zmetric(I0.to(dev), I1.to(dev), f01.to(dev), alpha), zref, atol=2e-6, max_outlier_frac=2e-3, what="zmetric")
+    lo = torch.randn(N, 4, 9, 15, generator=g)
+    _cmp(hip.resize_bilinear(lo.to(dev), 18, 30, mul=2.0),
+         F.interpolate(lo, size=(18, 30), mode="bilinear", align_corners=False) * 2.0, atol=1e-6, what="resize x2")
+    _cmp(hip.resize_bilinear(lo.to(dev), 72, 120, mul=8.0),
+         8 * F.interpolate(lo, scale_factor=(8, 8), mode="bilinear", align_corners=False), atol=4e-6, what="resize x8")
+    _cmp(hip.resize_bilinear(lo.to(dev), 20, 37), F.interpolate(lo, size=(20, 37), mode="bilinear", align_corners=False),
+         atol=1e-6, what="resize ragged")
+
+
+# ---------------------------------------------------------------------------------------------------
+# convolutions
+# ---------------------------------------------------------------------------------------------------
+CONVS = [  # cin parts, cout, k, stride, relu, residual, cout_store, up2 flags
+    ([96], 96, 3, 1, True, True, None, None),            # rec_ctx_ds.2 (+ residual)
+    ([48, 48], 48, 3, 1, False, False, None, None),      # conv_flow1 on cat(feat, warped)
+    ([48, 48, 4], 96, 3, 1, True, False, None, None),    # conv_flow2.0 on a 100-channel cat
+    ([48], 6, 3, 1, False, False, 4, None),              # conv_flow_bottom.8, first 4 channels
+    ([48], 4, 3, 1, False, True, None, None),            # conv_flow2.8 + up_flow
+    ([3, 3, 3, 3, 2, 2, 2, 2, 3, 3], 16, 4, 2, True, False, None, None),   # enc1 on the 26-channel cat
+    ([16], 32, 4, 2, True, False, None, None),           # enc2
+    ([32], 64, 4, 2, True, False, None, None),           # enc3
+    ([64], 64, 3, 1, True, False, None, None),           # dec0
+    ([64, 32], 32, 3, 1, True, False, None, [True, False]),   # dec1: NN x2 + cat
+    ([32, 16], 16, 3, 1, True, False, None, [True, False]),   # dec2
+    ([16], 6, 3, 1, False, False, None, [True]),              # dec3 on NN x2
+]
+
+
+@pytest.mark.parametrize("spec", CONVS, ids=[str(i) for i in range(len(CONVS))])
+@pytest.mark.parametrize("size", [(2, 24, 40), (1, 22, 70)])
+def test_conv_matches_torch_fp32(hip, dev, spec, size):
+    parts, cout, k, stride, relu, residual, store, up2 = spec
+    N, H, W = size
+    g = _gen(7)
+    up2 = up2 or [False] * len(parts)
+    srcs = [torch.rand(N, c, H // 2 if u else H, W // 2 if u else W, generator=g) * 2 - 1 for c, u in zip(parts, up2)]
+    cin = sum(parts)
+    wt = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+    bs = torch.randn(cout, generator=g) * 0.1
+    full = torch.cat([F.interpolate(s, scale_factor=2, mode="nearest") if u else s for s, u in zip(srcs, up2)], 1)
+    ref = F.conv2d(full, wt, bs, stride=stride, padding=1)
+    if relu:
+        ref = F.relu(ref)
+    if store:
+        ref = ref[:, :store]
+    res = torch.rand(ref.shape, generator=g) if residual else None
+    if residual:
+        ref = ref + res
+    got = hip.conv2d([s.to(dev) for s in srcs], wt.to(dev), bs.to(dev), stride=stride, relu=relu,
+                     residual=res.to(dev) if residual else None, cout_store=store, up2=up2)
+    _cmp(got, ref, atol=2e-5, rtol=1e-5, what="conv %s" % (spec,))
+
+
+def test_conv_batch_strided_views(hip, dev):
+    g = _gen(8)
+    feat = (torch.rand(2, 96, 12, 20, generator=g) * 2 - 1)
+    wt = torch.randn(48, 96, 3, 3, generator=g) / 30
+    fd = feat.to(dev)
+    got = hip.conv2d([fd[:, 48:], fd[:, :48]], wt.to(dev), None)
+    _cmp(got, F.conv2d(torch.cat([feat[:, 48:], feat[:, :48]], 1), wt, None, padding=1), atol=2e-5, what="strided views")
+
+
+# ---------------------------------------------------------------------------------------------------
+# synthesis tail
+# ---------------------------------------------------------------------------------------------------
+def test_synth_tail_fp64(hip, dev):
+    g = _gen(9)
+    N, H, W = 2, 19, 33
+    refine = torch.randn(N, 6, H, W, generator=g) * 3
+    cands = [torch.rand(N, 3, H, W, generator=g) * 2 - 1 for _ in range(6)]
+    t = torch.tensor([[0.125], [0.625]])
+    T = torch.tensor([1.5616], dtype=torch.float64)
+    occ = F.softmax(refine / T, dim=1)
+    t4 = t.view(N, 1, 1, 1)
+    wk = [(1 - t4), t4] * 3
+    num = sum(wk[k] * occ[:, k:k + 1] * cands[k] for k in range(6))
+    den = sum(wk[k] * occ[:, k:k + 1] for k in range(6))
+    out = hip.synth_tail(refine.to(dev), [c.to(dev) for c in cands], t.to(dev), float(T))
+    assert out.dtype == torch.float64
+    _cmp(out, num / den, atol=1e-13, what="tail fp64")
+    out32 = hip.synth_tail(refine.to(dev), [c.to(dev) for c in cands], t.to(dev), float(T), out_dtype=torch.float32)
+    _cmp(out32, (num / den).float(), atol=1e-7, what="tail fp32 out")
+
+
+# ---------------------------------------------------------------------------------------------------
+# whole frame-pair forward vs the reference's golden vectors
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["model_256x256_t0500", "model_200x500_t0125"])
+def test_model_matches_reference_golden(hip, oracle, golden, dev, model, case):
+    import fldr_harness as Hn
+    m, a = model
+    g = golden(case)
+    u8 = torch.from_numpy(g["frames_u8"])
+    frames = Hn.frames_from_uint8(u8).to(dev)
+    t = torch.tensor([[float(g["t"])]], device=dev)
+    pyr = Hn.build_pyramid(Hn.pad_frames(frames, a), a)
+    for i in range(1, 6):
+        _cmp(pyr[i], torch.from_numpy(g["pyr%d" % i]), atol=2e-6, what="pyramid %d" % i)
+    # stage boundaries, driven exactly like DCTXVFInet.forward does
+    flow = None
+    with torch.no_grad():
+        for level in range(5, 0, -1):
+            B, _, _, h, w = pyr[level].shape
+            import pca_comp
+            pca = pca_comp.to_pca_diff_f32(pyr[level].reshape(6, h, w), m.params[level], a, m.Mean8, m.EV8, m.meanVec8)
+            _cmp(pca.view(1, 96, h // 8, w // 8), torch.from_numpy(g["pca%d" % level]), atol=2e-6, what="pca L%d" % level)
+            feat = m.extract_features(pca.view(1, 96, h // 8, w // 8))
+            _cmp(feat, torch.from_numpy(g["feat%d" % level]), atol=2e-5, what="feat L%d" % level)
+            flow = m.vfinet(feat, flow, t.view(1, 1, 1, 1), level=level, is_training=False, normInput=pyr[level])
+            _cmp(flow, torch.from_numpy(g["flow%d" % level]), atol=2e-3, rtol=1e-3, what="flow L%d" % level)
+        out = Hn.interpolate(m, a, frames, t, pyramid=pyr)
+    assert out.dtype == torch.float64
+    H, W = frames.shape[3:]
+    ref = torch.from_numpy(g["out"]).double()[:, :, :H, :W]
+    err = _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="final frame")
+    p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
+    print("%s: max|err| %.2e, PSNR(8-bit) gpu vs reference %.1f dB" % (case, err, p))
+    assert p > 60.0
+
+
+def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
+    """Batch of 2 (the PCA min/max is then taken over the batch, as in the reference)."""
+    import fldr_harness as Hn
+    m, a = model
+    u = [Hn.synthetic_pair(256, 256, seed=s, quadrant=bool(s)) for s in (0, 1)]
+    frames = torch.cat([Hn.frames_from_uint8(x) for x in u], 0)
+    t = torch.tensor([[0.25], [0.75]])
+    out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)
+    _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="B=2 forward")
+
+
+# ---------------------------------------------------------------------------------------------------
+# full-size (BASELINE config 2: 3840x2160) checks
+# ---------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def frames4k(dev):
+    import fldr_harness as Hn
+    return Hn.frames_from_uint8(Hn.synthetic_pair(2160, 3840, seed=1, quadrant=True)).to(dev)
+
+
+def test_4k_forward_properties(hip, dev, model, frames4k):
+    import fldr_harness as Hn
+    m, a = model
+    t = torch.tensor([[0.5]], device=dev)
+    out = Hn.interpolate(m, a, frames4k, t)
+    assert out.shape == (1, 3, 2160, 3840) and out.dtype == torch.float64 and torch.isfinite(out).all()
+    out2 = Hn.interpolate(m, a, frames4k, t)
+    assert (out - out2).abs().max().item() < 1e-4            # only the splat's atomic order may differ (F9)
+    # static scene: both inputs equal -> the interpolated frame is that frame
+    same = frames4k.clone()
+    same[:, :, 1] = same[:, :, 0]
+    o3 = Hn.interpolate(m, a, same, t)
+    p = Hn.psnr(Hn.to_uint8_image(same[0, :, 0]), Hn.to_uint8_image(o3[0]))
+    print("static-scene PSNR at 4K: %.1f dB" % p)
+    assert p > 40.0
+
+
+def test_4k_splat_mass_and_linearity(hip, dev):
+    H, W = 2304, 3840
+    g = torch.Generator(device="cpu").manual_seed(11)
+    flow = ((torch.rand(1, 2, H // 8, W // 8, generator=g) - 0.5) * 6).to(dev)
+    flow = hip.resize_bilinear(flow, H, W, mul=8.0)
+    x = torch.rand(1, 2, H, W, device=dev)
+    y = torch.rand(1, 2, H, W, device=dev)
+    sx, sy = hip.softsplat_fwd(x, flow), hip.softsplat_fwd(y, flow)
+    sxy = hip.softsplat_fwd(2.0 * x - 0.5 * y, flow)
+    assert (sxy - (2.0 * sx - 0.5 * sy)).abs().max().item() < 1e-4          # linearity
+    ones = torch.ones(1, 1, H, W, device=dev)
+    acc = hip.softsplat_fwd(ones, flow)
+    # mass conservation: every source deposits the sum of its in-bounds corner weights
+    xs = torch.arange(W, device=dev, dtype=torch.float32).view(1, W) + flow[0, 0]
+    ys = torch.arange(H, device=dev, dtype=torch.float32).view(H, 1) + flow[0, 1]
+    tot = 0
+    for tx, wx in ((xs.floor(), xs.floor() + 1 - xs), (xs.floor() + 1, xs - xs.floor())):
+        for ty, wy in ((ys.floor(), ys.floor() + 1 - ys), (ys.floor() + 1, ys - ys.floor())):
+            tot = tot + (wx * wy * ((tx >= 0) & (tx < W) & (ty >= 0) & (ty < H))).double().sum()
+    assert abs(acc.double().sum().item() - tot.item()) / tot.item() < 1e-6
+
+
+@pytest.mark.timeout(900)
+def test_4k_forward_matches_oracle(hip, oracle, weights, dev, model, frames4k):
+    """BASELINE config 2 against the CPU oracle on the same seeded synthetic pair (tens of seconds of CPU)."""
+    import fldr_harness as Hn
+    m, a = model
+    t = torch.tensor([[0.5]])
+    out = Hn.interpolate(m, a, frames4k, t.to(dev)).cpu()
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames4k.cpu()), t)[:, :, :2160, :3840]
+    err = (out - ref).abs()
+    p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
+    print("4K: max|err| %.2e mean %.2e; PSNR(8-bit) gpu vs oracle %.1f dB" % (err.max().item(), err.mean().item(), p))
+    assert err.mean().item() < 1e-4 and (err > 4e-3).double().mean().item() < 1e-4 and p > 55.0

@@ -1,0 +1,121 @@
+"""CPU-side checks (no GPU): the C ABI library loads and exports everything include/fldr_hip.h declares, the
+host mirror of the reference interface (args, state-dict keys, padding/pyramid, error behaviour) is right."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import fldr_hip
+    hdr = open(os.path.join(ROOT, "include", "fldr_hip.h")).read()
+    declared = set(re.findall(r"\b(fldr_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"fldr_conv_desc"}
+    assert declared, "no declarations parsed"
+    lib = ctypes.CDLL(fldr_hip.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), "libfldr_hip.so does not export " + name
+    assert declared == set(fldr_hip.EXPORTS), (declared ^ set(fldr_hip.EXPORTS))
+    assert fldr_hip.lib().fldr_version() == 100
+    assert fldr_hip.lib().fldr_error_string(-2) == b"fldr: shape constraint violated"
+
+
+def test_conv_desc_layout_matches_header():
+    import fldr_hip
+    # 12 ptr + 12 i64 + 12 i32 + 12 i32 + i32 (+pad) + 4 ptr + 12 i32
+    assert ctypes.sizeof(fldr_hip.ConvDesc) == 12 * 8 + 12 * 8 + 12 * 4 + 12 * 4 + 8 + 4 * 8 + 12 * 4
+    assert fldr_hip.lib().fldr_conv_prepack_size(96, 100, 3) == 104 * 9 * 96
+    assert fldr_hip.lib().fldr_conv_prepack_size(6, 16, 3) == 16 * 9 * 16
+    assert fldr_hip.lib().fldr_conv_prepack_size(16, 26, 4) == 28 * 16 * 16
+    assert fldr_hip.lib().fldr_conv_prepack_size(128, 16, 3) < 0
+
+
+def test_args_match_reference_namespace():
+    import fldr_harness as Hn
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "args_papermodel_test5scales.json")))
+    a = Hn.args_config()
+    for k, v in ref.items():
+        assert getattr(a, k) == v, (k, getattr(a, k), v)
+
+
+def test_state_dict_keys_and_strict_load():
+    import fldr_harness as Hn
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "state_dict_keys.json")))
+    a = Hn.args_config()
+    model = a.net_object(a)
+    own = model.state_dict()
+    assert set(own) == set(ref), set(own) ^ set(ref)
+    for k, (shape, dtype) in ref.items():
+        assert list(own[k].shape) == shape and str(own[k].dtype) == dtype, k
+    # the re-exported archive loads strictly once the aliases / unused entries are restored
+    sd = Hn.npz_state_dict()
+    missing = set(ref) - set(sd)
+    assert all(re.match(r"(EV|Mean|meanVec)(16|32|64)$", k) or ".refine_unet.conv" in k for k in missing), missing
+    model2, _, _ = Hn.prepare_model(torch.device("cpu"))
+    assert float(model2.vfinet.T_param[0]) == pytest.approx(1.5616, abs=1e-3)
+    assert model2.EV8.dtype == torch.float64 and model2.rec_ctx_ds[0].weight.dtype == torch.float32
+    assert model2.base_modules[0] is model2.rec_ctx_ds and model2.base_modules[1] is model2.vfinet
+
+
+def test_pad_and_pyramid_match_oracle_and_golden(oracle, golden):
+    import fldr_harness as Hn
+    g = golden("model_200x500_t0125")
+    fr = Hn.frames_from_uint8(torch.from_numpy(g["frames_u8"]))
+    a = Hn.args_config()
+    pyr = Hn.build_pyramid(Hn.pad_frames(fr, a), a)
+    assert pyr[0].shape == (1, 3, 2, 256, 512)
+    ref = oracle.pad_and_pyramid(fr)
+    for i in range(6):
+        assert torch.equal(pyr[i], ref[i])
+        if i:
+            assert np.array_equal(pyr[i].numpy(), g["pyr%d" % i])
+    u = Hn.synthetic_pair(200, 500, seed=1, quadrant=True)
+    assert torch.equal(u, torch.from_numpy(g["frames_u8"])) and torch.equal(u, oracle.synthetic_pair(200, 500, 1, True))
+
+
+def test_cpu_tensors_fail_loudly():
+    """No CPU fallback anywhere: same behaviour as the reference (softSplat.py:251-252, correlation.py:343-344)."""
+    import softSplat
+    from OpticalFlow import correlation
+    import pca_comp
+    import fldr_harness as Hn
+    x = torch.zeros(1, 3, 8, 8)
+    f = torch.zeros(1, 2, 8, 8)
+    with pytest.raises(NotImplementedError):
+        softSplat.Softsplat()(x, f)
+    with pytest.raises(NotImplementedError):
+        softSplat._FunctionSoftsplat.apply(x, f)
+    with pytest.raises(NotImplementedError):
+        correlation.FunctionCorrelation(x, x)
+    with pytest.raises(AssertionError):
+        softSplat.FunctionSoftsplat(x, f, torch.zeros(1, 2, 8, 8), 'softmax')       # softSplat.py:321
+    with pytest.raises(AssertionError):
+        softSplat.FunctionSoftsplat(x, f, None, 'bogus')                             # softSplat.py:322
+    model, _, a = Hn.prepare_model(torch.device("cpu"))
+    with pytest.raises(NotImplementedError):
+        pca_comp.to_pca_diff(torch.zeros(6, 16, 16), model.params[0], a, model.Mean8, model.EV8, model.meanVec8)
+    with pytest.raises(NotImplementedError):
+        model([None] * 6, torch.tensor([[0.5]]), normInput=[], is_training=True)
+
+
+def test_missing_library_is_an_error(monkeypatch):
+    import fldr_hip
+    monkeypatch.setattr(fldr_hip, "_lib", None)
+    monkeypatch.setattr(fldr_hip, "LIB_PATH", "/nonexistent/libfldr_hip.so")
+    with pytest.raises(ImportError):
+        fldr_hip.lib()
+
+
+def test_psnr_and_uint8(oracle):
+    import fldr_harness as Hn
+    p = torch.tensor([[[-1.0, 1.0], [0.0, 3.0]]]).repeat(3, 1, 1)
+    img = Hn.to_uint8_image(p)
+    assert img.shape == (2, 2, 3) and img[0, 0, 0] == 0 and img[0, 1, 0] == 255 and img[1, 0, 0] == 128 and img[1, 1, 0] == 255
+    assert Hn.psnr(img, img) == float("inf")
+    assert Hn.psnr(img, img + 5) == pytest.approx(oracle.psnr(img, img + 5))

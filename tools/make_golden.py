@@ -267,6 +267,8 @@ def main():
              "cutoffUnnec tempbottomflowfix align_cornerse outMaskLess TOptimization testgetflowout timetest "
              "mean_vector_norm padding patch_size validation_patch_size oneEV pcanet").split()
     import json
+    with open(os.path.join(gold, "state_dict_keys.json"), "w") as f:
+        json.dump({k: [list(v.shape), str(v.dtype)] for k, v in ckpt["state_dict_Model"].items()}, f, indent=0)
     with open(os.path.join(gold, "args_papermodel_test5scales.json"), "w") as f:
         json.dump({n: getattr(args, n) for n in names if hasattr(args, n)}, f, indent=1, sort_keys=True)
 
