@@ -22,13 +22,13 @@ struct FldrTap {
 };
 
 __device__ __forceinline__ FldrTap fldr_grid_tap(float px, float py, float fx, float fy, int W, int H,
-                                                 float inv_wm1, float inv_hm1) {
+                                                 float wm1, float hm1) {
 #pragma clang fp contract(off)
     FldrTap t;
     float vx = px + fx;
     float vy = py + fy;
-    float gx = (2.0f * vx) * inv_wm1 - 1.0f;
-    float gy = (2.0f * vy) * inv_hm1 - 1.0f;
+    float gx = (2.0f * vx) / wm1 - 1.0f;      // true division, as torch's div(Tensor, Scalar) does for fp32
+    float gy = (2.0f * vy) / hm1 - 1.0f;
     float ix = (gx + 1.0f) * ((float)W * 0.5f) - 0.5f;
     float iy = (gy + 1.0f) * ((float)H * 0.5f) - 0.5f;
     float xf = floorf(ix), yf = floorf(iy);

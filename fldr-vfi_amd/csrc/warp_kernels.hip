@@ -168,7 +168,7 @@ extern "C" int fldr_bwarp(const float* x, const float* flo, float* out, int N, i
                           fldr_stream_t stream) {
     FLDR_CHECK_ARG(x && flo && out && N > 0 && C > 0 && H > 0 && W > 0);
     dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4), N);
-    float iw = 1.0f / (float)(W - 1 > 1 ? W - 1 : 1), ih = 1.0f / (float)(H - 1 > 1 ? H - 1 : 1);
+    float iw = (float)(W - 1 > 1 ? W - 1 : 1), ih = (float)(H - 1 > 1 ? H - 1 : 1);
     hipLaunchKernelGGL(bwarp_kernel, grid, dim3(256), 0, fldr_s(stream), x, flo, out, C, H, W, withmask, iw, ih,
                        (const float*)nullptr, 0, 0);
     FLDR_LAUNCH_RET();
@@ -179,7 +179,7 @@ extern "C" int fldr_bwarp_tscaled(const float* x, const float* flo, float* out, 
     FLDR_CHECK_ARG(x && flo && out && t && N > 0 && C > 0 && H > 0 && W > 0);
     FLDR_CHECK_ARG(x_mode >= 0 && x_mode <= 2 && flo_mode >= 0 && flo_mode <= 2);
     dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4), N);
-    float iw = 1.0f / (float)(W - 1 > 1 ? W - 1 : 1), ih = 1.0f / (float)(H - 1 > 1 ? H - 1 : 1);
+    float iw = (float)(W - 1 > 1 ? W - 1 : 1), ih = (float)(H - 1 > 1 ? H - 1 : 1);
     hipLaunchKernelGGL(bwarp_kernel, grid, dim3(256), 0, fldr_s(stream), x, flo, out, C, H, W, withmask, iw, ih, t, x_mode, flo_mode);
     FLDR_LAUNCH_RET();
 }
@@ -211,7 +211,7 @@ extern "C" int fldr_zmetric(const float* self_img, const float* other_img, const
                             int N, int C, int H, int W, fldr_stream_t stream) {
     FLDR_CHECK_ARG(self_img && other_img && flow && z && N > 0 && C > 0 && H > 0 && W > 0);
     dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4), N);
-    float iw = 1.0f / (float)(W - 1 > 1 ? W - 1 : 1), ih = 1.0f / (float)(H - 1 > 1 ? H - 1 : 1);
+    float iw = (float)(W - 1 > 1 ? W - 1 : 1), ih = (float)(H - 1 > 1 ? H - 1 : 1);
     hipLaunchKernelGGL(zmetric_kernel, grid, dim3(256), 0, fldr_s(stream), self_img, other_img, flow, alpha, z, C, H, W, iw, ih);
     FLDR_LAUNCH_RET();
 }

@@ -204,15 +204,12 @@ def zmetric(self_img, other_img, flow, alpha):
     return z
 
 
-_PACK_CACHE = {}
-
-
 def conv_prepack(weight):
-    """Repack an nn.Conv2d weight for fldr_conv2d; cached per (storage, version)."""
-    key = (weight.data_ptr(), weight._version, tuple(weight.shape), weight.device.index)
-    hit = _PACK_CACHE.get(key)
-    if hit is not None:
-        return hit
+    """Repack an nn.Conv2d weight for fldr_conv2d.  The packed copy is cached ON the tensor object (an
+    allocator may hand the same address to a different weight, so the address alone is not a key)."""
+    hit = getattr(weight, "_fldr_pack", None)
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
+        return hit[1]
     cout, cin, k, k2 = weight.shape
     assert k == k2
     n = lib().fldr_conv_prepack_size(cout, cin, k)
@@ -221,9 +218,7 @@ def conv_prepack(weight):
     w = weight.detach().contiguous()
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
     _check(lib().fldr_conv_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, k, _stream()), "fldr_conv_prepack")
-    if len(_PACK_CACHE) > 256:
-        _PACK_CACHE.clear()
-    _PACK_CACHE[key] = wp
+    weight._fldr_pack = ((weight._version, weight.data_ptr()), wp)
     return wp
 
 
