@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 4K (3840x2160) frame pairs interpolated per second (BASELINE.json metric, config 2:
+single 4K frame pair, 5-scale test path, t = 0.5) through the MI355X-native hot path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one (frame pair, t) forward = the reference's `model_net(input_gpuList, t, normInput=pyramid, ...)` call
+(main.py:867) with the 6-level pyramid already resident in HBM.  Frame pairs are independent, so N ranks each
+interpolate their own pair (weak scaling, no data-path collective); the only RCCL traffic is the barrier and a
+max-reduction of the elapsed time.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "fldr-vfi_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H4K, W4K = 2160, 3840
+PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_GBPS = 8000.0
+
+
+def shard_pairs(n_pairs, rank, world):
+    """Static round-robin of frame PAIRS over ranks: pair i -> rank i % world."""
+    return [i for i in range(n_pairs) if i % world == rank]
+
+
+def dominant_conv_roofline(model, pyr, steps):
+    """Roofline of the dominant kernel: the 96->96 3x3 fp32-MFMA convolution at the level-0 feature map
+    (rec_ctx_ds.0 / .2, conv_flow2.2 all launch this instance).  Algorithmic FLOPs per launch =
+    2 * cin * cout * 9 * pixels; duration measured with HIP events on the launch stream."""
+    import fldr_hip
+    h, w = pyr[0].shape[3] // 8, pyr[0].shape[4] // 8
+    x = torch.rand(1, 96, h, w, device=pyr[0].device) * 2 - 1
+    conv = model.rec_ctx_ds[0]
+    for _ in range(3):
+        fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True)
+    n = max(10, steps)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = torch.empty(1, 96, h, w, device=x.device)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(n):
+        fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flops = 2.0 * 96 * 96 * 9 * h * w
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_mfma_kernel<3,1,32,3,2,8> (3x3 96->96 @%dx%d, fp32 MFMA)" % (h, w),
+            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+            "traffic": None, "launch_ms": round(ms, 4), "flops_per_launch": flops}
+
+
+def cpu_baseline(frames_cpu, t_cpu):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores: ONE 4K
+    frame-pair forward (pyramid excluded, like the GPU number)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import fldr_oracle as O
+    import fldr_harness as Hn
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    w = O.load_weights(Hn.DEFAULT_WEIGHTS)
+    pyr = O.pad_and_pyramid(frames_cpu)
+    with torch.no_grad():
+        t0 = time.time()
+        O.forward(w, pyr, t_cpu)
+        dt = time.time() - t0
+    return {"value": round(1.0 / dt, 5), "unit": "4K frame-pairs/s", "cores": cores, "kind": "port",
+            "sample": "1 forward of the same 3840x2160 pair (seed 0, t=0.5), oracle/fldr_oracle.py on torch-CPU, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--width", type=int, default=W4K)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=device)
+
+    import fldr_harness as Hn
+    model, _, args = Hn.prepare_model(device)
+    pair = shard_pairs(world, rank, world)[0]                    # one pair per rank, seed = pair index
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(a.height, a.width, seed=pair)).to(device)
+    t = torch.tensor([[0.5]], device=device)
+    with torch.no_grad():
+        pyr = Hn.build_pyramid(Hn.pad_frames(frames, args), args)
+
+        def step():
+            return Hn.interpolate(model, args, frames, t, pyramid=pyr)
+
+        for _ in range(a.warmup):
+            out = step()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.steps):
+            out = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        # pyramid-inclusive rate (informational): pad + bicubic pyramid on the device + forward
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(1, a.steps // 4)):
+            Hn.interpolate(model, args, frames, t)
+        torch.cuda.synchronize()
+        dt_e2e = (time.perf_counter() - t1) / max(1, a.steps // 4)
+    assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
+    tt = torch.tensor([dt], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = tt.item()
+
+    if rank == 0:
+        res = {
+            "metric": "4K frame-pairs interpolated/sec", "value": round(world * a.steps / dt, 3), "unit": "frame-pairs/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "single %dx%d frame pair per GPU (padded 2304x3840), fLDRnet 5-scale test path "
+                                   "(--papermodel --test5scales), t=0.5, shipped checkpoint weights, fp64 output frame"
+                                   % (a.width, a.height),
+                       "parallelism": "dp%d (independent pairs, no data-path collective)" % world,
+                       "ms_per_step_incl_pad_and_pyramid": round(dt_e2e * 1e3, 3)},
+        }
+        res["roofline"] = dominant_conv_roofline(model, pyr, a.steps)
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(frames.cpu(), t.cpu())
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

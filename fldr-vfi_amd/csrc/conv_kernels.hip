@@ -54,19 +54,34 @@ struct ConvCfg {
     static constexpr int ICH = MT == 16 ? pad16mod32(IH * IWP) : IH * IWP;      // channel stride (floats)
     static constexpr int TAPS = KS * KS;
     static constexpr int MTOT = NMT * MT;
-    static constexpr int WCH = MT == 16 ? pad16mod32(TAPS * MTOT) : TAPS * MTOT;
-    static constexpr int LDS_FLOATS = CC * (ICH + WCH);
+    static constexpr int WCH = MT == 16 ? pad16mod32(TAPS * MTOT) : TAPS * MTOT;   // also the stride of wpack
     static constexpr int KG = MT == 16 ? 4 : 2;          // input channels per MFMA
+    static constexpr int NI = (IH * IW + 63) / 64;       // input elements per lane per channel
+    static constexpr int CPW = CC / 4;                   // channels staged per wave
+    static constexpr int WSLAB = CC * WCH;               // weight floats per chunk (contiguous in wpack)
+    static constexpr int NWI = (WSLAB / 4 + 255) / 256;  // 16-B LDS-DMA pieces per thread per chunk
+    static constexpr int W_LDS = NWI * 256 * 4;          // weight region rounded up to whole pieces
+    static constexpr int BUF_FLOATS = W_LDS + CC * ICH;  // one pipeline stage: [weights | input]
+    static constexpr int TAB_FLOATS = 2 * 112;           // per-channel plane pointers (64-bit), cin_pad <= 112
+    static constexpr int LDS_FLOATS = 2 * BUF_FLOATS + TAB_FLOATS;
+    static constexpr int KSTEPS = CC / KG * TAPS;        // MFMA k-steps per chunk
 };
 
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// The chunk loop is software pipelined over two LDS stages: while the MFMAs consume stage k,
+//   * the weight slab of chunk k+1 streams global -> LDS by LDS-DMA (global_load_lds_dwordx4, no VGPRs),
+//   * the input tile of chunk k+1 is prefetched into registers (zero padding / nearest-x2 / source
+//     selection resolved at load time) and written to LDS after the MFMA phase,
+// and ONE barrier per chunk separates the stages.
 template <int KS, int STRIDE, int MT, int NMT, int PT, int CC_>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     using Cfg = ConvCfg<KS, STRIDE, MT, NMT, PT, CC_>;
     constexpr int CC = Cfg::CC, IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IWH = Cfg::IWH, ICH = Cfg::ICH;
     constexpr int TAPS = Cfg::TAPS, MTOT = Cfg::MTOT, WCH = Cfg::WCH, KG = Cfg::KG;
+    constexpr int NI = Cfg::NI, CPW = Cfg::CPW, NWI = Cfg::NWI, W_LDS = Cfg::W_LDS, BUF = Cfg::BUF_FLOATS;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* in_s = smem;
-    float* w_s = smem + CC * ICH;
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = blockIdx.y;
@@ -77,15 +92,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     const int lj = lane & (MT - 1);          // pixel within pixel tile (B column) / cout within M tile (A row)
     const int lk = lane / MT;                // k index within the MFMA (0..KG-1)
 
-    // per-pixel-tile LDS base offsets of the B operand (tap (0,0), channel lk)
     int boff[PT];
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
-        int r = wave * Cfg::RPW + p / Cfg::TPR;          // output row within tile
-        int c0 = (p % Cfg::TPR) * MT;                    // output col within tile
-        boff[p] = lk * ICH + (r * STRIDE) * IWP + (c0 + lj);   // stride 2: even-column plane, col index = out col
+        int r = wave * Cfg::RPW + p / Cfg::TPR;
+        int c0 = (p % Cfg::TPR) * MT;
+        boff[p] = W_LDS + lk * ICH + (r * STRIDE) * IWP + (c0 + lj);
     }
     const int aoff = lk * WCH + lj;
+
+    // per-lane geometry of the staged input elements (identical for every channel and chunk)
+    int g_full[NI], g_half[NI], l_off[NI];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int e = lane + 64 * i;
+        const int y = e / IW, x = e % IW;
+        const int gy = iy0 + y, gx = ix0 + x;
+        const bool ok = e < IH * IW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        vmask |= ok ? (1u << i) : 0u;
+        g_full[i] = ok ? gy * a.Win + gx : 0;
+        g_half[i] = ok ? (gy >> 1) * (a.Win >> 1) + (gx >> 1) : 0;
+        l_off[i] = e < IH * IW ? y * IWP + (STRIDE == 2 ? (x & 1) * IWH + (x >> 1) : x) : -1;
+    }
 
     typedef typename std::conditional<MT == 32, f32x16, f32x4>::type acc_t;
     acc_t acc[NMT][PT];
@@ -96,90 +125,147 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[m][p][r] = 0.0f;
 
-    const int cin_pad = (a.cin + CC - 1) / CC * CC;
-    for (int c0 = 0; c0 < cin_pad; c0 += CC) {
-        // ---- stage weights: contiguous CC*TAPS*MTOT floats in wpack ----
-        {
-            const float4* g = reinterpret_cast<const float4*>(a.wpack + (int64_t)c0 * TAPS * MTOT);
-            constexpr int PER_CH4 = TAPS * MTOT / 4;
-            for (int e = tid; e < CC * PER_CH4; e += 256) {
-                int c = e / PER_CH4, r = e % PER_CH4;
-                *reinterpret_cast<float4*>(w_s + c * WCH + r * 4) = g[e];
-            }
+    float pre[CPW][NI];
+
+    // Per-channel plane pointer table (bit 0 = "stored at half resolution"), built once: resolving the
+    // source of a channel from the kernel arguments needs dynamically indexed loads, which must not sit
+    // in the pipelined loop (their vmcnt(0) would drain the prefetches every chunk).
+    unsigned long long* ctab = reinterpret_cast<unsigned long long*>(smem + 2 * BUF);
+    if (tid < 112) {
+        unsigned long long e = 0;
+        if (tid < a.cin) {
+            int s = 0;
+            while (s + 1 < a.n_src && tid >= a.src_cbegin[s + 1]) ++s;
+            const int up2 = a.src_up2[s];
+            const int64_t plane = up2 ? (int64_t)(a.Hin >> 1) * (a.Win >> 1) : (int64_t)a.Hin * a.Win;
+            const float* base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(tid - a.src_cbegin[s]) * plane;
+            e = (unsigned long long)reinterpret_cast<uintptr_t>(base) | (unsigned long long)(up2 ? 1 : 0);
         }
-        // ---- stage input tile: each wave assembles whole channels (source lookup is wave-uniform) ----
-        for (int c = wave; c < CC; c += 4) {
-            const int cg = c0 + c;
-            const float* base = nullptr;
-            int up2 = 0;
-            if (cg < a.cin) {
-                int s = 0;
-                while (s + 1 < a.n_src && cg >= a.src_cbegin[s + 1]) ++s;
-                up2 = a.src_up2[s];
-                const int hs = up2 ? a.Hin >> 1 : a.Hin, ws = up2 ? a.Win >> 1 : a.Win;
-                base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(cg - a.src_cbegin[s]) * hs * ws;
-            }
-            const int ws = up2 ? a.Win >> 1 : a.Win;
-            float* dst = in_s + c * ICH;
-            for (int e = lane; e < IH * IW; e += 64) {
-                int y = e / IW, x = e % IW;
-                int gy = iy0 + y, gx = ix0 + x;
-                float v = 0.0f;
-                if (base != nullptr && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win)
-                    v = up2 ? base[(int64_t)(gy >> 1) * ws + (gx >> 1)] : base[(int64_t)gy * ws + gx];
-                int col = STRIDE == 2 ? (x & 1) * IWH + (x >> 1) : x;
-                dst[y * IWP + col] = v;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over the chunk ----
-#pragma unroll 1
-        for (int cg = 0; cg < CC; cg += KG) {
-            const float* wc = w_s + cg * WCH + aoff;
-            const float* ic = in_s + cg * ICH;
+        ctab[tid] = e;
+    }
+    __syncthreads();
+
+    auto issue_weights = [&](int c0, float* stage) {
+        const float* g = a.wpack + (int64_t)c0 * WCH;
 #pragma unroll
-            for (int t = 0; t < TAPS; ++t) {
+        for (int i = 0; i < NWI; ++i) {
+            const int piece = i * 256 + wave * 64;                    // wave-uniform piece base (x16 B)
+            int src = (piece + lane) * 4;
+            src = src < Cfg::WSLAB ? src : 0;                        // tail pieces re-read the slab start (never consumed)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + src), (lptr_t)(stage + piece * 4), 16, 0, 0);
+        }
+    };
+    auto load_inputs = [&](int c0) {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            const unsigned long long e = ctab[c0 + wave + 4 * q];
+            const bool live = e != 0ull;
+            const bool up2 = (e & 1ull) != 0ull;
+            const float* base = reinterpret_cast<const float*>(static_cast<uintptr_t>(e & ~1ull));
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const bool ok = live && ((vmask >> i) & 1u);
+                const int off = up2 ? g_half[i] : g_full[i];
+                float v = 0.0f;
+                if (ok) v = base[off];
+                pre[q][i] = v;
+            }
+        }
+    };
+    auto store_inputs = [&](float* stage) {
+#pragma unroll
+        for (int q = 0; q < CPW; ++q) {
+            float* dst = stage + W_LDS + (wave + 4 * q) * ICH;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (l_off[i] >= 0) dst[l_off[i]] = pre[q][i];
+        }
+    };
+
+    const int cin_pad = (a.cin + CC - 1) / CC * CC;
+    issue_weights(0, smem);
+    load_inputs(0);
+    store_inputs(smem);
+    __syncthreads();
+
+    int stage = 0;
+    for (int c0 = 0; c0 < cin_pad; c0 += CC, stage ^= 1) {
+        float* cur = smem + stage * BUF;
+        float* nxt = smem + (stage ^ 1) * BUF;
+        const bool more = c0 + CC < cin_pad;
+        if (more) {
+            issue_weights(c0 + CC, nxt);
+            load_inputs(c0 + CC);
+        }
+        {
+            float av[2][NMT], bv[2][PT];
+            auto ld = [&](int buf, int k) {
+                const int cg = (k / TAPS) * KG, t = k % TAPS;
                 const int dy = t / KS, dx = t % KS;
                 const int toff = dy * IWP + (STRIDE == 2 ? (dx & 1) * IWH + (dx >> 1) : dx);
-                float av[NMT], bv[PT];
+                const float* wc = cur + cg * WCH + aoff + t * MTOT;
+                const float* ic = cur + cg * ICH + toff;
 #pragma unroll
-                for (int m = 0; m < NMT; ++m) av[m] = wc[t * MTOT + m * MT];
+                for (int m = 0; m < NMT; ++m) av[buf][m] = wc[m * MT];
 #pragma unroll
-                for (int p = 0; p < PT; ++p) bv[p] = ic[boff[p] + toff];
+                for (int p = 0; p < PT; ++p) bv[buf][p] = ic[boff[p]];
+            };
+            ld(0, 0);
+#pragma unroll
+            for (int k = 0; k < Cfg::KSTEPS; ++k) {
+                if (k + 1 < Cfg::KSTEPS) ld((k + 1) & 1, k + 1);       // operands of step k+1 fly under the MFMAs of step k
 #pragma unroll
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
                     for (int p = 0; p < PT; ++p) {
-                        if constexpr (MT == 32) acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m], bv[p], acc[m][p], 0, 0, 0);
-                        else                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[m], bv[p], acc[m][p], 0, 0, 0);
+                        if constexpr (MT == 32) acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k & 1][m], bv[k & 1][p], acc[m][p], 0, 0, 0);
+                        else                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k & 1][m], bv[k & 1][p], acc[m][p], 0, 0, 0);
                     }
+                __builtin_amdgcn_sched_group_barrier(0x100, NMT + PT, 0);   // DS reads of step k+1 ...
+                __builtin_amdgcn_sched_group_barrier(0x008, NMT * PT, 0);   // ... then the MFMAs of step k
             }
         }
+        if (more) store_inputs(nxt);
         __syncthreads();
     }
 
     // ---- epilogue: bias, ReLU, residual, store (lane = pixel column, registers = output channels) ----
+    // All bias / residual loads are issued first (clamped addresses, no branches), then combined and stored.
+    constexpr int NR = MT == 32 ? 16 : 4;
     const int64_t HWo = (int64_t)a.Hout * a.Wout;
     float* outn = a.out + (int64_t)n * a.cout_store * HWo;
     const float* resn = a.residual ? a.residual + (int64_t)n * a.cout_store * HWo : nullptr;
+    float bias_r[NMT][NR];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+            co = co < a.cout ? co : a.cout - 1;
+            bias_r[m][r] = a.bias ? a.bias[co] : 0.0f;
+        }
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int oy = oy0 + wave * Cfg::RPW + p / Cfg::TPR;
         const int ox = ox0 + (p % Cfg::TPR) * MT + lj;
         const bool pix_ok = oy < a.Hout && ox < a.Wout;
-        const int64_t po = (int64_t)oy * a.Wout + ox;
+        const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
+            float res_r[NR];
 #pragma unroll
-            for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) {
+            for (int r = 0; r < NR; ++r) {
                 int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
-                if (co < a.cout_store && pix_ok) {
-                    float v = acc[m][p][r];
-                    if (a.bias) v += a.bias[co];
-                    if (a.relu) v = fmaxf(v, 0.0f);
-                    if (resn) v += resn[(int64_t)co * HWo + po];
-                    outn[(int64_t)co * HWo + po] = v;
-                }
+                co = co < a.cout_store ? co : a.cout_store - 1;
+                res_r[r] = resn ? resn[(int64_t)co * HWo + po] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                float v = acc[m][p][r] + bias_r[m][r];
+                if (a.relu) v = fmaxf(v, 0.0f);
+                v += res_r[r];
+                if (co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
             }
         }
     }
@@ -195,13 +281,13 @@ static inline void conv_geometry(int cout, int ksize, int& mt, int& nmt, int& cc
 }
 
 __global__ void conv_prepack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int taps,
-                                    int mtot, int64_t total) {
+                                    int mtot, int wch, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    int m = (int)(i % mtot);
-    int t = (int)((i / mtot) % taps);
-    int c = (int)(i / ((int64_t)mtot * taps));
-    wp[i] = (m < cout && c < cin) ? w[((int64_t)m * cin + c) * taps + t] : 0.0f;
+    int r = (int)(i % wch);                 // position inside the channel row: [tap][m], then padding
+    int c = (int)(i / wch);
+    int m = r % mtot, t = r / mtot;
+    wp[i] = (t < taps && m < cout && c < cin) ? w[((int64_t)m * cin + c) * taps + t] : 0.0f;
 }
 
 extern "C" int64_t fldr_conv_prepack_size(int cout, int cin, int ksize) {
@@ -209,7 +295,9 @@ extern "C" int64_t fldr_conv_prepack_size(int cout, int cin, int ksize) {
     int mt, nmt, cc;
     conv_geometry(cout, ksize, mt, nmt, cc);
     int cin_pad = (cin + cc - 1) / cc * cc;
-    return (int64_t)cin_pad * ksize * ksize * nmt * mt;
+    int wch = ksize * ksize * nmt * mt;
+    if (mt == 16) wch = pad16mod32(wch);
+    return (int64_t)cin_pad * wch;
 }
 
 extern "C" int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream) {
@@ -218,8 +306,10 @@ extern "C" int fldr_conv_prepack(const float* weight, float* wpack, int cout, in
     if (total < 0) return (int)total;
     int mt, nmt, cc;
     conv_geometry(cout, ksize, mt, nmt, cc);
+    int wch = ksize * ksize * nmt * mt;
+    if (mt == 16) wch = pad16mod32(wch);
     hipLaunchKernelGGL(conv_prepack_kernel, dim3(fldr_cdiv(total, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin,
-                       ksize * ksize, nmt * mt, total);
+                       ksize * ksize, nmt * mt, wch, total);
     FLDR_LAUNCH_RET();
 }
 
@@ -274,10 +364,10 @@ extern "C" int fldr_conv2d(const fldr_conv_desc* d, fldr_stream_t stream) {
     int mt, nmt, cc;
     conv_geometry(d->cout, d->ksize, mt, nmt, cc);
     if (d->ksize == 3) {
-        if (mt == 16) return conv_launch<3, 1, 16, 1, 8, 8>(a, d->N, s);
-        if (nmt == 1) return conv_launch<3, 1, 32, 1, 4, 8>(a, d->N, s);
-        if (nmt == 2) return conv_launch<3, 1, 32, 2, 2, 8>(a, d->N, s);
-        return conv_launch<3, 1, 32, 3, 2, 8>(a, d->N, s);
+        if (mt == 16) return conv_launch<3, 1, 16, 1, 4, 8>(a, d->N, s);
+        if (nmt == 1) return conv_launch<3, 1, 32, 1, 2, 8>(a, d->N, s);
+        if (nmt == 2) return conv_launch<3, 1, 32, 2, 1, 8>(a, d->N, s);
+        return conv_launch<3, 1, 32, 3, 1, 8>(a, d->N, s);
     } else {
         if (mt == 16) return conv_launch<4, 2, 16, 1, 4, 4>(a, d->N, s);
         if (nmt == 1) return conv_launch<4, 2, 32, 1, 2, 4>(a, d->N, s);
