@@ -10,6 +10,11 @@
 static inline hipStream_t fldr_s(fldr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int fldr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
+// the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.
+// Call it on a whole batch of loaded values AFTER all loads of the batch have been written down.
+__device__ __forceinline__ void fldr_pin(float& v) { asm volatile("" : "+v"(v)); }
+
 // ---- bilinear sampling with F.grid_sample(align_corners=False, zeros) semantics ----------------
 // Position arithmetic follows the op sequence of DCTVFInet.bwarp (fLDRnet.py:561-565) followed by
 // PyTorch's unnormalisation ((g+1)*size/2 - 0.5) with FMA contraction disabled, so that sample
@@ -56,14 +61,21 @@ __device__ __forceinline__ float fldr_tap_mask(const FldrTap& t) {
     return m < 0.999f ? 0.0f : 1.0f;          // fLDRnet.py:573-574
 }
 
-__device__ __forceinline__ float fldr_tap_sample(const FldrTap& t, const float* __restrict__ plane, int W) {
+__device__ __forceinline__ float fldr_tap_sample(const FldrTap& t, const float* __restrict__ plane, int W, int H) {
 #pragma clang fp contract(off)
-    const float* p = plane + (int64_t)t.y0 * W + t.x0;
+    // The four taps are fetched UNCONDITIONALLY from clamped addresses and masked afterwards: a predicated
+    // load compiles to branch + load + s_waitcnt vmcnt(0), which serialises the gathers of a wave.
+    const int xa = min(max(t.x0, 0), W - 1), xb = min(max(t.x0 + 1, 0), W - 1);
+    const int ya = min(max(t.y0, 0), H - 1), yb = min(max(t.y0 + 1, 0), H - 1);
+    const float* ra = plane + (int64_t)ya * W;
+    const float* rb = plane + (int64_t)yb * W;
+    float pnw = ra[xa], pne = ra[xb], psw = rb[xa], pse = rb[xb];
+    fldr_pin(pnw); fldr_pin(pne); fldr_pin(psw); fldr_pin(pse);
     float v = 0.0f;
-    if (t.vnw) v += p[0] * t.wnw;
-    if (t.vne) v += p[1] * t.wne;
-    if (t.vsw) v += p[W] * t.wsw;
-    if (t.vse) v += p[W + 1] * t.wse;
+    v += t.vnw ? pnw * t.wnw : 0.0f;
+    v += t.vne ? pne * t.wne : 0.0f;
+    v += t.vsw ? psw * t.wsw : 0.0f;
+    v += t.vse ? pse * t.wse : 0.0f;
     return v;
 }
 

@@ -239,32 +239,50 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
-            co = co < a.cout ? co : a.cout - 1;
-            bias_r[m][r] = a.bias ? a.bias[co] : 0.0f;
-        }
+        for (int r = 0; r < NR; ++r) bias_r[m][r] = 0.0f;
+    if (a.bias) {                                            // wave-uniform: one batch of loads, no per-element branch
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                co = co < a.cout ? co : a.cout - 1;
+                bias_r[m][r] = a.bias[co];
+            }
+    }
 #pragma unroll
     for (int p = 0; p < PT; ++p) {
         const int oy = oy0 + wave * Cfg::RPW + p / Cfg::TPR;
         const int ox = ox0 + (p % Cfg::TPR) * MT + lj;
         const bool pix_ok = oy < a.Hout && ox < a.Wout;
         const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
+        float res_r[NMT][NR];
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) res_r[m][r] = 0.0f;
+        if (resn) {                                          // wave-uniform
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                    co = co < a.cout_store ? co : a.cout_store - 1;
+                    res_r[m][r] = resn[(int64_t)co * HWo + po];
+                }
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) fldr_pin(res_r[m][r]);
+        }
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
-            float res_r[NR];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) {
-                int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
-                co = co < a.cout_store ? co : a.cout_store - 1;
-                res_r[r] = resn ? resn[(int64_t)co * HWo + po] : 0.0f;
-            }
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
                 float v = acc[m][p][r] + bias_r[m][r];
                 if (a.relu) v = fmaxf(v, 0.0f);
-                v += res_r[r];
+                v += res_r[m][r];
                 if (co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
             }
         }

@@ -44,100 +44,132 @@ __device__ __forceinline__ void splat_add(float* __restrict__ plane, const Splat
 
 // mode: -1 raw (in has C channels, out has C channels); 0 summation; 1 average; 2 linear; 3 softmax
 //
-// LDS-binned scatter.  A workgroup owns a TY x 64 SOURCE tile and a group of CB accumulator channels.
-// Flows are locally coherent (they are bilinear upsamplings of a coarse field), so almost all targets of a
-// tile fall into a small window around the tile's displaced position: the window [oy,oy+WH) x [ox,ox+WW)
-// (origin = minimum target corner of the tile) lives in LDS, contributions are accumulated there with
-// ds_add_f32, and the window is then flushed with ONE global float atomic per touched cell, issued as
-// contiguous 256-B wave-instructions.  Targets outside the window (diverging flow) go straight to global
-// atomics, so the result is exact for any flow.  Versus one global atomic per (source, corner) this cuts
-// the memory-side atomic traffic ~3-4x, which is what bounds the splat (MI355X: ~1.3 TB/s of atomic bytes).
-template <int MODE, int CB, int TY, int WH, int WW>
-__global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict__ in, const float* __restrict__ flow,
-                                                         const float* __restrict__ metric, float* __restrict__ acc,
-                                                         int C, int H, int W, int groups) {
-    constexpr int PPT = TY / 4;                         // source pixels per thread (rows ly, ly+4, ...)
-    __shared__ float win[CB][WH * WW];
-    __shared__ int smin[2][4];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+// Strip scatter with in-register merging.  The splat is bound by the memory-side float-atomic rate
+// (MI355X: ~1.3 TB/s of atomic bytes), so the kernel minimises atomic requests instead of issuing one per
+// (source, corner): a wave walks DOWN a 64-pixel-wide strip, R rows per wave, one source pixel per lane.
+//   * horizontal merge: where lane l+1 lands exactly one cell to the right of lane l (the normal case for
+//     a locally smooth flow), lane l hands its right-hand corner column (NE,SE) to lane l+1 with a wave
+//     shuffle, which adds it to its own left-hand column (NW,SW): same cells;
+//   * vertical merge: the bottom cell of the previous row is kept pending in registers and, where the
+//     current row lands exactly one cell lower, added to the current top cell before ONE atomic is issued.
+// Aligned regions cost ~(1+1/R)(1+1/64) atomics per source instead of 4; any lane that is not aligned with
+// its neighbour simply emits its own corners, so the result is exact for arbitrary flows.  Every atomic
+// wave-instruction addresses (mostly) consecutive cells of one row: the contiguous 256-B shape.
+__device__ __forceinline__ void emit_cell(float* __restrict__ plane, int cx, int cy, int W, int H, float v) {
+    if (cx >= 0 && cx < W && cy >= 0 && cy < H) atomicAdd(plane + (int64_t)cy * W + cx, v);
+}
+
+template <int MODE, int CB, int R>
+__global__ __launch_bounds__(256) void splat_strip_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                          const float* __restrict__ metric, float* __restrict__ acc,
+                                                          int C, int H, int W, int groups) {
+#pragma clang fp contract(off)
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int n = blockIdx.z / groups, grp = blockIdx.z % groups;
     const int x = blockIdx.x * 64 + lane;
+    const int ybase = (blockIdx.y * 4 + wv) * R;
+    if (ybase >= H) return;                                   // wave-uniform
     const int64_t HW = (int64_t)H * W;
-    const int CA = (MODE >= 1) ? C + 1 : C;             // accumulator channels
+    const int CA = (MODE >= 1) ? C + 1 : C;                   // accumulator channels
+    const int cbase = grp * CB;
     const float* fl = flow + (int64_t)n * 2 * HW;
+    float* ap = acc + ((int64_t)n * CA + cbase) * HW;
+    const bool xin = x < W;
 
-    for (int i = tid; i < CB * WH * WW; i += 256) (&win[0][0])[i] = 0.0f;
-
-    SplatGeom g[PPT];
-    int mnx = 0x7fffffff, mny = 0x7fffffff;
+    // phase A: issue every load of the strip segment (R rows) before any atomic, for memory-level parallelism
+    float fx[R], fy[R], mt[R], val[R][CB];
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-        const int y = blockIdx.y * TY + wv + 4 * q;
-        g[q].vnw = g[q].vne = g[q].vsw = g[q].vse = false;
-        if (x < W && y < H) {
-            const int64_t pix = (int64_t)y * W + x;
-            g[q] = splat_geom(x, y, fl[pix], fl[HW + pix], W, H);
-            if (g[q].vnw | g[q].vne | g[q].vsw | g[q].vse) {
-                mnx = min(mnx, max(g[q].x0, 0));
-                mny = min(mny, max(g[q].y0, 0));
-            }
+    for (int r = 0; r < R; ++r) {
+        const int y = ybase + r;
+        const bool ok = xin && y < H;
+        const int64_t pix = ok ? (int64_t)y * W + x : 0;      // clamped: every load below is unconditional
+        fx[r] = fl[pix];
+        fy[r] = fl[HW + pix];
+        mt[r] = 0.0f;
+        if ((MODE == 2 || MODE == 3) && metric != nullptr) mt[r] = metric[(int64_t)n * HW + pix];   // wave-uniform test
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int cc = cbase + c < C ? cbase + c : C - 1;
+            val[r][c] = in[((int64_t)n * C + cc) * HW + pix];
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        mnx = min(mnx, __shfl_xor(mnx, off));
-        mny = min(mny, __shfl_xor(mny, off));
-    }
-    if (lane == 0) { smin[0][wv] = mnx; smin[1][wv] = mny; }
-    __syncthreads();
-    const int ox = min(min(smin[0][0], smin[0][1]), min(smin[0][2], smin[0][3]));
-    const int oy = min(min(smin[1][0], smin[1][1]), min(smin[1][2], smin[1][3]));
-    if (ox == 0x7fffffff) return;                       // nothing of this tile lands inside the image
-
-    float* ap = acc + (int64_t)n * CA * HW;
+    for (int r = 0; r < R; ++r) {                             // pin the batch, then mask
+        const bool ok = xin && ybase + r < H;
+        fldr_pin(fx[r]); fldr_pin(fy[r]); fldr_pin(mt[r]);
+        fx[r] = ok ? fx[r] : 0.0f;
+        fy[r] = ok ? fy[r] : 0.0f;
+        mt[r] = ok ? mt[r] : 0.0f;
 #pragma unroll
-    for (int q = 0; q < PPT; ++q) {
-        if (!(g[q].vnw | g[q].vne | g[q].vsw | g[q].vse)) continue;
-        const int y = blockIdx.y * TY + wv + 4 * q;
-        const int64_t pix = (int64_t)y * W + x;
+        for (int c = 0; c < CB; ++c) {
+            fldr_pin(val[r][c]);
+            val[r][c] = (ok && cbase + c < C) ? val[r][c] : 0.0f;
+        }
+    }
+
+    bool pend_valid = false;
+    int pend_x = 0, pend_y = 0;
+    float pend_v[CB];
+#pragma unroll
+    for (int c = 0; c < CB; ++c) pend_v[c] = 0.0f;
+
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int y = ybase + r;
+        if (y >= H) break;                                    // wave-uniform
+        SplatGeom g;
+        g.x0 = g.y0 = 0; g.wnw = g.wne = g.wsw = g.wse = 0.0f;
+        g.vnw = g.vne = g.vsw = g.vse = false;
+        if (xin) g = splat_geom(x, y, fx[r], fy[r], W, H);
+        const bool valid = xin && (g.vnw | g.vne | g.vsw | g.vse);
         float wgt = 1.0f;
-        if (MODE == 2) wgt = metric[(int64_t)n * HW + pix];
-        if (MODE == 3 && metric != nullptr) wgt = expf(metric[(int64_t)n * HW + pix]);
-        const int wx = g[q].x0 - ox, wy = g[q].y0 - oy;                 // window coords of the NW corner (>= -1)
-        const bool in_win = wx >= 0 && wy >= 0 && wx + 1 < WW && wy + 1 < WH;
+        if (MODE == 2) wgt = mt[r];
+        if (MODE == 3 && metric != nullptr) wgt = expf(mt[r]);
+        // neighbour alignment
+        const int nx0 = __shfl_down(g.x0, 1), ny0 = __shfl_down(g.y0, 1);
+        const int nvalid = __shfl_down((int)valid, 1);
+        const bool merge_right = valid && lane < 63 && nvalid && nx0 == g.x0 + 1 && ny0 == g.y0;
+        const int left_merges = __shfl_up((int)merge_right, 1);      // executed by ALL lanes (no short-circuit)
+        const bool from_left = lane > 0 && left_merges != 0;
+        const bool aligned = pend_valid && valid && pend_x == g.x0 && pend_y == g.y0;
+        const bool emit_right = valid && !merge_right;
+        const bool emit_pend = pend_valid && !aligned;
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const int c = grp * CB + cb;
-            if (c >= CA) break;
-            float v;
-            if (c < C) {
-                v = in[((int64_t)n * C + c) * HW + pix];
-                if (MODE == 3) v = (v + 1.0f) / 2.0f;                     // softSplat.py:334
-                if (MODE >= 2) v = v * wgt;                               // :328 / :338
-            } else {
-                v = wgt;                                                  // normalisation channel
+        for (int c = 0; c < CB; ++c) {
+            if (cbase + c >= CA) break;                       // wave-uniform
+            float v = 0.0f;
+            if (valid) {
+                if (cbase + c < C) {
+                    v = val[r][c];
+                    if (MODE == 3) v = (v + 1.0f) / 2.0f;     // softSplat.py:334
+                    if (MODE >= 2) v = v * wgt;               // :328 / :338
+                } else {
+                    v = wgt;                                  // normalisation channel
+                }
             }
-            if (in_win) {
-                float* wp = &win[cb][wy * WW + wx];
-                if (g[q].vnw) atomicAdd(wp, v * g[q].wnw);
-                if (g[q].vne) atomicAdd(wp + 1, v * g[q].wne);
-                if (g[q].vsw) atomicAdd(wp + WW, v * g[q].wsw);
-                if (g[q].vse) atomicAdd(wp + WW + 1, v * g[q].wse);
-            } else {
-                splat_add(ap + (int64_t)c * HW, g[q], W, v);
+            const float ne = g.vne ? v * g.wne : 0.0f, se = g.vse ? v * g.wse : 0.0f;
+            const float lt = __shfl_up(ne, 1), lb = __shfl_up(se, 1);
+            float top = (g.vnw ? v * g.wnw : 0.0f) + (from_left ? lt : 0.0f);
+            const float bot = (g.vsw ? v * g.wsw : 0.0f) + (from_left ? lb : 0.0f);
+            float* plane = ap + (int64_t)c * HW;
+            if (emit_right) {
+                emit_cell(plane, g.x0 + 1, g.y0, W, H, ne);
+                emit_cell(plane, g.x0 + 1, g.y0 + 1, W, H, se);
             }
+            if (emit_pend) emit_cell(plane, pend_x, pend_y, W, H, pend_v[c]);
+            if (aligned) top += pend_v[c];
+            if (valid) emit_cell(plane, g.x0, g.y0, W, H, top);
+            pend_v[c] = bot;
         }
+        pend_valid = valid;
+        pend_x = g.x0;
+        pend_y = g.y0 + 1;
     }
-    __syncthreads();
-    for (int i = tid; i < WH * WW; i += 256) {
-        const int gy = oy + i / WW, gx = ox + i % WW;
-        if (gy >= H || gx >= W) continue;
+    if (pend_valid) {
 #pragma unroll
-        for (int cb = 0; cb < CB; ++cb) {
-            const int c = grp * CB + cb;
-            if (c >= CA) break;
-            const float v = win[cb][i];
-            if (v != 0.0f) atomicAdd(ap + (int64_t)c * HW + (int64_t)gy * W + gx, v);
+        for (int c = 0; c < CB; ++c) {
+            if (cbase + c >= CA) break;
+            emit_cell(ap + (int64_t)c * HW, pend_x, pend_y, W, H, pend_v[c]);
         }
     }
 }
@@ -146,13 +178,13 @@ template <int MODE>
 static void splat_launch(const float* in, const float* flow, const float* metric, float* acc, int N, int C, int H, int W,
                          hipStream_t s) {
     const int CA = (MODE >= 1) ? C + 1 : C;
-    if (CA <= 4) {        // images: 4 accumulator channels per workgroup, 16x64 source tile, 32x96 window (48 KiB)
-        dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 16), N);
-        hipLaunchKernelGGL((splat_tile_kernel<MODE, 4, 16, 32, 96>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, 1);
-    } else {              // feature maps: channel groups of 7 (49 = 7 x 7), 8x64 tile, 20x96 window (52.5 KiB)
+    if (CA <= 4) {        // images: all (<=4) accumulator channels in one wave, 8 rows per wave
+        dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 8), N);
+        hipLaunchKernelGGL((splat_strip_kernel<MODE, 4, 8>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, 1);
+    } else {              // feature maps: channel groups of 7 (49 = 7 x 7) for parallelism, 8 rows per wave
         const int groups = fldr_cdiv(CA, 7);
-        dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 8), N * groups);
-        hipLaunchKernelGGL((splat_tile_kernel<MODE, 7, 8, 20, 96>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, groups);
+        dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 8), N * groups);
+        hipLaunchKernelGGL((splat_strip_kernel<MODE, 7, 8>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, groups);
     }
 }
 
@@ -233,15 +265,20 @@ __global__ __launch_bounds__(256) void bwarp_kernel(const float* __restrict__ x,
     const float* xp = x + (int64_t)n * C * HW;
     float* op = out + (int64_t)n * C * HW + pix;
     if (xs_mode == 0) {
-        for (int c = 0; c < C; ++c) op[(int64_t)c * HW] = fldr_tap_sample(tp, xp + (int64_t)c * HW, W) * m;
+        for (int c = 0; c < C; ++c) op[(int64_t)c * HW] = fldr_tap_sample(tp, xp + (int64_t)c * HW, W, H) * m;
     } else {
         for (int c = 0; c < C; ++c) {
-            const float* p = xp + (int64_t)c * HW + (int64_t)tp.y0 * W + tp.x0;
+            const float* pl = xp + (int64_t)c * HW;
+            const int xa = min(max(tp.x0, 0), W - 1), xb = min(max(tp.x0 + 1, 0), W - 1);
+            const int ya = min(max(tp.y0, 0), H - 1), yb = min(max(tp.y0 + 1, 0), H - 1);
+            float pnw = pl[(int64_t)ya * W + xa], pne = pl[(int64_t)ya * W + xb];
+            float psw = pl[(int64_t)yb * W + xa], pse = pl[(int64_t)yb * W + xb];
+            fldr_pin(pnw); fldr_pin(pne); fldr_pin(psw); fldr_pin(pse);
             float v = 0.0f;
-            if (tp.vnw) v += (p[0] * xs) * tp.wnw;
-            if (tp.vne) v += (p[1] * xs) * tp.wne;
-            if (tp.vsw) v += (p[W] * xs) * tp.wsw;
-            if (tp.vse) v += (p[W + 1] * xs) * tp.wse;
+            v += tp.vnw ? (pnw * xs) * tp.wnw : 0.0f;
+            v += tp.vne ? (pne * xs) * tp.wne : 0.0f;
+            v += tp.vsw ? (psw * xs) * tp.wsw : 0.0f;
+            v += tp.vse ? (pse * xs) * tp.wse : 0.0f;
             op[(int64_t)c * HW] = v * m;
         }
     }
@@ -284,7 +321,7 @@ __global__ __launch_bounds__(256) void zmetric_kernel(const float* __restrict__ 
     const float* op = other + (int64_t)n * C * HW;
     float acc = 0.0f;
     for (int c = 0; c < C; ++c) {
-        float wv = fldr_tap_sample(t, op + (int64_t)c * HW, W) * m;
+        float wv = fldr_tap_sample(t, op + (int64_t)c * HW, W, H) * m;
         acc += alpha * fabsf(sp[(int64_t)c * HW] - wv);
     }
     z[(int64_t)n * HW + pix] = acc / (float)C;

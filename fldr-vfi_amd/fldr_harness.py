@@ -128,18 +128,29 @@ def frames_from_uint8(u8):
 
 
 def synthetic_pair(H, W, seed=0, quadrant=False, device="cpu"):
-    """Seeded synthetic uint8 frame pair used by bench.py and the tests: a smooth random base
-    image; I1 is I0 shifted by (6,4) px, or by (+-12,+-8) px per quadrant to force occlusions/holes."""
+    """Seeded synthetic uint8 frame pair (bench.py, tests, golden fixtures): a multi-octave (1/f-like) random
+    texture, so that every pyramid level sees structure as in natural video; I1 is I0 shifted by (6,4) px, or by
+    (+-12,+-8) px per quadrant to force occlusions/holes.  (5x5-smoothed white noise, the first recipe, has no
+    content left below 1/8 resolution and the flow network then predicts meaningless +-40 px flows.)"""
     g = torch.Generator().manual_seed(seed)
-    base = F.avg_pool2d(torch.rand(1, 3, H + 48, W + 48, generator=g), 5, 1, 2)
-    I0 = base[..., 16:H + 16, 16:W + 16]
+    Hb, Wb = H + 64, W + 64
+    base = torch.zeros(1, 3, Hb, Wb)
+    for o in range(8):
+        s = 2 ** o
+        n = torch.rand(1, 3, -(-Hb // s) + 2, -(-Wb // s) + 2, generator=g)
+        if o:
+            n = F.interpolate(n, scale_factor=s, mode="bilinear", align_corners=False)
+        base += n[..., :Hb, :Wb] * (1.5 ** o)
+    base = (base - base.amin()) / (base.amax() - base.amin())
+    I0 = base[..., 32:H + 32, 32:W + 32]
     if not quadrant:
-        I1 = base[..., 20:H + 20, 22:W + 22]
+        I1 = base[..., 36:H + 36, 38:W + 38]
     else:
         I1 = I0.clone()
         h2, w2 = H // 2, W // 2
         for (ys, xs, dy, dx) in ((0, 0, 8, 12), (0, 1, -8, 12), (1, 0, 8, -12), (1, 1, -8, -12)):
             y0, x0 = ys * h2, xs * w2
-            I1[..., y0:y0 + h2, x0:x0 + w2] = base[..., 16 + y0 + dy:16 + y0 + dy + h2, 16 + x0 + dx:16 + x0 + dx + w2]
+            I1[..., y0:y0 + h2, x0:x0 + w2] = base[..., 32 + y0 + dy:32 + y0 + dy + h2, 32 + x0 + dx:32 + x0 + dx + w2]
     u8 = lambda a: (a.clamp(0, 1) * 255).round().to(torch.uint8)
     return torch.stack([u8(I0[0]), u8(I1[0])], 0).to(device)
+

@@ -32,7 +32,7 @@ def test_conv_desc_layout_matches_header():
     assert ctypes.sizeof(fldr_hip.ConvDesc) == 12 * 8 + 12 * 8 + 12 * 4 + 12 * 4 + 8 + 4 * 8 + 12 * 4
     assert fldr_hip.lib().fldr_conv_prepack_size(96, 100, 3) == 104 * 9 * 96
     assert fldr_hip.lib().fldr_conv_prepack_size(6, 16, 3) == 16 * 9 * 16
-    assert fldr_hip.lib().fldr_conv_prepack_size(16, 26, 4) == 28 * 16 * 16
+    assert fldr_hip.lib().fldr_conv_prepack_size(16, 26, 4) == 28 * 272      # channel rows padded to 16 mod 32 floats
     assert fldr_hip.lib().fldr_conv_prepack_size(128, 16, 3) < 0
 
 
