@@ -27,9 +27,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix pea
 PEAK_HBM_GBPS = 8000.0
 
 
-def shard_pairs(n_pairs, rank, world):
-    """Static round-robin of frame PAIRS over ranks: pair i -> rank i % world."""
-    return [i for i in range(n_pairs) if i % world == rank]
+from fldr_harness import shard_pairs, host_cores, max_over_ranks  # noqa: E402
 
 
 def dominant_conv_roofline(model, pyr, steps):
@@ -54,9 +52,19 @@ def dominant_conv_roofline(model, pyr, steps):
     ms = e0.elapsed_time(e1) / n
     flops = 2.0 * 96 * 96 * 9 * h * w
     ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_mfma_kernel<3,1,32,3,2,8> (3x3 96->96 @%dx%d, fp32 MFMA)" % (h, w),
+    return {"bound": "mfma", "kernel": "conv_mfma_kernel<3,1,32,3,1,8> (3x3 96->96 @%dx%d, fp32 MFMA)" % (h, w),
             "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": None, "launch_ms": round(ms, 4), "flops_per_launch": flops}
+            "traffic": _measured_traffic(), "launch_ms": round(ms, 4), "flops_per_launch": flops}
+
+
+def _measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None when no measurement is on file."""
+    p = os.path.join(ROOT, "profiles", "r01_conv96_traffic.json")
+    try:
+        return json.load(open(p))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
 
 
 def cpu_baseline(frames_cpu, t_cpu):
@@ -65,11 +73,7 @@ def cpu_baseline(frames_cpu, t_cpu):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fldr_oracle as O
     import fldr_harness as Hn
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except Exception:
-        pass
+    cores = host_cores()
     torch.set_num_threads(cores)
     w = O.load_weights(Hn.DEFAULT_WEIGHTS)
     pyr = O.pad_and_pyramid(frames_cpu)
@@ -132,10 +136,7 @@ def main():
         torch.cuda.synchronize()
         dt_e2e = (time.perf_counter() - t1) / max(1, a.steps // 4)
     assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
-    tt = torch.tensor([dt], device=device, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = tt.item()
+    dt = max_over_ranks(dt, device)
 
     if rank == 0:
         res = {

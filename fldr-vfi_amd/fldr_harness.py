@@ -154,3 +154,53 @@ def synthetic_pair(H, W, seed=0, quadrant=False, device="cpu"):
     u8 = lambda a: (a.clamp(0, 1) * 255).round().to(torch.uint8)
     return torch.stack([u8(I0[0]), u8(I1[0])], 0).to(device)
 
+
+
+# ---- data-parallel helpers (one process per GPU; frame pairs are independent: SURVEY 8e) -----------------
+def shard_pairs(n_pairs, rank, world):
+    """Static round-robin of frame PAIRS (not outputs) over ranks: pair i -> rank i % world, so that all t values
+    of a pair stay on one rank."""
+    return [i for i in range(n_pairs) if i % world == rank]
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX-reduce a Python float over the default process group (no-op without one)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return float(value)
+    t = torch.tensor([value], device=device, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+
+def reduce_psnr(psnr_sum, count, device="cpu"):
+    """SUM-reduce (sum of PSNRs, number of frames) over ranks -> global mean PSNR: the only collective the
+    evaluation loop needs (16 bytes; main.py:962 keeps these in AverageClass on a single process)."""
+    import torch.distributed as dist
+    t = torch.tensor([psnr_sum, float(count)], device=device, dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return (t[0] / t[1].clamp(min=1)).item(), int(t[1].item())
+
+
+def host_cores():
+    """CPU cores this process may actually use: min(affinity, cgroup cpu.max quota); 16 if unknown but huge."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return min(n, 16) if n > 64 else n

@@ -360,3 +360,25 @@ def test_4k_forward_matches_oracle(hip, oracle, weights, dev, model, frames4k):
     p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
     print("4K: max|err| %.2e mean %.2e; PSNR(8-bit) gpu vs oracle %.1f dB" % (err.max().item(), err.mean().item(), p))
     assert err.mean().item() < 1e-4 and (err > 4e-3).double().mean().item() < 1e-4 and p > 55.0
+
+
+def test_pwcnet_forward_runs_on_the_correlation_kernel(hip, oracle, dev):
+    """a17: signature + wiring only (weights are not shipped: numerics unpinned)."""
+    from OpticalFlow.PWCNet import PWCNet
+    from OpticalFlow import correlation
+    torch.manual_seed(0)
+    net = PWCNet().to(dev).eval()
+    a = torch.rand(2, 3, 100, 180, device=dev)
+    b = torch.rand(2, 3, 100, 180, device=dev)
+    calls = []
+    orig = correlation.FunctionCorrelation
+    correlation.FunctionCorrelation = lambda f, s: (calls.append((f.shape, f.detach().cpu(), s.detach().cpu())), orig(f, s))[1]
+    try:
+        with torch.no_grad():
+            flow = net(a, b)
+    finally:
+        correlation.FunctionCorrelation = orig
+    assert flow.shape == (2, 2, 100, 180) and torch.isfinite(flow).all()
+    assert [c[0][1] for c in calls] == [196, 128, 96, 64, 32]          # one cost volume per decoder level
+    _, f, s = calls[0]
+    _cmp(orig(f.to(dev), s.to(dev)), oracle.correlation(f, s), atol=1e-5, rtol=1e-5, what="in-network cost volume")

@@ -119,3 +119,12 @@ def test_psnr_and_uint8(oracle):
     assert img.shape == (2, 2, 3) and img[0, 0, 0] == 0 and img[0, 1, 0] == 255 and img[1, 0, 0] == 128 and img[1, 1, 0] == 255
     assert Hn.psnr(img, img) == float("inf")
     assert Hn.psnr(img, img + 5) == pytest.approx(oracle.psnr(img, img + 5))
+
+
+def test_pwcnet_state_dict_layout_matches_reference():
+    from OpticalFlow.PWCNet import PWCNet
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "pwcnet_state_dict_keys.json")))
+    own = PWCNet().state_dict()
+    assert set(own) == set(ref), set(own) ^ set(ref)
+    for k, shape in ref.items():
+        assert list(own[k].shape) == shape, k

@@ -269,6 +269,9 @@ def main():
     import json
     with open(os.path.join(gold, "state_dict_keys.json"), "w") as f:
         json.dump({k: [list(v.shape), str(v.dtype)] for k, v in ckpt["state_dict_Model"].items()}, f, indent=0)
+    from OpticalFlow.PWCNet import PWCNet as RefPWC          # reference class, for its state-dict layout only
+    with open(os.path.join(gold, "pwcnet_state_dict_keys.json"), "w") as f:
+        json.dump({k: list(v.shape) for k, v in RefPWC().state_dict().items()}, f, indent=0)
     with open(os.path.join(gold, "args_papermodel_test5scales.json"), "w") as f:
         json.dump({n: getattr(args, n) for n in names if hasattr(args, n)}, f, indent=1, sort_keys=True)
 
