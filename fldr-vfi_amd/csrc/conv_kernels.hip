@@ -19,6 +19,20 @@
 #include "common.h"
 #include <type_traits>
 
+#ifdef FLDR_STAMPS
+// Diagnostic build only (tools/stamps): per-phase s_memtime sums of workgroup 0, written to a buffer no kernel reads.
+#ifndef FLDR_STAMP_BLOCK
+#define FLDR_STAMP_BLOCK 0
+#endif
+__device__ unsigned long long fldr_stamp_buf[4 * 8];
+#define STAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int fldr_debug_read_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_stamp_buf), sizeof(unsigned long long) * 32);
+}
+#else
+#define STAMP(var)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -36,6 +50,7 @@ struct ConvArgs {
     int32_t Hin, Win, Hout, Wout;
     int32_t relu;
     int32_t tiles_x;
+    int32_t groups;            // output-channel groups of MTOT channels; blockIdx.x = tile * groups + group
 };
 
 constexpr int pad16mod32(int v) { return v + ((16 - (v % 32)) + 32) % 32; }
@@ -76,7 +91,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //     selection resolved at load time) and written to LDS after the MFMA phase,
 // and ONE barrier per chunk separates the stages.
 template <int KS, int STRIDE, int MT, int NMT, int PT, int CC_>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, (MT == 16 && NMT == 3) ? 3 : 2) void conv_mfma_kernel(ConvArgs a) {
     using Cfg = ConvCfg<KS, STRIDE, MT, NMT, PT, CC_>;
     constexpr int CC = Cfg::CC, IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IWH = Cfg::IWH, ICH = Cfg::ICH;
     constexpr int TAPS = Cfg::TAPS, MTOT = Cfg::MTOT, WCH = Cfg::WCH, KG = Cfg::KG;
@@ -85,7 +100,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = blockIdx.y;
-    const int tile_y = blockIdx.x / a.tiles_x, tile_x = blockIdx.x % a.tiles_x;
+    const int grp = blockIdx.x % a.groups, tile = blockIdx.x / a.groups;
+    const int cbase = grp * MTOT;                            // first output channel of this workgroup
+    const int tile_y = tile / a.tiles_x, tile_x = tile % a.tiles_x;
     const int oy0 = tile_y * Cfg::TH, ox0 = tile_x * Cfg::TW;
     const int iy0 = oy0 * STRIDE - 1, ix0 = ox0 * STRIDE - 1;          // pad = 1
 
@@ -126,6 +143,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[m][p][r] = 0.0f;
 
     float pre[CPW][NI];
+    const int cin_pad = (a.cin + CC - 1) / CC * CC;
 
     // Per-channel plane pointer table (bit 0 = "stored at half resolution"), built once: resolving the
     // source of a channel from the kernel arguments needs dynamically indexed loads, which must not sit
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
     __syncthreads();
 
     auto issue_weights = [&](int c0, float* stage) {
-        const float* g = a.wpack + (int64_t)c0 * WCH;
+        const float* g = a.wpack + ((int64_t)grp * cin_pad + c0) * WCH;
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             const int piece = i * 256 + wave * 64;                    // wave-uniform piece base (x16 B)
@@ -182,23 +200,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         }
     };
 
-    const int cin_pad = (a.cin + CC - 1) / CC * CC;
     issue_weights(0, smem);
     load_inputs(0);
     store_inputs(smem);
     __syncthreads();
 
+#ifdef FLDR_STAMPS
+    unsigned long long s_issue = 0, s_mfma = 0, s_store = 0, s_bar = 0, s_n = 0;
+    STAMP(t_begin)
+#endif
     int stage = 0;
     for (int c0 = 0; c0 < cin_pad; c0 += CC, stage ^= 1) {
         float* cur = smem + stage * BUF;
         float* nxt = smem + (stage ^ 1) * BUF;
         const bool more = c0 + CC < cin_pad;
-        if (more) {
-            issue_weights(c0 + CC, nxt);
-            load_inputs(c0 + CC);
-        }
+        STAMP(t0)
+        STAMP(t1)
         {
-            float av[2][NMT], bv[2][PT];
+            float av[3][NMT], bv[3][PT];
             auto ld = [&](int buf, int k) {
                 const int cg = (k / TAPS) * KG, t = k % TAPS;
                 const int dy = t / KS, dx = t % KS;
@@ -211,25 +230,44 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
                 for (int p = 0; p < PT; ++p) bv[buf][p] = ic[boff[p]];
             };
             ld(0, 0);
+            if (Cfg::KSTEPS > 1) ld(1, 1);
 #pragma unroll
             for (int k = 0; k < Cfg::KSTEPS; ++k) {
-                if (k + 1 < Cfg::KSTEPS) ld((k + 1) & 1, k + 1);       // operands of step k+1 fly under the MFMAs of step k
+                // staging of the NEXT chunk is issued from inside the MFMA stream so that it overlaps matrix work
+                if (k == 1 && more) issue_weights(c0 + CC, nxt);
+                if (k == 2 && more) load_inputs(c0 + CC);
+                if (k == Cfg::KSTEPS - 2 && more) store_inputs(nxt);
+                if (k + 2 < Cfg::KSTEPS) ld((k + 2) % 3, k + 2);       // operands of step k+2 fly under the MFMAs of steps k, k+1
 #pragma unroll
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
                     for (int p = 0; p < PT; ++p) {
-                        if constexpr (MT == 32) acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k & 1][m], bv[k & 1][p], acc[m][p], 0, 0, 0);
-                        else                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k & 1][m], bv[k & 1][p], acc[m][p], 0, 0, 0);
+                        if constexpr (MT == 32) acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[k % 3][m], bv[k % 3][p], acc[m][p], 0, 0, 0);
+                        else                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[k % 3][m], bv[k % 3][p], acc[m][p], 0, 0, 0);
                     }
-                __builtin_amdgcn_sched_group_barrier(0x100, NMT + PT, 0);   // DS reads of step k+1 ...
+                __builtin_amdgcn_sched_group_barrier(0x100, NMT + PT, 0);   // DS reads of step k+2 ...
                 __builtin_amdgcn_sched_group_barrier(0x008, NMT * PT, 0);   // ... then the MFMAs of step k
             }
         }
-        if (more) store_inputs(nxt);
+        STAMP(t2)
+        STAMP(t3)
         __syncthreads();
+        STAMP(t4)
+#ifdef FLDR_STAMPS
+        s_issue += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3; s_n += 1;
+#endif
     }
+#ifdef FLDR_STAMPS
+    STAMP(t_loop_end)
+#endif
 
     // ---- epilogue: bias, ReLU, residual, store (lane = pixel column, registers = output channels) ----
+#ifdef FLDR_STAMPS
+    if (blockIdx.x == FLDR_STAMP_BLOCK && blockIdx.y == 0 && lane == 0) {
+        unsigned long long* o = fldr_stamp_buf + wave * 8;
+        o[0] = s_issue; o[1] = s_mfma; o[2] = s_store; o[3] = s_bar; o[4] = s_n; o[5] = t_loop_end - t_begin;
+    }
+#endif
     // All bias / residual loads are issued first (clamped addresses, no branches), then combined and stored.
     constexpr int NR = MT == 32 ? 16 : 4;
     const int64_t HWo = (int64_t)a.Hout * a.Wout;
@@ -245,7 +283,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                int co = cbase + (MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r);
                 co = co < a.cout ? co : a.cout - 1;
                 bias_r[m][r] = a.bias[co];
             }
@@ -266,7 +304,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
             for (int m = 0; m < NMT; ++m)
 #pragma unroll
                 for (int r = 0; r < NR; ++r) {
-                    int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                    int co = cbase + (MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r);
                     co = co < a.cout_store ? co : a.cout_store - 1;
                     res_r[m][r] = resn[(int64_t)co * HWo + po];
                 }
@@ -279,7 +317,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
         for (int m = 0; m < NMT; ++m) {
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                const int co = cbase + (MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r);
                 float v = acc[m][p][r] + bias_r[m][r];
                 if (a.relu) v = fmaxf(v, 0.0f);
                 v += res_r[m][r];
@@ -292,42 +330,54 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a) {
 // ------------------------------------------------------------------------------------------------
 // weight prepack: [cout,cin,k,k] -> [cin_pad][taps][mtot], zero padded
 // ------------------------------------------------------------------------------------------------
-static inline void conv_geometry(int cout, int ksize, int& mt, int& nmt, int& cc) {
-    mt = cout <= 16 ? 16 : 32;
-    nmt = (cout + mt - 1) / mt;
+// Instance selection: M shape (16|32), M tiles per workgroup, output-channel groups, cin chunk.
+//   cout <= 16 : 16x16x4, 1 tile           cout <= 32 : 32x32x2, 1 tile        cout <= 48 : 16x16x4, 3 tiles
+//   cout <= 64 : 32x32x2, 2 tiles          cout <= 96 : 16x16x4, 3 tiles x 2 groups (half-size quanta: the
+//   96-channel layers dominate and 2160 half tiles balance over 256 CUs far better than 1080 full ones)
+static inline void conv_geometry(int cout, int ksize, int& mt, int& nmt, int& groups, int& cc) {
+    groups = 1;
+    if (cout <= 16)      { mt = 16; nmt = 1; }
+    else if (cout <= 32) { mt = 32; nmt = 1; }
+    else if (cout <= 48) { mt = 16; nmt = 3; }
+    else if (cout <= 64) { mt = 32; nmt = 2; }
+    else                 { mt = 16; nmt = 3; groups = 2; }
     cc = ksize == 4 ? 4 : 8;
 }
 
-__global__ void conv_prepack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int taps,
-                                    int mtot, int wch, int64_t total) {
+static inline int conv_wch(int ksize, int mt, int nmt) {
+    int wch = ksize * ksize * nmt * mt;
+    return mt == 16 ? pad16mod32(wch) : wch;
+}
+
+// wpack layout: [group][cin_pad][WCH], WCH = taps * MTOT (+ padding), element (t, m) of a row at t * MTOT + m
+__global__ void conv_prepack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int cin_pad,
+                                    int taps, int mtot, int wch, int64_t total) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
-    int r = (int)(i % wch);                 // position inside the channel row: [tap][m], then padding
-    int c = (int)(i / wch);
-    int m = r % mtot, t = r / mtot;
+    int r = (int)(i % wch);
+    int c = (int)((i / wch) % cin_pad);
+    int g = (int)(i / ((int64_t)wch * cin_pad));
+    int m = g * mtot + r % mtot, t = r / mtot;
     wp[i] = (t < taps && m < cout && c < cin) ? w[((int64_t)m * cin + c) * taps + t] : 0.0f;
 }
 
 extern "C" int64_t fldr_conv_prepack_size(int cout, int cin, int ksize) {
-    if (cout <= 0 || cin <= 0 || (ksize != 3 && ksize != 4) || cout > 96) return FLDR_E_ARG;
-    int mt, nmt, cc;
-    conv_geometry(cout, ksize, mt, nmt, cc);
+    if (cout <= 0 || cin <= 0 || (ksize != 3 && ksize != 4) || cout > 96 || cin > 112) return FLDR_E_ARG;
+    int mt, nmt, groups, cc;
+    conv_geometry(cout, ksize, mt, nmt, groups, cc);
     int cin_pad = (cin + cc - 1) / cc * cc;
-    int wch = ksize * ksize * nmt * mt;
-    if (mt == 16) wch = pad16mod32(wch);
-    return (int64_t)cin_pad * wch;
+    return (int64_t)groups * cin_pad * conv_wch(ksize, mt, nmt);
 }
 
 extern "C" int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream) {
     FLDR_CHECK_ARG(weight && wpack);
     int64_t total = fldr_conv_prepack_size(cout, cin, ksize);
     if (total < 0) return (int)total;
-    int mt, nmt, cc;
-    conv_geometry(cout, ksize, mt, nmt, cc);
-    int wch = ksize * ksize * nmt * mt;
-    if (mt == 16) wch = pad16mod32(wch);
+    int mt, nmt, groups, cc;
+    conv_geometry(cout, ksize, mt, nmt, groups, cc);
+    int cin_pad = (cin + cc - 1) / cc * cc;
     hipLaunchKernelGGL(conv_prepack_kernel, dim3(fldr_cdiv(total, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin,
-                       ksize * ksize, nmt * mt, wch, total);
+                       cin_pad, ksize * ksize, nmt * mt, conv_wch(ksize, mt, nmt), total);
     FLDR_LAUNCH_RET();
 }
 
@@ -345,7 +395,7 @@ static int conv_launch(const ConvArgs& a, int N, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>), dim3(b.tiles_x * tiles_y, N), dim3(256), lds, s, b);
+    hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>), dim3(b.tiles_x * tiles_y * b.groups, N), dim3(256), lds, s, b);
     FLDR_LAUNCH_RET();
 }
 
@@ -379,17 +429,18 @@ extern "C" int fldr_conv2d(const fldr_conv_desc* d, fldr_stream_t stream) {
     a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
     a.Hin = d->Hin; a.Win = d->Win; a.Hout = d->Hout; a.Wout = d->Wout; a.relu = d->relu; a.tiles_x = 0;
     hipStream_t s = fldr_s(stream);
-    int mt, nmt, cc;
-    conv_geometry(d->cout, d->ksize, mt, nmt, cc);
+    int mt, nmt, groups, cc;
+    conv_geometry(d->cout, d->ksize, mt, nmt, groups, cc);
+    a.groups = groups;
     if (d->ksize == 3) {
-        if (mt == 16) return conv_launch<3, 1, 16, 1, 4, 8>(a, d->N, s);
-        if (nmt == 1) return conv_launch<3, 1, 32, 1, 2, 8>(a, d->N, s);
-        if (nmt == 2) return conv_launch<3, 1, 32, 2, 1, 8>(a, d->N, s);
-        return conv_launch<3, 1, 32, 3, 1, 8>(a, d->N, s);
+        if (mt == 16 && nmt == 1) return conv_launch<3, 1, 16, 1, 4, 8>(a, d->N, s);
+        if (mt == 16)             return conv_launch<3, 1, 16, 3, 2, 8>(a, d->N, s);
+        if (nmt == 1)             return conv_launch<3, 1, 32, 1, 2, 8>(a, d->N, s);
+        return conv_launch<3, 1, 32, 2, 1, 8>(a, d->N, s);
     } else {
-        if (mt == 16) return conv_launch<4, 2, 16, 1, 4, 4>(a, d->N, s);
-        if (nmt == 1) return conv_launch<4, 2, 32, 1, 2, 4>(a, d->N, s);
-        if (nmt == 2) return conv_launch<4, 2, 32, 2, 2, 4>(a, d->N, s);
+        if (mt == 16 && nmt == 1) return conv_launch<4, 2, 16, 1, 4, 4>(a, d->N, s);
+        if (mt == 32 && nmt == 1) return conv_launch<4, 2, 32, 1, 2, 4>(a, d->N, s);
+        if (mt == 32 && nmt == 2) return conv_launch<4, 2, 32, 2, 2, 4>(a, d->N, s);
         return FLDR_E_ARG;
     }
 }
@@ -402,4 +453,23 @@ extern "C" const char* fldr_error_string(int code) {
     if (code == FLDR_E_SHAPE) return "fldr: shape constraint violated";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "fldr: unknown error";
+}
+
+// Diagnostic: resident workgroups per CU the runtime reports for the main 3x3 instances at their LDS sizes.
+extern "C" int fldr_debug_conv_occupancy(int* out4) {
+    int n = 0;
+    hipError_t e;
+    {
+        using Cfg = ConvCfg<3, 1, 16, 3, 2, 8>;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mfma_kernel<3, 1, 16, 3, 2, 8>, 256, sizeof(float) * Cfg::LDS_FLOATS);
+        if (e != hipSuccess) return (int)e;
+        out4[0] = n; out4[1] = (int)(sizeof(float) * Cfg::LDS_FLOATS);
+    }
+    {
+        using Cfg = ConvCfg<3, 1, 32, 2, 1, 8>;
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, conv_mfma_kernel<3, 1, 32, 2, 1, 8>, 256, sizeof(float) * Cfg::LDS_FLOATS);
+        if (e != hipSuccess) return (int)e;
+        out4[2] = n; out4[3] = (int)(sizeof(float) * Cfg::LDS_FLOATS);
+    }
+    return 0;
 }
