@@ -1,0 +1,169 @@
+// Fused end of the network: PCARefineUNet.dec3 on the nearest-x2 upsampled dec2 output (fLDRnet.py:642-643)
+// + occlusion softmax / T + 6-way blend in fp64 (fLDRnet.py:511-524), one kernel, refine_out never stored.
+//
+// Nearest x2 upsampling followed by a 3x3 / pad 1 convolution is, for each of the four output phases (a,b) of
+// a low-resolution pixel (i,j), a 2x2 convolution over low-res rows {i-1+a, i+a} and columns {j-1+b, j+b} whose
+// weights are sums of the 3x3 taps that fall on the same low-res pixel (rows: a=0 -> {w0, w1+w2}, a=1 ->
+// {w0+w1, w2}; same for columns).  Zero padding of the upsampled image equals zero padding of the low-res one.
+// That is 4 taps instead of 9 (2.25x fewer MACs) and no redundant reads.  With 16 -> 6 channels this layer
+// is far too thin for the matrix cores (6 of 16 MFMA rows would be useful), so it runs on the vector ALUs with
+// the phase weights as scalar (SGPR) operands: one thread = one low-res pixel = 2x2 output pixels x 6 logits,
+// the 8x32 low-res tile (+halo) of all 16 input channels staged once in LDS.  HBM-bound by the 18 candidate
+// planes + the fp64 frame it writes.
+#include "common.h"
+
+#define D3_CIN 16
+#define D3_COUT 6
+#define D3_TH 8
+#define D3_TW 32
+
+// weff[c][phase][co][tap], tap = dy2*2+dx2  (1536 floats)
+__global__ void dec3_prepack_kernel(const float* __restrict__ w, float* __restrict__ weff) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= D3_CIN * 4 * D3_COUT * 4) return;
+    const int tap = i & 3, co = (i >> 2) % D3_COUT, ph = (i / (4 * D3_COUT)) & 3, c = i / (16 * D3_COUT);
+    const int a = ph >> 1, b = ph & 1, dy2 = tap >> 1, dx2 = tap & 1;
+    // 3x3 rows covered by low-res row (a + dy2 - ... ): a=0: dy2=0 -> {0}, dy2=1 -> {1,2};  a=1: dy2=0 -> {0,1}, dy2=1 -> {2}
+    const int r0 = a == 0 ? (dy2 == 0 ? 0 : 1) : (dy2 == 0 ? 0 : 2), r1 = a == 0 ? (dy2 == 0 ? 0 : 2) : (dy2 == 0 ? 1 : 2);
+    const int c0 = b == 0 ? (dx2 == 0 ? 0 : 1) : (dx2 == 0 ? 0 : 2), c1 = b == 0 ? (dx2 == 0 ? 0 : 2) : (dx2 == 0 ? 1 : 2);
+    const float* wk = w + ((int64_t)co * D3_CIN + c) * 9;
+    float s = 0.0f;
+    for (int r = r0; r <= r1; ++r)
+        for (int q = c0; q <= c1; ++q) s += wk[r * 3 + q];
+    weff[i] = s;
+}
+
+struct FinalArgs {
+    const float* cand[6];
+    int64_t bstride[6];
+};
+
+template <typename OUT>
+__global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict__ d2, const float* __restrict__ weff,
+                                                         const float* __restrict__ bias, FinalArgs cd,
+                                                         const float* __restrict__ tv, double T, OUT* __restrict__ out,
+                                                         float* __restrict__ refine_dbg, int H, int W) {
+    const int h = H >> 1, w = W >> 1;
+    __shared__ float tile[D3_CIN][D3_TH + 2][D3_TW + 2];
+    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int i0 = blockIdx.y * D3_TH, j0 = blockIdx.x * D3_TW, n = blockIdx.z;
+    const float* src = d2 + (int64_t)n * D3_CIN * h * w;
+    constexpr int TILE_E = (D3_TH + 2) * (D3_TW + 2);
+    constexpr int NLD = (D3_CIN * TILE_E + 255) / 256;
+    float st[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {                      // unconditional clamped loads, then mask (see common.h)
+        const int e = tid + 256 * q;
+        const int c = min(e / TILE_E, D3_CIN - 1), r = e % TILE_E;
+        const int gy = i0 - 1 + r / (D3_TW + 2), gx = j0 - 1 + r % (D3_TW + 2);
+        const int cy = min(max(gy, 0), h - 1), cx = min(max(gx, 0), w - 1);
+        st[q] = src[((int64_t)c * h + cy) * w + cx];
+    }
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int e = tid + 256 * q;
+        const int r = e % TILE_E;
+        const int gy = i0 - 1 + r / (D3_TW + 2), gx = j0 - 1 + r % (D3_TW + 2);
+        fldr_pin(st[q]);
+        if (e < D3_CIN * TILE_E) (&tile[0][0][0])[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? st[q] : 0.0f;
+    }
+    __syncthreads();
+
+    float acc[4][D3_COUT];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int co = 0; co < D3_COUT; ++co) acc[ph][co] = bias[co];
+#pragma unroll 2
+    for (int c = 0; c < D3_CIN; ++c) {
+        float x[3][3];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) x[dy][dx] = tile[c][ty + dy][tx + dx];
+        const float* wc = weff + c * (4 * D3_COUT * 4);      // wave-uniform -> scalar loads
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int a = ph >> 1, b = ph & 1;
+#pragma unroll
+            for (int co = 0; co < D3_COUT; ++co) {
+                const float* wq = wc + (ph * D3_COUT + co) * 4;
+                float s = acc[ph][co];
+                s = fmaf(wq[0], x[a][b], s);
+                s = fmaf(wq[1], x[a][b + 1], s);
+                s = fmaf(wq[2], x[a + 1][b], s);
+                s = fmaf(wq[3], x[a + 1][b + 1], s);
+                acc[ph][co] = s;
+            }
+        }
+    }
+
+    const int li = i0 + ty, lj = j0 + tx;
+    if (li >= h || lj >= w) return;
+    const int64_t HW = (int64_t)H * W;
+    const float t = tv[n];
+    const double w1 = (double)t, w0 = (double)(1.0f - t);
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int64_t po = (int64_t)(2 * li + a) * W + 2 * lj;           // two horizontally adjacent output pixels
+        float2 cv[6][3];
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                cv[k][ch] = *reinterpret_cast<const float2*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * HW + po);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma clang fp contract(off)
+            const int ph = a * 2 + b;
+            if (refine_dbg) {
+#pragma unroll
+                for (int co = 0; co < D3_COUT; ++co) refine_dbg[((int64_t)n * D3_COUT + co) * HW + po + b] = acc[ph][co];
+            }
+            double s[6], mx = -1.0e300;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { s[k] = (double)acc[ph][k] / T; mx = s[k] > mx ? s[k] : mx; }
+            double sum = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { s[k] = exp(s[k] - mx); sum += s[k]; }
+            double wo[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) wo[k] = ((k & 1) ? w1 : w0) * (s[k] / sum);
+            double div = ((wo[0] + wo[1]) + wo[2]) + wo[3];               // fLDRnet.py:517
+            div = div + (wo[4] + wo[5]);                                   // :522
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                double v[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) v[k] = wo[k] * (double)(b ? cv[k][ch].y : cv[k][ch].x);
+                double o = v[0] + v[1];                                    // :518
+                o = o + (v[2] + v[3]);                                     // :520
+                o = o + (v[4] + v[5]);                                     // :521
+                out[((int64_t)n * 3 + ch) * HW + po + b] = (OUT)(o / div); // :524
+            }
+        }
+    }
+}
+
+extern "C" int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(weight && weff);
+    hipLaunchKernelGGL(dec3_prepack_kernel, dim3(fldr_cdiv(D3_CIN * 4 * D3_COUT * 4, 256)), dim3(256), 0, fldr_s(stream), weight, weff);
+    FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+                               const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
+                               float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d2 && weff && bias && cand && cand_bstride && t && N > 0 && H > 0 && W > 0);
+    FLDR_CHECK_ARG((out_f64 != nullptr) != (out_f32 != nullptr));
+    if ((H | W) & 1) return FLDR_E_SHAPE;
+    FinalArgs a;
+    for (int k = 0; k < 6; ++k) {
+        FLDR_CHECK_ARG(cand[k] && (((uintptr_t)cand[k]) & 7) == 0 && (cand_bstride[k] & 1) == 0);
+        a.cand[k] = cand[k]; a.bstride[k] = cand_bstride[k];
+    }
+    dim3 grid(fldr_cdiv(W / 2, D3_TW), fldr_cdiv(H / 2, D3_TH), N);
+    if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W);
+    else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W);
+    FLDR_LAUNCH_RET();
+}

@@ -224,8 +224,14 @@ class DCTVFInet(nn.Module):
         im0_tot = self.bwarp(I0, flowback_0, withmask=mask)                                            # :478
         im1_tot = self.bwarp(I1, flowback_1, withmask=mask)                                            # :479
         srcs = [I0, I1, warped0, warped1, flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot]  # :480 (no cat)
-        refine_out = self.refine_unet(srcs)
-        out = fldr_hip.synth_tail(refine_out[:, 0:6], [warped0, warped1, im0_tot, im1_tot, I0, I1], t4, T)   # :511-524
+        cands = [warped0, warped1, im0_tot, im1_tot, I0, I1]
+        unet = self.refine_unet
+        if tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and H % 2 == 0 and W % 2 == 0:
+            # dec3 + softmax/T + blend in one kernel; refine_out (6 full-resolution planes) is never stored
+            out = fldr_hip.dec3_synth(unet.forward_until_dec2(srcs), unet.dec3.weight, unet.dec3.bias, cands, t4, T)
+        else:
+            refine_out = unet(srcs)
+            out = fldr_hip.synth_tail(refine_out[:, 0:6], cands, t4, T)                                # :511-524
         flow_out = None
         if a.testgetflowout:
             flow_out = torch.cat([t4 * flow_01_lo, (1 - t4) * flow_10_lo], 1)[:, 0:4]                  # :407,535
@@ -263,8 +269,8 @@ class PCARefineUNet(nn.Module):
         self.dec2 = _conv3(2 * nf + nf, nf)
         self.dec3 = _conv3(nf, self.output_maps)
 
-    def forward(self, concat, feat_dim=0):
-        """concat: the 26-channel tensor of fLDRnet.py:480 OR the list of its parts (never materialised)."""
+    def forward_until_dec2(self, concat):
+        """Everything up to and including dec2 + ReLU (fLDRnet.py:621-640), at half resolution."""
         srcs = list(concat) if isinstance(concat, (list, tuple)) else [concat]
         cv = fldr_hip.conv2d
         enc1 = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True)
@@ -272,5 +278,9 @@ class PCARefineUNet(nn.Module):
         out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True)
         out = cv([out], self.dec0.weight, self.dec0.bias, relu=True)
         out = cv([out, enc2], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False])     # NN + cat (:632-634)
-        out = cv([out, enc1], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])     # :638-640
-        return cv([out], self.dec3.weight, self.dec3.bias, up2=[True])                            # :642-643
+        return cv([out, enc1], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])    # :638-640
+
+    def forward(self, concat, feat_dim=0):
+        """concat: the 26-channel tensor of fLDRnet.py:480 OR the list of its parts (never materialised)."""
+        out = self.forward_until_dec2(concat)
+        return fldr_hip.conv2d([out], self.dec3.weight, self.dec3.bias, up2=[True])               # :642-643

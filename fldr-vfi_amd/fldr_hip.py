@@ -51,6 +51,9 @@ _SIGNATURES = {
     "fldr_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fldr_dec3_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
+    "fldr_dec3_synth": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                       _c_float_p, ctypes.c_double, _c_float_p, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -296,3 +299,36 @@ def synth_tail(refine, cands, t, T_param, out_dtype=torch.float64):
     _check(lib().fldr_synth_tail(_dev(refine, "refine"), ptrs, strides, _dev(t, "t"), float(T_param), o64, o32,
                                  N, H, W, _stream()), "fldr_synth_tail")
     return out
+
+
+def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, want_refine=False):
+    """Fused dec3 (on the nearest-x2 upsampled dec2 output) + softmax/T + blend (fLDRnet.py:642-643, 511-524)."""
+    N, cin, h, w = d2.shape
+    assert tuple(weight.shape) == (6, 16, 3, 3) and cin == 16 and len(cands) == 6
+    H, W = 2 * h, 2 * w
+    hit = getattr(weight, "_fldr_dec3", None)
+    if hit is None or hit[0] != (weight._version, weight.data_ptr()):
+        weff = torch.empty(1536, device=weight.device, dtype=torch.float32)
+        _check(lib().fldr_dec3_prepack(_dev(weight.detach().contiguous(), "weight"), _dev(weff, "weff"), _stream()), "fldr_dec3_prepack")
+        weight._fldr_dec3 = hit = ((weight._version, weight.data_ptr()), weff)
+    weff = hit[1]
+    d2 = d2.contiguous()
+    ptrs = (ctypes.c_void_p * 6)()
+    strides = (ctypes.c_int64 * 6)()
+    keep = []
+    for k, c in enumerate(cands):
+        assert c.shape == (N, 3, H, W)
+        if not c[0].is_contiguous():
+            c = c.contiguous()
+        keep.append(c)
+        ptrs[k] = _dev(c[0], "candidate").value
+        strides[k] = c.stride(0) if N > 1 else 0
+    t = t.reshape(N).contiguous().float()
+    out = torch.empty(N, 3, H, W, device=d2.device, dtype=out_dtype)
+    refine = torch.empty(N, 6, H, W, device=d2.device, dtype=torch.float32) if want_refine else None
+    o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
+    o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
+    _check(lib().fldr_dec3_synth(_dev(d2, "d2"), _dev(weff, "weff"), _dev(bias.detach(), "bias"), ptrs, strides, _dev(t, "t"),
+                                 float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None, N, H, W, _stream()),
+           "fldr_dec3_synth")
+    return (out, refine) if want_refine else out

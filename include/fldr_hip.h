@@ -152,6 +152,15 @@ int fldr_synth_tail(const float* refine, const float* const cand[6], const int64
                     const float* t, double T_param, double* out_f64, float* out_f32,
                     int N, int H, int W, fldr_stream_t stream);
 
+/* Fused PCARefineUNet.dec3 (3x3, 16 -> 6, on the nearest-x2 upsampled dec2 output, fLDRnet.py:642-643) + the tail above
+ * (fLDRnet.py:511-524): refine_out is never stored.  d2: dec2 output [N,16,H/2,W/2]; weff: dec3 weights repacked by
+ * fldr_dec3_prepack ([6,16,3,3] -> 1536 floats of per-phase 2x2 weights); bias [6]; cand/t/T/out as fldr_synth_tail.
+ * refine_out_or_null: optional [N,6,H,W] debug/verification output of the logits. H, W even; candidate rows 8-B aligned. */
+int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream);
+int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+                    const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
+                    float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -382,3 +382,25 @@ def test_pwcnet_forward_runs_on_the_correlation_kernel(hip, oracle, dev):
     assert [c[0][1] for c in calls] == [196, 128, 96, 64, 32]          # one cost volume per decoder level
     _, f, s = calls[0]
     _cmp(orig(f.to(dev), s.to(dev)), oracle.correlation(f, s), atol=1e-5, rtol=1e-5, what="in-network cost volume")
+
+
+def test_fused_dec3_synth_matches_unfused(hip, dev):
+    """dec3-on-nearest-x2 as four 2x2 phase convolutions + fp64 tail == 3x3 conv kernel + fldr_synth_tail."""
+    g = _gen(12)
+    N, h, w = 2, 20, 38
+    d2 = torch.rand(N, 16, h, w, generator=g)                              # post-ReLU activations
+    wt = torch.randn(6, 16, 3, 3, generator=g) / 6
+    bs = torch.randn(6, generator=g) * 0.3
+    cands = [torch.rand(N, 3, 2 * h, 2 * w, generator=g) * 2 - 1 for _ in range(6)]
+    t = torch.tensor([[0.25], [0.5]])
+    ref_logits = F.conv2d(F.interpolate(d2, scale_factor=2, mode="nearest"), wt, bs, padding=1)
+    out, logits = hip.dec3_synth(d2.to(dev), wt.to(dev), bs.to(dev), [c.to(dev) for c in cands], t.to(dev), 1.5616, want_refine=True)
+    _cmp(logits, ref_logits, atol=3e-6, rtol=1e-6, what="phase-decomposed dec3 logits")
+    unf = hip.synth_tail(hip.conv2d([d2.to(dev)], wt.to(dev), bs.to(dev), up2=[True]), [c.to(dev) for c in cands], t.to(dev), 1.5616)
+    _cmp(out, unf, atol=2e-6, what="fused vs unfused tail")
+    occ = F.softmax(ref_logits.double() / 1.5616, dim=1)
+    t4 = t.view(N, 1, 1, 1)
+    wk = [(1 - t4), t4] * 3
+    num = sum(wk[k] * occ[:, k:k + 1] * cands[k] for k in range(6))
+    den = sum(wk[k] * occ[:, k:k + 1] for k in range(6))
+    _cmp(out, num / den, atol=2e-6, what="fused tail vs torch")
