@@ -71,6 +71,24 @@ class DCTXVFInet(nn.Module):
             self.ev_params = [p for p in self.EVs + self.pca_means if p is not None]
         self.used_pcas = None
         self.params = None
+        # Pair-invariant cache: PCA features, all flow levels and the splat metrics do not depend on t
+        # (fLDRnet.py:396-405, 442-446), yet the reference recomputes them for each of the 7 t values of an 8x
+        # interpolation (main.py:833,867).  Opt-in: set `pair_cache = True`; a hit requires the SAME level-0 tensor
+        # object at the same version, or a bit-identical one (exact device compare), so results never change.
+        self.pair_cache = False
+        self._pair_state = None
+
+    def _pair_lookup(self, x0):
+        st = self._pair_state
+        if st is None:
+            return None
+        ref, ver = st["key"]
+        if ref is x0 and ver == x0._version:
+            return st
+        if ref.shape == x0.shape and ref.device == x0.device and torch.equal(ref, x0):
+            st["key"] = (x0, x0._version)
+            return st
+        return None
 
     # ---- reference API ------------------------------------------------------------------------
     def save_params(self, params):
@@ -106,20 +124,23 @@ class DCTXVFInet(nn.Module):
         i8 = a.scales.index(8)
         if self.params is None:
             raise RuntimeError("call save_params(...) first (main.py:347)")
-        feats = []
-        for i in range(n_levels):
-            B, _, _, h, w = x_l[i].shape
-            pca = to_pca_diff_f32(x_l[i].reshape(B * 6, h, w), self.params[i], a, self.pca_means[i8], self.EVs[i8],
-                                  self.mean_vecs[i8]).view(B, a.dctvfi_nf * 6, h // 8, w // 8)      # :146
-            feats.append(self.extract_features(pca) if a.ref_feat_extrac else pca)
         t4 = t_value.view(B2, 1, 1, 1)
-        flow = None
-        for level in range(a.S_tst, 0, -1):                                                            # :210-214
-            flow = self.vfinet(feats[level], flow, t4, level=level, is_training=False, normInput=x_l[level],
-                               validation=validation, orig_images=x_l[0])
-            feats[level] = None
-        out, refined = self.vfinet(feats[0], flow, t4, level=0, is_training=False, normInput=x_l[0],
-                                   validation=validation, orig_images=x_l[0])
+        state = self._pair_lookup(x_l[0]) if self.pair_cache else None
+        if state is None:
+            feats = []
+            for i in range(n_levels):
+                B, _, _, h, w = x_l[i].shape
+                pca = to_pca_diff_f32(x_l[i].reshape(B * 6, h, w), self.params[i], a, self.pca_means[i8], self.EVs[i8],
+                                      self.mean_vecs[i8]).view(B, a.dctvfi_nf * 6, h // 8, w // 8)  # :146
+                feats.append(self.extract_features(pca) if a.ref_feat_extrac else pca)
+            flow = None
+            for level in range(a.S_tst, -1, -1):                                                       # :210-218
+                flow = self.vfinet.estimate_flow(feats[level], flow)
+                feats[level] = None
+            state = {"key": (x_l[0], x_l[0]._version), "flow0": flow}
+            self._pair_state = state if self.pair_cache else None
+        out, refined = self.vfinet._synthesise(state["flow0"], x_l[0], t4, validation,
+                                               cache=state if self.pair_cache else None)
         return out[:, :, :self.output_size_test[0], :self.output_size_test[1]], refined                # :222
 
 
@@ -171,6 +192,13 @@ class DCTVFInet(nn.Module):
                 feat_pyr=[], mypwc=[], orig_images=None, frameT=None):
         if is_training:
             raise NotImplementedError("fldr-hip implements the inference (test) branch only")
+        flow_l = self.estimate_flow(feat_x, flow_l_prev)
+        if level != 0:
+            return flow_l                                                                              # :396-397
+        return self._synthesise(flow_l, normInput, t_value, validation)
+
+    def estimate_flow(self, feat_x, flow_l_prev):
+        """Flow estimation of one pyramid level (fLDRnet.py:368-391); t-independent."""
         a = self.args
         B, C, H, W = feat_x.shape
         half = a.img_ch * a.dctvfi_nf
@@ -185,12 +213,10 @@ class DCTVFInet(nn.Module):
             ca = fldr_hip.conv2d([feat0, w1], f1.weight, f1.bias)
             cb = fldr_hip.conv2d([feat1, w0], f1.weight, f1.bias)
             flow_l = self._chain([ca, cb, up], self.conv_flow2, (0, 2, 4, 6, 8), final_residual=up)    # :389-391
-        if level != 0:
-            return flow_l                                                                              # :396-397
-        return self._synthesise(flow_l, normInput, t_value, validation)
+        return flow_l
 
     # ---- level 0 (fLDRnet.py:400-535) ------------------------------------------------------------
-    def _synthesise(self, flow_l, x_l, t_value, validation):
+    def _synthesise(self, flow_l, x_l, t_value, validation, cache=None):
         a = self.args
         B = flow_l.shape[0]
         t4 = t_value.view(B, 1, 1, 1).float()
@@ -206,16 +232,23 @@ class DCTVFInet(nn.Module):
             assert (H, W) == tuple(self.output_size_val), "validation crop differs from the input size"
         flow_10_lo, flow_01_lo = flow_l[:, :2], flow_l[:, 2:]
         # t-scaling happens on the low-resolution flows, then x`up` bilinear upsampling times `up` (:404-422)
-        lo = torch.cat([t4 * flow_01_lo, (1 - t4) * flow_10_lo, flow_10_lo, flow_01_lo], 1)
-        big = fldr_hip.resize_bilinear(lo, H, W, mul=float(up))
-        flow_t0, flow_t1, flow_10, flow_01 = big[:, 0:2], big[:, 2:4], big[:, 4:6], big[:, 6:8]
-        I0 = x_l[:, :, 0].contiguous()
-        I1 = x_l[:, :, 1].contiguous()
-        if a.impmasksoftsplat:
-            z0 = fldr_hip.zmetric(I0, I1, flow_01, za0)                                                # :442-443
-            z1 = fldr_hip.zmetric(I1, I0, flow_10, za1)                                                # :445-446
-        else:
-            z0 = z1 = None
+        inv = cache.get("level0") if cache is not None else None
+        if inv is None:                                   # t-independent part (cached per pair when enabled)
+            both = fldr_hip.resize_bilinear(flow_l, H, W, mul=float(up))
+            flow_10, flow_01 = both[:, :2], both[:, 2:]
+            I0 = x_l[:, :, 0].contiguous()
+            I1 = x_l[:, :, 1].contiguous()
+            if a.impmasksoftsplat:
+                z0 = fldr_hip.zmetric(I0, I1, flow_01, za0)                                            # :442-443
+                z1 = fldr_hip.zmetric(I1, I0, flow_10, za1)                                            # :445-446
+            else:
+                z0 = z1 = None
+            inv = (flow_10, flow_01, I0, I1, z0, z1)
+            if cache is not None:
+                cache["level0"] = inv
+        flow_10, flow_01, I0, I1, z0, z1 = inv
+        tl = fldr_hip.resize_bilinear(torch.cat([t4 * flow_01_lo, (1 - t4) * flow_10_lo], 1), H, W, mul=float(up))
+        flow_t0, flow_t1 = tl[:, 0:2], tl[:, 2:4]
         warped0 = self.softsplat(I0, flow_t0, z=z0)                                                    # :449
         warped1 = self.softsplat(I1, flow_t1, z=z1)                                                    # :450
         mask = not a.outMaskLess

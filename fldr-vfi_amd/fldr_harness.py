@@ -110,6 +110,27 @@ def interpolate(model, args, frames, t_value, pyramid=None):
     return pred[:, :, :OH, :OW]
 
 
+def interpolate_multi(model, args, frames, t_values, pyramid=None):
+    """All outputs of one pair (e.g. t = 1/8 ... 7/8 for the 8x X-Test / Inter4K protocol, main.py:833-867) with the
+    pair-invariant stage (PCA features, six flow levels, splat metrics) computed once.  Returns a list of frames."""
+    B, C, T, OH, OW = frames.shape
+    prev = model.pair_cache
+    model.pair_cache = True
+    try:
+        with torch.no_grad():
+            if pyramid is None:
+                pyramid = build_pyramid(pad_frames(frames, args), args)
+            outs = []
+            for tv in t_values:
+                t = torch.full((B, 1), float(tv), device=frames.device, dtype=torch.float32)
+                pred, _ = model([None] * (args.S_tst + 1), t, normInput=pyramid, is_training=False, validation=False)
+                outs.append(pred[:, :, :OH, :OW])
+    finally:
+        model.pair_cache = prev
+        model._pair_state = None
+    return outs
+
+
 def to_uint8_image(pred):
     """[3,H,W] in [-1,1] -> rounded [H,W,3] in [0,255] (main.py:885-894, utils.py:685-688)."""
     p = np.asarray(pred.detach().cpu() if torch.is_tensor(pred) else pred, dtype=np.float64)

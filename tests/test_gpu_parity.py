@@ -404,3 +404,36 @@ def test_fused_dec3_synth_matches_unfused(hip, dev):
     num = sum(wk[k] * occ[:, k:k + 1] * cands[k] for k in range(6))
     den = sum(wk[k] * occ[:, k:k + 1] for k in range(6))
     _cmp(out, num / den, atol=2e-6, what="fused tail vs torch")
+
+
+def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
+    """8x protocol: 7 outputs per pair with PCA/flows/z computed once == 7 independent forwards == oracle."""
+    import fldr_harness as Hn
+    m, a = model
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(256, 384, seed=3, quadrant=True)).to(dev)
+    ts = [k / 8 for k in range(1, 8)]
+    cached = Hn.interpolate_multi(m, a, frames, ts)
+    assert m.pair_cache is False and m._pair_state is None
+    pyr = oracle.pad_and_pyramid(frames.cpu())
+    for tv, c in zip(ts, cached):
+        t = torch.tensor([[tv]])
+        plain = Hn.interpolate(m, a, frames, t.to(dev))
+        _cmp(c, plain, atol=2e-5, what="cached vs uncached t=%g" % tv)
+        if tv in (0.125, 0.5):
+            with torch.no_grad():
+                ref = oracle.forward(weights, pyr, t)[:, :, :256, :384]
+            _cmp(c, ref, atol=2e-3, max_outlier_frac=1e-4, what="cached vs oracle t=%g" % tv)
+    # a different pair must not hit the cache
+    m.pair_cache = True
+    try:
+        t = torch.tensor([[0.5]], device=dev)
+        o1 = Hn.interpolate(m, a, frames, t)
+        other = Hn.frames_from_uint8(Hn.synthetic_pair(256, 384, seed=4)).to(dev)
+        o2 = Hn.interpolate(m, a, other, t)
+        m.pair_cache = False
+        m._pair_state = None
+        _cmp(o2, Hn.interpolate(m, a, other, t), atol=2e-5, what="cache miss on a new pair")
+        assert (o1 - o2).abs().max().item() > 1e-2
+    finally:
+        m.pair_cache = False
+        m._pair_state = None
