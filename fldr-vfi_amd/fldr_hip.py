@@ -49,6 +49,9 @@ _SIGNATURES = {
     "fldr_conv_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_conv_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_conv2d": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_conv_split_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
+    "fldr_conv_split_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
+    "fldr_conv2d_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_dec3_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
@@ -225,7 +228,27 @@ def conv_prepack(weight):
     return wp
 
 
-def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=None, up2=None, out=None):
+# Arithmetic of the 3x3 stride-1 convolutions: "split" = 3 x fp16-split MFMA (fp32-equivalent accuracy, default),
+# "fp32" = exact fp32 MFMA.  Stride-2 4x4 convolutions always use the exact fp32 MFMA kernel.
+CONV_PRECISION = os.environ.get("FLDR_CONV_PRECISION", "split")
+
+
+def conv_split_prepack(weight):
+    hit = getattr(weight, "_fldr_pack_split", None)
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
+        return hit[1]
+    cout, cin, k, _ = weight.shape
+    n = lib().fldr_conv_split_prepack_size(cout, cin)
+    if n < 0:
+        raise FldrError("unsupported convolution shape %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    _check(lib().fldr_conv_split_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, _stream()), "fldr_conv_split_prepack")
+    weight._fldr_pack_split = ((weight._version, weight.data_ptr()), wp)
+    return wp
+
+
+def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=None, up2=None, out=None, precision=None):
     """conv(cat(srcs, 1)) with optional fused nearest-x2 read per source, ReLU and post-activation residual.
 
     srcs: list of [N,c_s,H_s,W_s] fp32 tensors whose (N, c, h, w) block may be a batch-strided view
@@ -263,7 +286,8 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     cs = cout if cout_store is None else cout_store
     if out is None:
         out = torch.empty(N, cs, Hout, Wout, device=srcs[0].device, dtype=torch.float32)
-    wp = conv_prepack(weight)
+    split = (precision or CONV_PRECISION) == "split" and k == 3 and stride == 1
+    wp = conv_split_prepack(weight) if split else conv_prepack(weight)
     d.wpack = wp.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     if residual is not None:
@@ -274,7 +298,10 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     d.N, d.cin, d.cout, d.cout_store = N, cin, cout, cs
     d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
     d.ksize, d.stride, d.relu, d.precision = k, stride, int(bool(relu)), 0
-    _check(lib().fldr_conv2d(ctypes.byref(d), _stream()), "fldr_conv2d")
+    if split:
+        _check(lib().fldr_conv2d_split(ctypes.byref(d), _stream()), "fldr_conv2d_split")
+    else:
+        _check(lib().fldr_conv2d(ctypes.byref(d), _stream()), "fldr_conv2d")
     return out
 
 

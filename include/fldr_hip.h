@@ -139,6 +139,14 @@ int64_t fldr_conv_prepack_size(int cout, int cin, int ksize);
 int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream);
 int fldr_conv2d(const fldr_conv_desc* desc, fldr_stream_t stream);
 
+/* The same convolution (3x3 / stride 1 only) on the fp16 matrix cores with fp32-equivalent accuracy: every operand is
+ * split into fp16 hi + lo halves and each product is formed by three fp16 MFMAs with fp32 accumulation ("3 x fp16
+ * split"; measured error vs fp64 <= that of the exact fp32 MFMA chain, see csrc/conv_split_kernels.hip).  Takes the
+ * same descriptor; desc->wpack must come from fldr_conv_split_prepack (it also holds the power-of-two weight scale). */
+int64_t fldr_conv_split_prepack_size(int cout, int cin);
+int fldr_conv_split_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.
  * ------------------------------------------------------------------------------------------ */

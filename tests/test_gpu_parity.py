@@ -437,3 +437,25 @@ def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
     finally:
         m.pair_cache = False
         m._pair_state = None
+
+
+@pytest.mark.parametrize("shape", [([96], 96), ([48, 48, 4], 96), ([48, 48], 48), ([64], 64), ([64, 32], 32), ([48], 4)])
+def test_split_fp16_conv_is_fp32_equivalent(hip, dev, shape):
+    """The 3 x fp16-split MFMA convolution against an fp64 reference: its error must be at the level of the exact
+    fp32 MFMA kernel's (both differ from fp64 only by fp32 accumulation rounding)."""
+    parts, cout = shape
+    g = _gen(13)
+    N, H, W = 1, 41, 77
+    srcs = [F.relu(torch.randn(N, c, H, W, generator=g)) * (0.02 if i % 2 else 1.0) for i, c in enumerate(parts)]
+    cin = sum(parts)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.03
+    bs = torch.randn(cout, generator=g) * 0.1
+    ref = F.conv2d(torch.cat(srcs, 1).double(), wt.double(), bs.double(), padding=1)
+    dsrc = [s.to(dev) for s in srcs]
+    e = {}
+    for prec in ("fp32", "split"):
+        got = hip.conv2d(dsrc, wt.to(dev), bs.to(dev), precision=prec).double().cpu()
+        e[prec] = ((got - ref).abs().mean().item(), (got - ref).abs().max().item())
+    print("cin %3d cout %2d: mean|err| fp32-MFMA %.2e  split %.2e ; max %.2e / %.2e (|ref| mean %.2e)"
+          % (cin, cout, e["fp32"][0], e["split"][0], e["fp32"][1], e["split"][1], ref.abs().mean().item()))
+    assert e["split"][0] <= 1.5 * e["fp32"][0] + 1e-8 and e["split"][1] <= 2.0 * e["fp32"][1] + 1e-7
