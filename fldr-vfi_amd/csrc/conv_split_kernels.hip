@@ -23,6 +23,20 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 
+#ifdef FLDR_STAMPS
+// Diagnostic build only (tools/stamps): per-phase s_memtime sums of one workgroup, written to a buffer no kernel reads.
+#ifndef FLDR_STAMP_BLOCK
+#define FLDR_STAMP_BLOCK 0
+#endif
+__device__ unsigned long long fldr_split_stamp_buf[8 * 8];
+#define SSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int fldr_debug_read_split_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_split_stamp_buf), sizeof(unsigned long long) * 64);
+}
+#else
+#define SSTAMP(var)
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* sgptr_t;
@@ -39,11 +53,10 @@ typedef __attribute__((address_space(3))) void* slptr_t;
 #define SP_HDR 4                                // floats before the packed weights: {1/scale, -, -, -}
 
 struct SplitArgs {
-    const float* src[FLDR_CONV_MAX_SRC];
-    int64_t src_bstride[FLDR_CONV_MAX_SRC];
-    int32_t src_cbegin[FLDR_CONV_MAX_SRC + 1];
-    int32_t src_up2[FLDR_CONV_MAX_SRC];
-    int32_t n_src;
+    // per input channel (after concatenation) of sample 0: plane pointer, bit 0 = "stored at half resolution, read
+    // through nearest x2"; 0 = padding channel.  Built on the host, read with scalar loads.
+    unsigned long long chan[SP_MAX_CIN];
+    int64_t chan_bstride[SP_MAX_CIN];
     const float* wpack;        // {header, halves...}
     const float* bias;
     const float* residual;
@@ -60,18 +73,20 @@ struct SplitCfg {
     static constexpr int W_BYTES = SP_STEPS * NMT * 2 * 1024;           // one chunk of one group, hi + lo
     static constexpr int PIECES = W_BYTES / 16;                         // 16-B LDS-DMA pieces (a multiple of 64)
     static constexpr int NWI = (PIECES + 511) / 512;                    // sweeps of the 512-thread workgroup
-    static constexpr int STAGE_BYTES = W_BYTES + SP_IN_BYTES;
-    static constexpr int TAB_BYTES = SP_MAX_CIN * 8;
-    static constexpr int LDS_BYTES = 2 * STAGE_BYTES + TAB_BYTES;
+    static constexpr int W_OFF = 0;                                     // 3-stage weight ring
+    static constexpr int X_OFF = 3 * W_BYTES;                           // 2 input stages
+    static constexpr int LDS_BYTES = X_OFF + 2 * SP_IN_BYTES;
     static_assert(PIECES % 64 == 0, "weight slab must be a whole number of wave-wide DMA pieces");
 };
 
+// x = hi + lo with hi = x truncated to 11 significant bits (exactly representable in fp16 for normal-range x, so its
+// conversion is exact) and lo = fp16(x - hi): 3 VALU ops per element instead of 5-6 for the round-to-nearest split.
 __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const _Float16 h = (_Float16)x[k];
-        hi[k] = h;
-        lo[k] = (_Float16)(x[k] - (float)h);
+        const float t = __uint_as_float(__float_as_uint(x[k]) & 0xFFFFE000u);
+        hi[k] = (_Float16)t;
+        lo[k] = (_Float16)(x[k] - t);
     }
 }
 
@@ -89,23 +104,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
     const int cin_pad = (a.cin + 15) / 16 * 16;
     const int n_chunks = cin_pad / 16;
 
-    // channel table (plane pointer | half-resolution flag), built once
-    unsigned long long* ctab = reinterpret_cast<unsigned long long*>(smem + 2 * Cfg::STAGE_BYTES);
-    if (tid < SP_MAX_CIN) {
-        unsigned long long e = 0;
-        if (tid < a.cin) {
-            int s = 0;
-            while (s + 1 < a.n_src && tid >= a.src_cbegin[s + 1]) ++s;
-            const int up2 = a.src_up2[s];
-            const int64_t plane = up2 ? (int64_t)(a.H >> 1) * (a.W >> 1) : (int64_t)a.H * a.W;
-            const float* base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(tid - a.src_cbegin[s]) * plane;
-            e = (unsigned long long)reinterpret_cast<uintptr_t>(base) | (unsigned long long)(up2 ? 1 : 0);
-        }
-        ctab[tid] = e;
-    }
-
     // staging geometry: waves 0-3 stage channels 0-7 of a chunk, waves 4-7 channels 8-15; 340 pixels over 256 threads
-    const int scg = wave >> 2;                         // wave-uniform 8-channel plane
+    const int scg = __builtin_amdgcn_readfirstlane(wave >> 2);      // wave-uniform 8-channel plane (in an SGPR)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);                    // the younger wave of each SIMD loses MFMA arbitration otherwise
     const int st = tid & 255;
     int g_full[2], g_half[2], l_off[2];
     bool s_ok[2];
@@ -134,8 +135,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
     float pre[2][8];
     const float* wsrc = a.wpack + SP_HDR + (int64_t)grp * n_chunks * (Cfg::W_BYTES / 4);
 
-    auto issue_weights = [&](int chunk, unsigned char* stage) {
+    auto issue_weights = [&](int chunk) {                       // -> weight ring stage chunk % 3
         const float* g = wsrc + (int64_t)chunk * (Cfg::W_BYTES / 4);
+        unsigned char* stage = smem + Cfg::W_OFF + (chunk % 3) * Cfg::W_BYTES;
 #pragma unroll
         for (int i = 0; i < Cfg::NWI; ++i) {
             const int piece = i * 512 + wave * 64;                                    // wave-uniform, x16 bytes
@@ -143,75 +145,125 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
                 __builtin_amdgcn_global_load_lds((sgptr_t)(g + (piece + lane) * 4), (slptr_t)(stage + piece * 16), 16, 0, 0);
         }
     };
+    const float* zero_word = a.wpack + 3;                          // header slot holding 0.0f
     auto load_inputs = [&](int chunk) {
+        // Every load is unconditional: padding pixels and padding channels read a zero word instead of being masked
+        // (a predicated load compiles to branch + load + s_waitcnt vmcnt(0)); bases are SGPRs, offsets precomputed.
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const unsigned long long e = ctab[chunk * 16 + scg * 8 + k];
-            const bool live = e != 0ull;
+            const int cg = chunk * 16 + scg * 8 + k;                 // wave-uniform
+            const unsigned long long e = a.chan[cg];
+            const bool ok = e != 0ull;
             const bool up2 = (e & 1ull) != 0ull;
-            const float* base = reinterpret_cast<const float*>(static_cast<uintptr_t>(e & ~1ull));
+            const float* base = ok ? reinterpret_cast<const float*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)n * a.chan_bstride[cg]
+                                   : zero_word;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float v = 0.0f;
-                if (live && s_ok[i]) v = base[up2 ? g_half[i] : g_full[i]];
-                pre[i][k] = v;
+                const float* p = s_ok[i] ? base + (ok ? (up2 ? g_half[i] : g_full[i]) : 0) : zero_word;
+                pre[i][k] = *p;
             }
         }
     };
-    auto store_inputs = [&](unsigned char* stage) {
+    auto store_inputs = [&](int chunk) {                        // -> input stage chunk & 1
+        unsigned char* stage = smem + Cfg::X_OFF + (chunk & 1) * SP_IN_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (l_off[i] < 0) continue;
             h8 hi, lo;
             split8(pre[i], hi, lo);
-            *reinterpret_cast<h8*>(stage + Cfg::W_BYTES + l_off[i]) = hi;
-            *reinterpret_cast<h8*>(stage + Cfg::W_BYTES + 2 * SP_CG_STRIDE + l_off[i]) = lo;
+            *reinterpret_cast<h8*>(stage + l_off[i]) = hi;
+            *reinterpret_cast<h8*>(stage + 2 * SP_CG_STRIDE + l_off[i]) = lo;
         }
     };
 
-    __syncthreads();                                   // channel table visible
-    issue_weights(0, smem);
+    // Pipeline (per chunk k): MFMA steps on {weights ring k%3, input stage k&1}; before the last step: write the
+    // registers prefetched for chunk k+1 to input stage (k+1)&1, THEN issue the LDS-DMA of chunk k+2's weights and
+    // the register prefetch of chunk k+2's inputs.  The only vmcnt wait is the one in front of that LDS write (all
+    // older loads were issued a full chunk earlier); the chunk barrier is a raw s_barrier behind lgkmcnt(0), so the
+    // freshly issued DMA and loads stay in flight across it.
+    issue_weights(0);
     load_inputs(0);
-    store_inputs(smem);
-    __syncthreads();
+    store_inputs(0);
+    if (n_chunks > 1) { issue_weights(1); load_inputs(1); }
+    __syncthreads();                                   // (drains everything once; fine in the prologue)
 
+#ifdef FLDR_STAMPS
+    unsigned long long st_mfma = 0, st_stage = 0, st_last = 0, st_bar = 0;
+    SSTAMP(tb0)
+#endif
     for (int ch = 0; ch < n_chunks; ++ch) {
-        unsigned char* cur = smem + (ch & 1) * Cfg::STAGE_BYTES;
-        unsigned char* nxt = smem + ((ch + 1) & 1) * Cfg::STAGE_BYTES;
-        const bool more = ch + 1 < n_chunks;
-        const unsigned char* win = cur + lane * 16;
-        const unsigned char* xin = cur + Cfg::W_BYTES;
-#pragma unroll
-        for (int s = 0; s < SP_STEPS; ++s) {
-            if (s == 0 && more) issue_weights(ch + 1, nxt);
-            if (s == 1 && more) load_inputs(ch + 1);
-            if (s == SP_STEPS - 1 && more) store_inputs(nxt);
-            // taps of this step: tA = 2s, tB = 2s+1 (tB = 9 is the zero-weight pad tap: read tap 8's pixels again)
+        SSTAMP(t0)
+        const unsigned char* win = smem + Cfg::W_OFF + (ch % 3) * Cfg::W_BYTES + lane * 16;
+        const unsigned char* xin = smem + Cfg::X_OFF + (ch & 1) * SP_IN_BYTES;
+        h8 bh[2][2], bl[2][2], ah[2][NMT], al[2][NMT];
+        auto ld = [&](int buf, int s) {
+            // taps of step s: tA = 2s, tB = 2s+1 (tB = 9 is the zero-weight pad tap: re-read tap 8's pixels, finite)
             const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
             const int offA = ((tA / 3) * SP_IW + tA % 3) * 16, offB = ((tB / 3) * SP_IW + tB % 3) * 16;
             const int toff = tap_sel ? offB : offA;
-            h8 bh[2], bl[2], ah[NMT], al[NMT];
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                bh[p] = *reinterpret_cast<const h8*>(xin + boff[p] + toff);
-                bl[p] = *reinterpret_cast<const h8*>(xin + 2 * SP_CG_STRIDE + boff[p] + toff);
+                bh[buf][p] = *reinterpret_cast<const h8*>(xin + boff[p] + toff);
+                bl[buf][p] = *reinterpret_cast<const h8*>(xin + 2 * SP_CG_STRIDE + boff[p] + toff);
             }
 #pragma unroll
             for (int m = 0; m < NMT; ++m) {
-                ah[m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
-                al[m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+                ah[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+                al[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
             }
+        };
+        ld(0, 0);
 #pragma unroll
-            for (int m = 0; m < NMT; ++m)
+        for (int s = 0; s < SP_STEPS; ++s) {
+            if (s == SP_STEPS - 1) {
+                SSTAMP(t1)
+                if (ch + 1 < n_chunks) store_inputs(ch + 1);
+                if (ch + 2 < n_chunks) { issue_weights(ch + 2); load_inputs(ch + 2); }
+                SSTAMP(t2)
+#ifdef FLDR_STAMPS
+                st_mfma += t1 - t0; st_stage += t2 - t1; tb0 = t2;
+#endif
+            }
+            // term-major order: the 2*NMT accumulators are independent within a term, so no MFMA waits for its predecessor
 #pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh[p], acc[m][p], 0, 0, 0);
-                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl[p], acc[m][p], 0, 0, 0);
-                    acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh[p], acc[m][p], 0, 0, 0);
-                }
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const h8 av = term == 2 ? al[s & 1][m] : ah[s & 1][m];
+                        const h8 bv = term == 1 ? bl[s & 1][p] : bh[s & 1][p];
+#if !defined(SPLIT_ABLATE) || SPLIT_ABLATE != 2
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][p], 0, 0, 0);
+#else
+                        asm volatile("" :: "v"(av), "v"(bv));
+#endif
+                    }
+            // the operands of step s+1 are requested AFTER the MFMAs of step s have been issued: they return while the
+            // matrix pipe works, and the lgkmcnt wait in front of step s+1 covers reads that are a whole step old
+#if !defined(SPLIT_ABLATE) || SPLIT_ABLATE != 1
+            if (s + 1 < SP_STEPS) ld((s + 1) & 1, s + 1);
+#else
+            if (s + 1 < SP_STEPS) { for (int p = 0; p < 2; ++p) { bh[(s + 1) & 1][p] = bh[s & 1][p]; bl[(s + 1) & 1][p] = bl[s & 1][p]; }
+                                    for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; al[(s + 1) & 1][m] = al[s & 1][m]; } }
+#endif
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NMT, 0);
         }
-        __syncthreads();
+        SSTAMP(t3)
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): my LDS writes are done (vmcnt left alone)
+        __builtin_amdgcn_s_barrier();
+        SSTAMP(t4)
+#ifdef FLDR_STAMPS
+        st_last += t3 - tb0; st_bar += t4 - t3;
+#endif
     }
+#ifdef FLDR_STAMPS
+    if (blockIdx.x == FLDR_STAMP_BLOCK && blockIdx.y == 0 && lane == 0) {
+        unsigned long long* o = fldr_split_stamp_buf + wave * 8;
+        o[0] = st_mfma; o[1] = st_stage; o[2] = st_last; o[3] = st_bar; o[4] = n_chunks;
+    }
+#endif
 
     // ---- epilogue: undo the weight scale, bias, ReLU, residual, coalesced 64-B row segments ----
     const float inv_scale = a.wpack[0];
@@ -374,21 +426,19 @@ extern "C" int fldr_conv2d_split(const fldr_conv_desc* d, fldr_stream_t stream) 
     if (d->Hout != d->Hin || d->Wout != d->Win) return FLDR_E_SHAPE;
     SplitArgs a;
     int csum = 0;
-    for (int s = 0; s < FLDR_CONV_MAX_SRC; ++s) {
-        const bool live = s < d->n_src;
-        if (live) {
-            FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0);
-            if (d->src_up2[s] && ((d->Hin | d->Win) & 1)) return FLDR_E_SHAPE;
+    for (int s = 0; s < d->n_src; ++s) {
+        FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0);
+        if (d->src_up2[s] && ((d->Hin | d->Win) & 1)) return FLDR_E_SHAPE;
+        if (csum + d->src_c[s] > SP_MAX_CIN) return FLDR_E_ARG;
+        const int64_t plane = d->src_up2[s] ? (int64_t)(d->Hin >> 1) * (d->Win >> 1) : (int64_t)d->Hin * d->Win;
+        for (int c = 0; c < d->src_c[s]; ++c) {
+            a.chan[csum + c] = (unsigned long long)reinterpret_cast<uintptr_t>(d->src[s] + (int64_t)c * plane) | (d->src_up2[s] ? 1ull : 0ull);
+            a.chan_bstride[csum + c] = d->src_bstride[s];
         }
-        a.src[s] = live ? d->src[s] : nullptr;
-        a.src_bstride[s] = live ? d->src_bstride[s] : 0;
-        a.src_up2[s] = live ? d->src_up2[s] : 0;
-        a.src_cbegin[s] = csum;
-        if (live) csum += d->src_c[s];
+        csum += d->src_c[s];
     }
-    a.src_cbegin[FLDR_CONV_MAX_SRC] = csum;
     if (csum != d->cin) return FLDR_E_SHAPE;
-    a.n_src = d->n_src;
+    for (int c = csum; c < SP_MAX_CIN; ++c) { a.chan[c] = 0ull; a.chan_bstride[c] = 0; }
     a.wpack = d->wpack; a.bias = d->bias; a.residual = d->residual; a.out = d->out;
     a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
     a.H = d->Hin; a.W = d->Win; a.relu = d->relu; a.tiles_x = 0;
