@@ -24,6 +24,7 @@ import torch.distributed as dist  # noqa: E402
 
 H4K, W4K = 2160, 3840
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 matrix peak
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -31,36 +32,47 @@ from fldr_harness import shard_pairs, host_cores, max_over_ranks  # noqa: E402
 
 
 def dominant_conv_roofline(model, pyr, steps):
-    """Roofline of the dominant kernel: the 96->96 3x3 fp32-MFMA convolution at the level-0 feature map
-    (rec_ctx_ds.0 / .2, conv_flow2.2 all launch this instance).  Algorithmic FLOPs per launch =
-    2 * cin * cout * 9 * pixels; duration measured with HIP events on the launch stream."""
+    """Roofline of the dominant kernel: the 96->96 3x3 convolution at the level-0 feature map (rec_ctx_ds.0/.2,
+    conv_flow2.0/.2 launch this instance; 32 % of the GPU time).  It runs on the fp16 matrix cores with the 3 x fp16
+    split (fp32-equivalent accuracy), i.e. it issues THREE fp16 MFMA flops per algorithmic flop.
+    algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels; achieved = 3 x that / launch time, against the dense
+    fp16 MFMA peak.  Duration measured with HIP events on the launch stream.  The exact fp32-MFMA kernel of the same
+    layer (FLDR_CONV_PRECISION=fp32) is timed beside it."""
     import fldr_hip
     h, w = pyr[0].shape[3] // 8, pyr[0].shape[4] // 8
     x = torch.rand(1, 96, h, w, device=pyr[0].device) * 2 - 1
     conv = model.rec_ctx_ds[0]
-    for _ in range(3):
-        fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True)
-    n = max(10, steps)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     out = torch.empty(1, 96, h, w, device=x.device)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(n):
-        fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    n = max(10, steps)
+
+    def timed(prec):
+        for _ in range(3):
+            fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision=prec)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(n):
+            fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision=prec)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    ms, ms32 = timed("split"), timed("fp32")
     flops = 2.0 * 96 * 96 * 9 * h * w
-    ach = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_mfma_kernel<3,1,16,3,2,8> (3x3 96->96 @%dx%d as 2 groups of 48 output channels, fp32 MFMA 16x16x4)" % (h, w),
-            "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
-            "traffic": _measured_traffic(), "launch_ms": round(ms, 4), "flops_per_launch": flops}
+    ach = 3.0 * flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv3x3_split_kernel<3> (3x3 96->96 @%dx%d, 2 groups of 48 output channels, "
+                                       "3 x fp16-split v_mfma_f32_16x16x32_f16)" % (h, w),
+            "achieved": round(ach, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4),
+            "traffic": _measured_traffic(), "launch_ms": round(ms, 4), "flops_per_launch": flops,
+            "issued_mfma_flops_per_launch": 3.0 * flops, "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+            "exact_fp32_mfma_kernel": {"launch_ms": round(ms32, 4), "achieved": round(flops / (ms32 * 1e-3) / 1e12, 1),
+                                       "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
 
 
 def _measured_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None when no measurement is on file."""
-    p = os.path.join(ROOT, "profiles", "r01_conv96_traffic.json")
+    p = os.path.join(ROOT, "profiles", "r01_conv96_split_traffic.json")
     try:
         return json.load(open(p))["hbm_bytes_per_launch"]
     except Exception:
@@ -159,7 +171,7 @@ def main():
         res = {
             "metric": "4K frame-pairs interpolated/sec", "value": round(world * a.steps / dt, 3), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3x3 convs: 3 x fp16-split MFMA with fp32 accumulation, error <= exact fp32 MFMA; rest fp32/fp64)", "data": "synthetic",
             "config": {"workload": "single %dx%d frame pair per GPU (padded 2304x3840), fLDRnet 5-scale test path "
                                    "(--papermodel --test5scales), t=0.5, shipped checkpoint weights, fp64 output frame"
                                    % (a.width, a.height),
