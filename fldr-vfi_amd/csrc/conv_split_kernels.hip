@@ -66,6 +66,7 @@ struct SplitArgs {
     int32_t relu;
     int32_t tiles_x;
     int32_t groups;
+    int32_t n_tiles, tiles_per_xcd;
 };
 
 template <int NMT>
@@ -97,7 +98,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = blockIdx.y;
-    const int grp = blockIdx.x % a.groups, tile = blockIdx.x / a.groups;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so XCD x gets the
+    // contiguous tile range [x*tpx, (x+1)*tpx) and all output-channel groups of a tile back to back: the groups
+    // re-read the same input tile and vertically adjacent tiles share halo rows through that XCD's L2.
+    const int xcd = blockIdx.x & 7, kx = blockIdx.x >> 3;
+    const int grp = kx % a.groups;
+    const int tile = xcd * a.tiles_per_xcd + kx / a.groups;
+    if (tile >= a.n_tiles) return;                                    // workgroup-uniform
     const int cbase = grp * MTOT;
     const int oy0 = (tile / a.tiles_x) * SP_TH, ox0 = (tile % a.tiles_x) * SP_TW;
     const int lj = lane & 15, lg = lane >> 4;
@@ -414,7 +421,9 @@ static int split_launch(const SplitArgs& a, int N, hipStream_t s) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_split_kernel<NMT>), dim3(b.tiles_x * tiles_y * b.groups, N), dim3(512), Cfg::LDS_BYTES, s, b);
+    b.n_tiles = b.tiles_x * tiles_y;
+    b.tiles_per_xcd = (b.n_tiles + 7) / 8;
+    hipLaunchKernelGGL((conv3x3_split_kernel<NMT>), dim3(8 * b.tiles_per_xcd * b.groups, N), dim3(512), Cfg::LDS_BYTES, s, b);
     FLDR_LAUNCH_RET();
 }
 
