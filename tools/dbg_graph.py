@@ -8,7 +8,7 @@ t = torch.tensor([[0.5]], device=dev)
 with torch.no_grad():
     pyr = Hn.build_pyramid(Hn.pad_frames(frames, args), args)
     ref = Hn.interpolate(model, args, frames, t, pyramid=pyr).clone()
-    for ns in (1, 2, 3, 4):
+    for ns in (3, 4, 5):
         streams = [torch.cuda.Stream() for _ in range(ns)]
         graphs, outs = [], []
         for s in streams:
