@@ -91,7 +91,9 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
     }
 }
 
-template <int NMT>
+// TERMS = 3: hi*hi + hi*lo + lo*hi (fp32-equivalent); TERMS = 1: hi*hi only = plain fp16 inputs, fp32 accumulate
+// (BASELINE config 5, "fp16 path with MFMA convs"; 11-bit operands, error ~1e-3 relative).
+template <int NMT, int TERMS>
 __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
     using Cfg = SplitCfg<NMT>;
     constexpr int MTOT = 16 * NMT;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
             }
             // term-major order: the 2*NMT accumulators are independent within a term, so no MFMA waits for its predecessor
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < TERMS; ++term)
 #pragma unroll
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -254,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
             if (s + 1 < SP_STEPS) { for (int p = 0; p < 2; ++p) { bh[(s + 1) & 1][p] = bh[s & 1][p]; bl[(s + 1) & 1][p] = bl[s & 1][p]; }
                                     for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; al[(s + 1) & 1][m] = al[s & 1][m]; } }
 #endif
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * NMT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TERMS * NMT, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 4 + 2 * NMT, 0);
         }
         SSTAMP(t3)
@@ -408,7 +410,7 @@ extern "C" int fldr_conv_split_prepack(const float* weight, float* wpack, int co
     FLDR_LAUNCH_RET();
 }
 
-template <int NMT>
+template <int NMT, int TERMS>
 static int split_launch(const SplitArgs& a, int N, hipStream_t s) {
     using Cfg = SplitCfg<NMT>;
     SplitArgs b = a;
@@ -416,14 +418,14 @@ static int split_launch(const SplitArgs& a, int N, hipStream_t s) {
     const int tiles_y = fldr_cdiv(a.H, SP_TH);
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<NMT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<NMT, TERMS>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
     b.n_tiles = b.tiles_x * tiles_y;
     b.tiles_per_xcd = (b.n_tiles + 7) / 8;
-    hipLaunchKernelGGL((conv3x3_split_kernel<NMT>), dim3(8 * b.tiles_per_xcd * b.groups, N), dim3(512), Cfg::LDS_BYTES, s, b);
+    hipLaunchKernelGGL((conv3x3_split_kernel<NMT, TERMS>), dim3(8 * b.tiles_per_xcd * b.groups, N), dim3(512), Cfg::LDS_BYTES, s, b);
     FLDR_LAUNCH_RET();
 }
 
@@ -455,7 +457,12 @@ extern "C" int fldr_conv2d_split(const fldr_conv_desc* d, fldr_stream_t stream) 
     split_geometry(d->cout, nmt, groups);
     a.groups = groups;
     hipStream_t s = fldr_s(stream);
-    if (nmt == 1) return split_launch<1>(a, d->N, s);
-    if (nmt == 2) return split_launch<2>(a, d->N, s);
-    return split_launch<3>(a, d->N, s);
+    if (d->precision == 1) {                           // plain fp16 inputs
+        if (nmt == 1) return split_launch<1, 1>(a, d->N, s);
+        if (nmt == 2) return split_launch<2, 1>(a, d->N, s);
+        return split_launch<3, 1>(a, d->N, s);
+    }
+    if (nmt == 1) return split_launch<1, 3>(a, d->N, s);
+    if (nmt == 2) return split_launch<2, 3>(a, d->N, s);
+    return split_launch<3, 3>(a, d->N, s);
 }

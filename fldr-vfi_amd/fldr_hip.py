@@ -229,7 +229,8 @@ def conv_prepack(weight):
 
 
 # Arithmetic of the 3x3 stride-1 convolutions: "split" = 3 x fp16-split MFMA (fp32-equivalent accuracy, default),
-# "fp32" = exact fp32 MFMA.  Stride-2 4x4 convolutions always use the exact fp32 MFMA kernel.
+# "fp32" = exact fp32 MFMA, "fp16" = fp16 inputs with fp32 accumulation (BASELINE config 5; NOT fp32-equivalent).
+# Stride-2 4x4 convolutions always use the exact fp32 MFMA kernel.
 CONV_PRECISION = os.environ.get("FLDR_CONV_PRECISION", "split")
 
 
@@ -286,7 +287,10 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     cs = cout if cout_store is None else cout_store
     if out is None:
         out = torch.empty(N, cs, Hout, Wout, device=srcs[0].device, dtype=torch.float32)
-    split = (precision or CONV_PRECISION) == "split" and k == 3 and stride == 1
+    prec = precision or CONV_PRECISION
+    if prec not in ("split", "fp32", "fp16"):
+        raise ValueError("precision must be split, fp32 or fp16")
+    split = prec in ("split", "fp16") and k == 3 and stride == 1
     wp = conv_split_prepack(weight) if split else conv_prepack(weight)
     d.wpack = wp.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -297,7 +301,7 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     d.out = _dev(out, "out").value
     d.N, d.cin, d.cout, d.cout_store = N, cin, cout, cs
     d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
-    d.ksize, d.stride, d.relu, d.precision = k, stride, int(bool(relu)), 0
+    d.ksize, d.stride, d.relu, d.precision = k, stride, int(bool(relu)), (1 if (split and prec == "fp16") else 0)
     if split:
         _check(lib().fldr_conv2d_split(ctypes.byref(d), _stream()), "fldr_conv2d_split")
     else:

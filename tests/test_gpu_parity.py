@@ -459,3 +459,28 @@ def test_split_fp16_conv_is_fp32_equivalent(hip, dev, shape):
     print("cin %3d cout %2d: mean|err| fp32-MFMA %.2e  split %.2e ; max %.2e / %.2e (|ref| mean %.2e)"
           % (cin, cout, e["fp32"][0], e["split"][0], e["fp32"][1], e["split"][1], ref.abs().mean().item()))
     assert e["split"][0] <= 1.5 * e["fp32"][0] + 1e-8 and e["split"][1] <= 2.0 * e["fp32"][1] + 1e-7
+
+
+def test_fp16_conv_path_config5(hip, oracle, weights, dev, model):
+    """BASELINE config 5: 3x3 convs with plain fp16 inputs (fp32 accumulate).  Not fp32-equivalent: report the error
+    and the PSNR between its rounded 8-bit frame and the oracle's (the fp32-class paths are at ~100 dB)."""
+    import fldr_harness as Hn
+    m, a = model
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(512, 768, seed=5, quadrant=True)).to(dev)
+    t = torch.tensor([[0.5]])
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames.cpu()), t)
+    res = {}
+    prev = hip.CONV_PRECISION
+    try:
+        for prec in ("fp32", "split", "fp16"):
+            hip.CONV_PRECISION = prec
+            out = Hn.interpolate(m, a, frames, t.to(dev)).cpu()
+            err = (out - ref).abs()
+            res[prec] = (err.max().item(), err.mean().item(), Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0])))
+    finally:
+        hip.CONV_PRECISION = prev
+    for k, v in res.items():
+        print("conv precision %-5s: max|err| %.2e mean %.2e  PSNR(8-bit vs oracle) %.1f dB" % ((k,) + v))
+    assert res["split"][1] <= 2.0 * res["fp32"][1] + 1e-8            # the split path is fp32-class
+    assert res["fp16"][2] > 45.0                                      # fp16 inputs: visually lossless, but not fp32-class
