@@ -1,0 +1,107 @@
+// Callers either side of the hot path, moved onto the GPU:
+//   * ingest: uint8 frames -> [-1,1] fp32, reflect padding to a multiple of 2^S*8 and the direct (non-cascaded)
+//     bicubic pyramid that main.py:840-856 / run_on_your_images.py:124-145 build on the CPU before uploading
+//     283 MB of fp32 (here: 50 MB of uint8 go up, everything else is produced on the device);
+//   * metrics: crop, de-normalise, round-half-even to the 8-bit grid and the squared error against the uint8
+//     ground truth (main.py:885-911, utils.py:644-652, 685-688) instead of a 212 MB fp64 download.
+#include "common.h"
+
+// frames_u8 [B,T=2,3,H,W] (I0 then I1) -> out [B,3,2,Hp,Wp]: v = u8/255*2-1 (run_on_your_images.py:84),
+// right/bottom reflect padding as F.pad(mode='reflect') on the [B,C*T,H,W] view (main.py:848)
+__global__ __launch_bounds__(256) void ingest_kernel(const uint8_t* __restrict__ u8, float* __restrict__ out,
+                                                     int H, int W, int Hp, int Wp) {
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int bct = blockIdx.z;                 // ((b*3 + c)*2 + t) in the output
+    if (x >= Wp) return;
+    const int t = bct & 1, c = (bct >> 1) % 3, b = bct / 6;
+    const int sx = x < W ? x : 2 * (W - 1) - x;
+    const int sy = y < H ? y : 2 * (H - 1) - y;
+    const uint8_t v = u8[(((int64_t)(b * 2 + t) * 3 + c) * H + sy) * W + sx];
+    float f = (float)v / 255.0f;
+    f = f * 2.0f;
+    out[((int64_t)bct * Hp + y) * Wp + x] = f - 1.0f;
+}
+
+// Level i of the pyramid from level 0: F.interpolate(scale_factor=2^-i, mode='bicubic', align_corners=False) (main.py:855).
+// For integer down-factors s the source position (dst+0.5)*s-0.5 always has fraction 0.5, so the four cubic
+// convolution weights (A = -0.75) are the constants (-3/32, 19/32, 19/32, -3/32); taps are index-clamped.
+__global__ __launch_bounds__(256) void pyramid_bicubic_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int Hs, int Ws, int s) {
+#pragma clang fp contract(off)
+    const int Hd = Hs / s, Wd = Ws / s;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int plane = blockIdx.z;
+    if (x >= Wd) return;
+    const float c0 = -0.09375f, c1 = 0.59375f;
+    const int fx = x * s + s / 2 - 1, fy = y * s + s / 2 - 1;       // floor of the source position
+    const float* p = src + (int64_t)plane * Hs * Ws;
+    float r[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int iy = min(max(fy - 1 + j, 0), Hs - 1);
+        const float* row = p + (int64_t)iy * Ws;
+        const float v0 = row[min(max(fx - 1, 0), Ws - 1)], v1 = row[min(max(fx, 0), Ws - 1)];
+        const float v2 = row[min(max(fx + 1, 0), Ws - 1)], v3 = row[min(max(fx + 2, 0), Ws - 1)];
+        r[j] = ((v0 * c0 + v1 * c1) + v2 * c1) + v3 * c0;
+    }
+    dst[((int64_t)plane * Hd + y) * Wd + x] = ((r[0] * c0 + r[1] * c1) + r[2] * c1) + r[3] * c0;
+}
+
+extern "C" int fldr_ingest_u8(const uint8_t* frames_u8, float* level0, int B, int H, int W, int Hp, int Wp,
+                              fldr_stream_t stream) {
+    FLDR_CHECK_ARG(frames_u8 && level0 && B > 0 && H > 1 && W > 1 && Hp >= H && Wp >= W);
+    if (Hp - H >= H || Wp - W >= W) return FLDR_E_SHAPE;            // reflect padding needs pad < size
+    dim3 grid(fldr_cdiv(Wp, 256), Hp, B * 6);
+    hipLaunchKernelGGL(ingest_kernel, grid, dim3(256), 0, fldr_s(stream), frames_u8, level0, H, W, Hp, Wp);
+    FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_pyramid_bicubic(const float* level0, float* level_i, int planes, int Hp, int Wp, int factor,
+                                    fldr_stream_t stream) {
+    FLDR_CHECK_ARG(level0 && level_i && planes > 0 && Hp > 0 && Wp > 0 && factor >= 2);
+    if (Hp % factor || Wp % factor || (factor & (factor - 1))) return FLDR_E_SHAPE;
+    dim3 grid(fldr_cdiv(Wp / factor, 256), Hp / factor, planes);
+    hipLaunchKernelGGL(pyramid_bicubic_kernel, grid, dim3(256), 0, fldr_s(stream), level0, level_i, Hp, Wp, factor);
+    FLDR_LAUNCH_RET();
+}
+
+// pred [B,3,Hp,Wp] (fp64 or fp32, [-1,1]) cropped to H x W -> rounded 8-bit value (np.around: half to even),
+// optional uint8 image out_u8 [B,3,H,W]; sse[b] += sum (target - rounded)^2 against target_u8 [B,3,H,W] when given.
+template <typename T>
+__global__ __launch_bounds__(256) void metrics_kernel(const T* __restrict__ pred, const uint8_t* __restrict__ target,
+                                                      uint8_t* __restrict__ out_u8, double* __restrict__ sse,
+                                                      int H, int W, int Hp, int Wp) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int bc = blockIdx.z;
+    double e = 0.0;
+    if (x < W) {
+        double v = ((double)pred[((int64_t)bc * Hp + y) * Wp + x] + 1.0) / 2.0;        // utils.py:685-688
+        v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        const double q = rint(v * 255.0);                                             // np.around (main.py:894)
+        const int64_t o = ((int64_t)bc * H + y) * W + x;
+        if (out_u8) out_u8[o] = (uint8_t)q;
+        if (target) { const double d = (double)target[o] - q; e = d * d; }
+    }
+    if (target) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) e += __shfl_xor(e, off);
+        __shared__ double part[4];
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = e;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(sse + bc / 3, (part[0] + part[1]) + (part[2] + part[3]));
+    }
+}
+
+extern "C" int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8_t* target_u8_or_null, uint8_t* out_u8_or_null,
+                                  double* sse_zeroed_or_null, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(pred && B > 0 && H > 0 && W > 0 && Hp >= H && Wp >= W);
+    FLDR_CHECK_ARG((target_u8_or_null == nullptr) == (sse_zeroed_or_null == nullptr));
+    dim3 grid(fldr_cdiv(W, 256), H, B * 3);
+    if (pred_is_f64) hipLaunchKernelGGL(metrics_kernel<double>, grid, dim3(256), 0, fldr_s(stream), (const double*)pred, target_u8_or_null, out_u8_or_null, sse_zeroed_or_null, H, W, Hp, Wp);
+    else             hipLaunchKernelGGL(metrics_kernel<float>, grid, dim3(256), 0, fldr_s(stream), (const float*)pred, target_u8_or_null, out_u8_or_null, sse_zeroed_or_null, H, W, Hp, Wp);
+    FLDR_LAUNCH_RET();
+}

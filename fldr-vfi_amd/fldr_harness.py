@@ -131,6 +131,22 @@ def interpolate_multi(model, args, frames, t_values, pyramid=None):
     return outs
 
 
+def interpolate_u8(model, args, frames_u8, t_value, target_u8=None):
+    """End-to-end on the device: uint8 frames [B,2,3,H,W] (I0, I1) -> normalise + reflect pad + bicubic pyramid
+    (fldr_ingest_u8 / fldr_pyramid_bicubic) -> forward -> rounded uint8 frame [B,3,H,W] (and, with a uint8 ground
+    truth, the per-sample PSNR list) via fldr_frame_metrics.  Only uint8 crosses PCIe in either direction."""
+    import fldr_hip
+    B, T, C, H, W = frames_u8.shape
+    with torch.no_grad():
+        pyr = fldr_hip.ingest_pyramid(frames_u8, args.S_tst + 1)
+        pred, _ = model([None] * (args.S_tst + 1), t_value, normInput=pyr, is_training=False, validation=False)
+        sse, img = fldr_hip.frame_metrics(pred, min(H, pred.shape[2]), min(W, pred.shape[3]), target_u8, want_u8=True)
+    if sse is None:
+        return img, None
+    mse = (sse / (3.0 * H * W)).cpu()
+    return img, [float("inf") if m == 0 else 10 * math.log10(255.0 ** 2 / m) for m in mse.tolist()]
+
+
 def to_uint8_image(pred):
     """[3,H,W] in [-1,1] -> rounded [H,W,3] in [0,255] (main.py:885-894, utils.py:685-688)."""
     p = np.asarray(pred.detach().cpu() if torch.is_tensor(pred) else pred, dtype=np.float64)

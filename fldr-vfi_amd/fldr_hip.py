@@ -57,6 +57,10 @@ _SIGNATURES = {
     "fldr_dec3_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
     "fldr_dec3_synth": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_frame_metrics": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+                           + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
@@ -363,3 +367,41 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
                                  float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None, N, H, W, _stream()),
            "fldr_dec3_synth")
     return (out, refine) if want_refine else out
+
+
+def ingest_pyramid(frames_u8, n_levels=6):
+    """uint8 frames [B,2,3,H,W] on the device -> the model's normInput list (level i: [B,3,2,Hp/2^i,Wp/2^i] fp32):
+    normalisation, reflect padding and the direct bicubic pyramid of main.py:840-856, all on the GPU."""
+    B, T, C, H, W = frames_u8.shape
+    assert T == 2 and C == 3
+    div = (2 ** (n_levels - 1)) * 8
+    Hp, Wp = (H + div - 1) // div * div, (W + div - 1) // div * div
+    u8 = frames_u8.contiguous()
+    lv0 = torch.empty(B, 3, 2, Hp, Wp, device=u8.device, dtype=torch.float32)
+    code = lib().fldr_ingest_u8(_dev(u8, "frames", torch.uint8), _dev(lv0, "level0"), B, H, W, Hp, Wp, _stream())
+    _check(code, "fldr_ingest_u8")
+    pyr = [lv0]
+    for i in range(1, n_levels):
+        f = 2 ** i
+        lv = torch.empty(B, 3, 2, Hp // f, Wp // f, device=u8.device, dtype=torch.float32)
+        _check(lib().fldr_pyramid_bicubic(_dev(lv0, "level0"), _dev(lv, "level"), B * 6, Hp, Wp, f, _stream()), "fldr_pyramid_bicubic")
+        pyr.append(lv)
+    return pyr
+
+
+def frame_metrics(pred, H, W, target_u8=None, want_u8=False):
+    """pred [B,3,Hp,Wp] (fp64/fp32) -> (sse [B] fp64 device tensor or None, uint8 image [B,3,H,W] or None)."""
+    B, C, Hp, Wp = pred.shape
+    assert C == 3 and pred.dtype in (torch.float64, torch.float32)
+    pred = pred.contiguous()
+    sse = torch.zeros(B, device=pred.device, dtype=torch.float64) if target_u8 is not None else None
+    img = torch.empty(B, 3, H, W, device=pred.device, dtype=torch.uint8) if want_u8 else None
+    if target_u8 is not None:
+        target_u8 = target_u8.contiguous()
+        assert target_u8.shape == (B, 3, H, W)
+    _check(lib().fldr_frame_metrics(_dev(pred, "pred", pred.dtype), int(pred.dtype == torch.float64),
+                                    _dev(target_u8, "target", torch.uint8) if target_u8 is not None else None,
+                                    _dev(img, "image", torch.uint8) if want_u8 else None,
+                                    _dev(sse, "sse", torch.float64) if sse is not None else None,
+                                    B, H, W, Hp, Wp, _stream()), "fldr_frame_metrics")
+    return sse, img

@@ -169,6 +169,24 @@ int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const
                     const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
                     float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Callers either side of the path, on the device (the reference does these on the CPU).
+ * ------------------------------------------------------------------------------------------ */
+
+/* frames_u8 [B,2,3,H,W] (I0, I1) -> level0 [B,3,2,Hp,Wp] fp32: x/255*2-1 (run_on_your_images.py:84) with right/bottom
+ * reflect padding (main.py:840-849).  Hp, Wp: padded size (multiples of 2^S_tst*8), pad < size. */
+int fldr_ingest_u8(const uint8_t* frames_u8, float* level0, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream);
+
+/* One pyramid level: F.interpolate(level0 planes, scale_factor=1/factor, mode='bicubic', align_corners=False)
+ * (main.py:855-856), factor a power of two >= 2.  level0 [planes,Hp,Wp] -> level_i [planes,Hp/factor,Wp/factor]. */
+int fldr_pyramid_bicubic(const float* level0, float* level_i, int planes, int Hp, int Wp, int factor, fldr_stream_t stream);
+
+/* main.py:885-911 on the device: crop pred [B,3,Hp,Wp] (fp64 if pred_is_f64 else fp32) to H x W, (x+1)/2 clipped to
+ * [0,1] * 255, rounded half-to-even; optionally written as uint8 [B,3,H,W]; when target_u8 [B,3,H,W] is given,
+ * sse[b] (zeroed by the caller) accumulates the squared error, so PSNR = 10 log10(255^2 * 3HW / sse[b]). */
+int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8_t* target_u8_or_null, uint8_t* out_u8_or_null,
+                       double* sse_zeroed_or_null, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -484,3 +484,35 @@ def test_fp16_conv_path_config5(hip, oracle, weights, dev, model):
         print("conv precision %-5s: max|err| %.2e mean %.2e  PSNR(8-bit vs oracle) %.1f dB" % ((k,) + v))
     assert res["split"][1] <= 2.0 * res["fp32"][1] + 1e-8            # the split path is fp32-class
     assert res["fp16"][2] > 45.0                                      # fp16 inputs: visually lossless, but not fp32-class
+
+
+@pytest.mark.parametrize("size", [(200, 500), (256, 256), (130, 300)])
+def test_gpu_ingest_matches_cpu_caller(hip, oracle, dev, size):
+    """uint8 -> normalise -> reflect pad -> bicubic pyramid on the device == the reference's CPU pre-processing."""
+    import fldr_harness as Hn
+    H, W = size
+    u8 = Hn.synthetic_pair(H, W, seed=6, quadrant=True)                 # [2,3,H,W]
+    ref = oracle.pad_and_pyramid(oracle.frames_from_uint8(u8))
+    got = hip.ingest_pyramid(u8.unsqueeze(0).to(dev))
+    assert len(got) == 6
+    assert torch.equal(got[0].cpu(), ref[0])                            # normalisation + reflect padding: bit exact
+    for i in range(1, 6):
+        _cmp(got[i], ref[i], atol=2e-6, what="bicubic level %d" % i)
+
+
+def test_gpu_metrics_and_u8_roundtrip(hip, oracle, weights, dev, model):
+    import fldr_harness as Hn
+    m, a = model
+    H, W = 200, 330
+    u8 = Hn.synthetic_pair(H, W, seed=8)
+    t = torch.tensor([[0.5]])
+    gt = Hn.synthetic_pair(H, W, seed=9)[0:1]                           # any uint8 "ground truth" [1,3,H,W]
+    img, ps = Hn.interpolate_u8(m, a, u8.unsqueeze(0).to(dev), t.to(dev), target_u8=gt.to(dev))
+    assert img.dtype == torch.uint8 and img.shape == (1, 3, H, W) and len(ps) == 1
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(oracle.frames_from_uint8(u8)), t)[:, :, :H, :W]
+    ref_img = oracle.to_uint8_image(ref, H, W)                          # [H,W,3] float
+    diff = (img[0].permute(1, 2, 0).cpu().double().numpy() - ref_img)
+    assert (np.abs(diff) > 0).mean() < 1e-3 and np.abs(diff).max() <= 1  # rounding ties aside, identical 8-bit frames
+    want = oracle.psnr(gt[0].permute(1, 2, 0).double().numpy(), img[0].permute(1, 2, 0).cpu().double().numpy())
+    assert abs(ps[0] - want) < 1e-9
