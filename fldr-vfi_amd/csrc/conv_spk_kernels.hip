@@ -1,0 +1,569 @@
+// 3x3 / stride 1 / pad 1 convolutions on SPLIT-PACKED activations: persistent, LDS-DMA fed, 3 x fp16-split MFMA.
+//
+// Arithmetic: exactly that of conv_split_kernels.hip (x = hi + lo in fp16, hi*hi + hi*lo + lo*hi on
+// v_mfma_f32_16x16x32_f16 with fp32 accumulation, same tap/channel order), so results are bit-identical to that
+// kernel.  What changes is where the hi/lo split happens and how operands travel:
+//
+//   * Activations between convolutions live in HBM in the "split-packed" (SPK) layout
+//         [N][G = ceil(C/8)][kind: hi, lo][H*W][8 halves]            (16 B per pixel, group and kind)
+//     which costs the same 4 B per element as fp32 but is already the MFMA B-operand image: the PRODUCER's epilogue
+//     splits each value once (fldr_spk_pack does it for fp32 NCHW tensors that come from other kernels), and the
+//     consumer's staging is pure LDS-DMA (global_load_lds_dwordx4, one pixel x 8 channels per lane) — no VGPRs, no
+//     VALU, no per-chunk vmcnt(0).  Measured on the previous kernel (tools/stamps, 96->96 @288x480): of 27.5 us per
+//     workgroup, 7.2 us were exposed register staging + split arithmetic, ~10 us prologue/epilogue/launch latency
+//     and 7.2 us the MFMA loop itself.
+//   * Workgroups are PERSISTENT (one per CU; 156 KB of LDS): each walks a list of (sample, tile, output-channel
+//     group) units and the (unit, chunk) iterations form ONE software pipeline — the DMA of iteration g+2 is issued
+//     at the top of iteration g whatever unit it belongs to, so the fetch latency of a unit's first chunk and the
+//     store tail of the previous unit hide under MFMAs instead of being paid per workgroup.
+//   * Per iteration (16 input channels): 3-stage LDS ring of {weights in A-operand order (hi, lo), input tile
+//     10 x 34 px as 4 planes [hi g0, hi g1, lo g0, lo g1] of 16-B elements}; the only wait is a counted
+//     s_waitcnt vmcnt(K) (K = the DMA instructions this wave issued for iteration g+2) in front of one raw s_barrier.
+//
+// Zero padding: out-of-image pixels and padding channel groups read a 16-B block of zeros in the weight header.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* kgptr_t;
+typedef __attribute__((address_space(3))) void* klptr_t;
+
+#define SPK_MAX_GROUPS 14                       // 112 input channels
+#define SPK_TH 8
+#define SPK_TW 32
+#define SPK_IH (SPK_TH + 2)
+#define SPK_IW (SPK_TW + 2)
+#define SPK_PLANE 5632                          // bytes per LDS plane: 340 px * 16 B rounded up to a multiple of 256
+#define SPK_IN_BYTES (4 * SPK_PLANE)
+#define SPK_STEPS 5                             // tap pairs per 16-channel chunk (9 taps + 1 zero tap)
+#define SPK_HDR 8                               // floats before the packed weights: {1/scale, scale, max|w|, 0, 0,0,0,0}
+
+struct SpkArgs {
+    unsigned long long grp_ptr[SPK_MAX_GROUPS];   // hi plane of input group g, sample 0; bit 0 = stored at half resolution (nearest x2 read); 0 = padding group
+    int64_t grp_bstride[SPK_MAX_GROUPS];          // bytes between samples
+    const float* wpack;
+    const float* bias;
+    const float* residual;
+    float* out_f32;                               // [N, cout_store, H, W] or null
+    unsigned char* out_spk;                       // SPK tensor of cout_store channels or null
+    int64_t out_spk_bstride;                      // bytes between samples
+    int32_t n_chunks, cout, cout_store;
+    int32_t H, W;
+    int32_t relu;
+    int32_t tiles_x, n_tiles, groups;
+    int32_t n_units, units_per_xcd, wgs_per_xcd;
+};
+
+template <int NMT>
+struct SpkCfg {
+    static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;          // one chunk of one output group, hi + lo
+    static constexpr int PIECES = W_BYTES / 16;
+    static constexpr int NWI = (PIECES + 511) / 512;
+    static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
+    static constexpr int LDS_BYTES = 3 * STAGE;
+    static constexpr int K_MIN = 3 + PIECES / 512;                      // DMA instructions EVERY wave issues per iteration
+    static_assert(PIECES % 64 == 0, "weight slab must be a whole number of wave-wide DMA pieces");
+};
+
+__device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo) {
+    const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);     // 11 significant bits: exact in fp16
+    hi = (_Float16)t;
+    lo = (_Float16)(x - t);
+}
+
+// Scheduling pattern of one MFMA step: N_DS groups of {a share of the N_MFMA matrix instructions, one LDS read}.
+template <int N_MFMA, int N_DS, int I>
+struct SpkInterleave {
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, (N_MFMA * (I + 1)) / N_DS - (N_MFMA * I) / N_DS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        SpkInterleave<N_MFMA, N_DS, I + 1>::run();
+    }
+};
+template <int N_MFMA, int N_DS>
+struct SpkInterleave<N_MFMA, N_DS, N_DS> {
+    static __device__ __forceinline__ void run() {}
+};
+
+template <int NMT, int TERMS, bool HAS_RES>
+__global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
+    using Cfg = SpkCfg<NMT>;
+    constexpr int MTOT = 16 * NMT;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 15, lg = lane >> 4;
+    const int n_chunks = a.n_chunks;
+
+    // Units of this workgroup.  Workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2): XCD x owns
+    // the contiguous unit range [x*upx, (x+1)*upx) (unit = (sample, tile, group), group fastest), so the output
+    // groups of a tile and vertically adjacent tiles meet in one L2.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int u_end = min((xcd + 1) * a.units_per_xcd, a.n_units);
+    const int u_first = xcd * a.units_per_xcd + slot;
+    if (u_first >= u_end) return;                                        // workgroup-uniform
+    const int my_units = (u_end - u_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_units * n_chunks;
+
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+
+    // ---- issue side: which pieces of the input image this wave's three DMA instructions fill ----
+    const int ip = wave >> 1;                                            // LDS plane: kind = ip >> 1, group of the chunk = ip & 1
+    const int ikind = ip >> 1, igrp = ip & 1;
+    const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
+    int iss_u = u_first, iss_c = 0;
+    int g_full[3], g_half[3];
+    bool g_ok[3], g_act[3];
+    int iss_n = 0;
+    const float* iss_w = nullptr;
+    auto issue_geometry = [&]() {
+        const int grp = iss_u % a.groups, t = iss_u / a.groups;
+        const int tile = t % a.n_tiles;
+        iss_n = t / a.n_tiles;
+        const int oy0 = (tile / a.tiles_x) * SPK_TH, ox0 = (tile % a.tiles_x) * SPK_TW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int e = ((wave & 1) * 3 + i) * 64 + lane;
+            const int y = e / SPK_IW, x = e % SPK_IW;
+            const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
+            g_act[i] = e < SPK_PLANE / 16;
+            g_ok[i] = e < SPK_IH * SPK_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            g_full[i] = g_ok[i] ? (gy * a.W + gx) * 16 : 0;
+            g_half[i] = g_ok[i] ? ((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16 : 0;
+        }
+        iss_w = a.wpack + SPK_HDR + (int64_t)grp * n_chunks * (Cfg::W_BYTES / 4);
+    };
+    auto issue = [&](int stage_idx) {                                    // DMA of (iss_u, iss_c) -> ring stage
+        // Past the workgroup's last iteration the same instructions are issued against the zero block (into a ring
+        // stage nobody reads any more), so that the counted vmcnt wait below holds in every iteration.
+        const bool live = iss_u < u_end;                                 // workgroup-uniform
+        unsigned char* stage = smem + stage_idx * Cfg::STAGE;
+        const float* g = iss_w + (int64_t)iss_c * (Cfg::W_BYTES / 4);
+#pragma unroll
+        for (int i = 0; i < Cfg::NWI; ++i) {
+            const int piece = i * 512 + wave * 64;
+            if (piece < Cfg::PIECES) {
+                const float* src = live ? g + (piece + lane) * 4 : reinterpret_cast<const float*>(zero_blk);
+                __builtin_amdgcn_global_load_lds((kgptr_t)src, (klptr_t)(stage + piece * 16), 16, 0, 0);
+            }
+        }
+        const int gi = live ? iss_c * 2 + igrp : 0;
+        const unsigned long long e = live ? a.grp_ptr[gi] : 0ull;
+        const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
+        const int64_t plane = up2 ? (int64_t)(a.H >> 1) * (a.W >> 1) * 16 : (int64_t)a.H * a.W * 16;
+        const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * a.grp_bstride[gi]
+                           + (ikind ? plane : 0);
+        unsigned char* dst = stage + Cfg::W_BYTES + ip * SPK_PLANE + (wave & 1) * 3 * 1024;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const char* p = (g_ok[i] && !nul) ? base + (up2 ? g_half[i] : g_full[i]) : zero_blk;
+            if (g_act[i])
+                __builtin_amdgcn_global_load_lds((kgptr_t)p, (klptr_t)(dst + i * 1024), 16, 0, 0);
+        }
+        if (live && ++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
+    };
+
+    // ---- compute side ----
+    int boff[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) boff[p] = Cfg::W_BYTES + (lg & 1) * SPK_PLANE + (wave * SPK_IW + p * 16 + lj) * 16;
+    const int tap_sel = lg >> 1;
+    f4 acc[NMT][2];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) acc[m][p] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int cur_u = u_first, cur_c = 0;
+    const float inv_scale = a.wpack[0];
+    const int64_t HW = (int64_t)a.H * a.W;
+    const int gout = (a.cout_store + 7) >> 3;
+    // The output-channel group is the same for every unit of a workgroup (the host keeps wgs_per_xcd a multiple of
+    // `groups`), so the bias is fetched once.
+    const int cbase = (u_first % a.groups) * MTOT;
+    float bias_r[NMT][4];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int co = cbase + m * 16 + lg * 4 + r;
+            co = co < a.cout ? co : a.cout - 1;
+            bias_r[m][r] = a.bias ? a.bias[co] : 0.0f;
+        }
+
+    // Epilogue in three parts so that no memory latency sits between the last MFMA of a unit and the barrier:
+    //   residual_prefetch  at the top of the unit's last iteration, BEFORE that iteration's DMA is issued (loads retire
+    //                      in order, so waiting for it never drains the DMA);
+    //   finish             after the last MFMA: scale, bias, ReLU, residual, hi/lo split — registers only;
+    //   store              after the barrier, at the top of the next iteration (the stores are then older than the
+    //                      next DMA and have a whole iteration to retire before the next counted wait).
+    float res_r[NMT][2][4];
+    float ov[NMT][2][4];
+    int64_t st_po[2];
+    bool st_ok[2];
+    int st_n = 0;
+    auto unit_pixels = [&](int u, int64_t (&po)[2], bool (&ok)[2], int& n) {
+        const int t = u / a.groups;
+        const int tile = t % a.n_tiles;
+        n = t / a.n_tiles;
+        const int oy = (tile / a.tiles_x) * SPK_TH + wave;
+        const int ox0 = (tile % a.tiles_x) * SPK_TW;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int ox = ox0 + p * 16 + lj;
+            ok[p] = oy < a.H && ox < a.W;
+            po[p] = ok[p] ? (int64_t)oy * a.W + ox : 0;
+        }
+    };
+    auto residual_prefetch = [&]() {
+        int64_t po[2]; bool ok[2]; int n;
+        unit_pixels(cur_u, po, ok, n);
+        const float* resn = a.residual + (int64_t)n * a.cout_store * HW;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int co = cbase + m * 16 + lg * 4 + r;
+                    co = co < a.cout_store ? co : a.cout_store - 1;
+                    res_r[m][p][r] = resn[(int64_t)co * HW + po[p]];
+                }
+    };
+    auto finish = [&]() {
+        unit_pixels(cur_u, st_po, st_ok, st_n);
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = acc[m][p][r] * inv_scale + bias_r[m][r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    if constexpr (HAS_RES) v += res_r[m][p][r];
+                    ov[m][p][r] = v;
+                    acc[m][p][r] = 0.0f;
+                }
+    };
+    auto store = [&]() {
+        float* outn = a.out_f32 ? a.out_f32 + (int64_t)st_n * a.cout_store * HW : nullptr;
+        unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)st_n * a.out_spk_bstride : nullptr;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const int co0 = cbase + m * 16 + lg * 4;
+                if (outn) {
+                    if (!(a.cout_store & 3)) {                       // whole quads of channels: one predicate per 4 stores
+                        if (co0 < a.cout_store && st_ok[p]) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) outn[(int64_t)(co0 + r) * HW + st_po[p]] = ov[m][p][r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + r < a.cout_store && st_ok[p]) outn[(int64_t)(co0 + r) * HW + st_po[p]] = ov[m][p][r];
+                    }
+                }
+                if (spkn) {
+                    const int go = co0 >> 3;
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = co0 + r < a.cout_store ? ov[m][p][r] : 0.0f;
+                        _Float16 h, l;
+                        spk_split(x, h, l);
+                        hi[r] = h; lo[r] = l;
+                    }
+                    if (go < gout && st_ok[p]) {
+                        unsigned char* q = spkn + ((int64_t)go * 2 * HW + st_po[p]) * 16 + (lg & 1) * 8;
+                        *reinterpret_cast<h4*>(q) = hi;
+                        *reinterpret_cast<h4*>(q + HW * 16) = lo;
+                    }
+                }
+            }
+    };
+
+    // ---- pipeline ----
+    issue_geometry();
+    issue(0);
+    issue(1);                                          // (a dummy zero-block fill when the workgroup has one iteration)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): both prologue stages have landed
+    __builtin_amdgcn_s_barrier();
+
+    int st_cur = 0, st_iss = 2;
+    bool store_pending = false;
+    for (int g = 0; g < total; ++g) {
+        if (store_pending) { store(); store_pending = false; }
+        const bool last = cur_c == n_chunks - 1;       // workgroup-uniform
+        if constexpr (HAS_RES) { if (last) residual_prefetch(); }
+        issue(st_iss);                                 // iteration g+2 (dummy zero-block fills past the end): every
+                                                       // iteration issues the same number of DMA instructions
+        const unsigned char* sb = smem + st_cur * Cfg::STAGE;
+        const unsigned char* win = sb + lane * 16;
+        h8 bh[2][2], bl[2][2], ah[2][NMT], al[2][NMT];
+        auto ld = [&](int buf, int s) {
+            // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values).
+            // Issue order = consumption order of the term-major MFMA sequence (hi x hi, hi x lo, lo x hi), so the
+            // counted lgkmcnt waits let the first MFMAs of a step start before its last operands have arrived.
+            const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
+            const int offA = ((tA / 3) * SPK_IW + tA % 3) * 16, offB = ((tB / 3) * SPK_IW + tB % 3) * 16;
+            const int toff = tap_sel ? offB : offA;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) bh[buf][p] = *reinterpret_cast<const h8*>(sb + boff[p] + toff);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) ah[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+            if constexpr (TERMS > 1) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p) bl[buf][p] = *reinterpret_cast<const h8*>(sb + 2 * SPK_PLANE + boff[p] + toff);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) al[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            }
+        };
+        constexpr int N_MFMA = 2 * TERMS * NMT, N_DS = TERMS > 1 ? 4 + 2 * NMT : 2 + NMT;
+        constexpr int N_TAIL = N_MFMA >= 12 ? 4 : (N_MFMA >= 6 ? 2 : 0);
+        ld(0, 0);
+        __builtin_amdgcn_sched_barrier(0);                           // keep step 0's reads out of the interleave pattern below
+#pragma unroll
+        for (int s = 0; s < SPK_STEPS; ++s) {
+            if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);           // lands while this step's MFMAs run
+#pragma unroll
+            for (int term = 0; term < TERMS; ++term)
+#pragma unroll
+                for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const h8 av = term == 2 ? al[s & 1][m] : ah[s & 1][m];
+                        const h8 bv = term == 1 ? bl[s & 1][p] : bh[s & 1][p];
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][p], 0, 0, 0);
+                    }
+            // spread the next step's LDS reads evenly between this step's MFMAs
+            if (s + 1 < SPK_STEPS) {
+                // ... over all but the last N_TAIL MFMAs, which cover the latency of the last read (the wait in front
+                // of the next step is an lgkmcnt(0))
+                SpkInterleave<N_MFMA - N_TAIL, N_DS, 0>::run();
+                __builtin_amdgcn_sched_group_barrier(0x008, N_TAIL, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
+            }
+        }
+        if (last) {
+            finish();
+            store_pending = true;
+            cur_c = 0; cur_u += a.wgs_per_xcd;
+        } else {
+            ++cur_c;
+        }
+        // Iteration g+1's DMA (issued one iteration ago) must have landed; this iteration's may stay in flight.  Loads
+        // retire in order, so "at most K_MIN of my vector-memory operations outstanding" implies it.
+        __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_MIN);
+        __builtin_amdgcn_s_barrier();
+        st_cur = st_cur == 2 ? 0 : st_cur + 1;
+        st_iss = st_iss == 2 ? 0 : st_iss + 1;
+    }
+    if (store_pending) store();
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 NCHW <-> SPK
+// ------------------------------------------------------------------------------------------------
+__global__ void spk_pack_kernel(const float* __restrict__ src, int64_t src_bstride, unsigned char* __restrict__ dst,
+                                int64_t dst_bstride, int C, int64_t HW) {
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, n = blockIdx.z;
+    if (pix >= HW) return;
+    const float* s = src + (int64_t)n * src_bstride + (int64_t)g * 8 * HW + pix;
+    float x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) x[k] = g * 8 + k < C ? s[(int64_t)k * HW] : 0.0f;
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { _Float16 h, l; spk_split(x[k], h, l); hi[k] = h; lo[k] = l; }
+    unsigned char* d = dst + (int64_t)n * dst_bstride + ((int64_t)g * 2 * HW + pix) * 16;
+    *reinterpret_cast<h8*>(d) = hi;
+    *reinterpret_cast<h8*>(d + HW * 16) = lo;
+}
+
+__global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t src_bstride, float* __restrict__ dst,
+                                  int C, int64_t HW) {
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, n = blockIdx.z;
+    if (pix >= HW) return;
+    const unsigned char* s = src + (int64_t)n * src_bstride + ((int64_t)g * 2 * HW + pix) * 16;
+    const h8 hi = *reinterpret_cast<const h8*>(s), lo = *reinterpret_cast<const h8*>(s + HW * 16);
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+        if (g * 8 + k < C) dst[((int64_t)n * C + g * 8 + k) * HW + pix] = (float)hi[k] + (float)lo[k];
+}
+
+extern "C" int64_t fldr_spk_bytes(int C, int H, int W) {
+    if (C <= 0 || H <= 0 || W <= 0) return FLDR_E_ARG;
+    return (int64_t)((C + 7) / 8) * 2 * H * W * 16;
+}
+
+extern "C" int fldr_spk_pack(const float* src, int64_t src_bstride, void* dst, int N, int C, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0);
+    const int64_t HW = (int64_t)H * W;
+    hipLaunchKernelGGL(spk_pack_kernel, dim3(fldr_cdiv(HW, 256), (C + 7) / 8, N), dim3(256), 0, fldr_s(stream), src, src_bstride,
+                       reinterpret_cast<unsigned char*>(dst), fldr_spk_bytes(C, H, W), C, HW);
+    FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(src && dst && N > 0 && C > 0 && H > 0 && W > 0);
+    const int64_t HW = (int64_t)H * W;
+    hipLaunchKernelGGL(spk_unpack_kernel, dim3(fldr_cdiv(HW, 256), (C + 7) / 8, N), dim3(256), 0, fldr_s(stream),
+                       reinterpret_cast<const unsigned char*>(src), fldr_spk_bytes(C, H, W), dst, C, HW);
+    FLDR_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights: same body layout as conv_split_kernels.hip ([group][chunk][step][m][kind][lane][8 halves]) behind an
+// 8-float header whose second half is the zero block
+// ------------------------------------------------------------------------------------------------
+static inline void spk_geometry(int cout, int& nmt, int& groups) {
+    if (cout <= 16)      { nmt = 1; groups = 1; }
+    else if (cout <= 32) { nmt = 2; groups = 1; }
+    else if (cout <= 48) { nmt = 3; groups = 1; }
+    else if (cout <= 64) { nmt = 2; groups = 2; }
+    else                 { nmt = 3; groups = (cout + 47) / 48; }
+}
+
+__global__ void spk_absmax_kernel(const float* __restrict__ w, int64_t n, float* __restrict__ hdr) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x < SPK_HDR) {
+        const float mx = red[0];
+        float scale = 1.0f;                                  // largest power of two with mx * scale <= 8192
+        if (mx > 0.0f) scale = exp2f(floorf(log2f(8192.0f / mx)));
+        const float v[SPK_HDR] = {1.0f / scale, scale, mx, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        hdr[threadIdx.x] = v[threadIdx.x];
+    }
+}
+
+__global__ void spk_prepack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int nmt,
+                                   int n_chunks, int64_t total_h8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_h8) return;
+    const float scale = wp[1];
+    const int lane = (int)(i % 64);
+    const int kind = (int)((i / 64) % 2);
+    const int m = (int)((i / 128) % nmt);
+    const int s = (int)((i / (128 * nmt)) % SPK_STEPS);
+    const int ch = (int)((i / (128 * nmt * SPK_STEPS)) % n_chunks);
+    const int gr = (int)(i / ((int64_t)128 * nmt * SPK_STEPS * n_chunks));
+    const int li = lane & 15, lg = lane >> 4;
+    const int co = gr * 16 * nmt + m * 16 + li;
+    const int tap = 2 * s + (lg >> 1);
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = ch * 16 + (lg & 1) * 8 + j;
+        float x = (tap < 9 && co < cout && c < cin) ? w[((int64_t)co * cin + c) * 9 + tap] * scale : 0.0f;
+        const _Float16 h = (_Float16)x;
+        v[j] = kind == 0 ? h : (_Float16)(x - (float)h);
+    }
+    reinterpret_cast<h8*>(wp + SPK_HDR)[i] = v;
+}
+
+extern "C" int64_t fldr_conv_spk_prepack_size(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cout > 96 || cin > SPK_MAX_GROUPS * 8) return FLDR_E_ARG;
+    int nmt, groups;
+    spk_geometry(cout, nmt, groups);
+    const int n_chunks = (cin + 15) / 16;
+    return SPK_HDR + (int64_t)groups * n_chunks * SPK_STEPS * nmt * 2 * 64 * 4;
+}
+
+extern "C" int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(weight && wpack);
+    const int64_t total = fldr_conv_spk_prepack_size(cout, cin);
+    if (total < 0) return (int)total;
+    int nmt, groups;
+    spk_geometry(cout, nmt, groups);
+    const int n_chunks = (cin + 15) / 16;
+    const int64_t total_h8 = (total - SPK_HDR) / 4;
+    hipLaunchKernelGGL(spk_absmax_kernel, dim3(1), dim3(256), 0, fldr_s(stream), weight, (int64_t)cout * cin * 9, wpack);
+    hipLaunchKernelGGL(spk_prepack_kernel, dim3(fldr_cdiv(total_h8, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin,
+                       nmt, n_chunks, total_h8);
+    FLDR_LAUNCH_RET();
+}
+
+// Persistent workgroups per XCD (32 = one per CU); fldr_debug_spk_wgs_per_xcd changes it for occupancy experiments.
+static int g_spk_wgs_per_xcd = 32;
+extern "C" int fldr_debug_spk_wgs_per_xcd(int v) { if (v > 0) g_spk_wgs_per_xcd = v; return g_spk_wgs_per_xcd; }
+
+template <int NMT, int TERMS, bool HAS_RES>
+static int spk_launch2(SpkArgs& a, int N, hipStream_t s) {
+    using Cfg = SpkCfg<NMT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_spk_kernel<NMT, TERMS, HAS_RES>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    a.tiles_x = fldr_cdiv(a.W, SPK_TW);
+    a.n_tiles = a.tiles_x * fldr_cdiv(a.H, SPK_TH);
+    a.n_units = N * a.n_tiles * a.groups;
+    a.units_per_xcd = (a.n_units + 7) / 8;
+    a.units_per_xcd = (a.units_per_xcd + a.groups - 1) / a.groups * a.groups;      // whole tiles per XCD
+    a.wgs_per_xcd = a.units_per_xcd < g_spk_wgs_per_xcd ? a.units_per_xcd : g_spk_wgs_per_xcd;
+    a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;                           // one output group per workgroup (bias kept in registers)
+    if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
+    hipLaunchKernelGGL((conv3x3_spk_kernel<NMT, TERMS, HAS_RES>), dim3(8 * a.wgs_per_xcd), dim3(512), Cfg::LDS_BYTES, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+template <int NMT, int TERMS>
+static int spk_launch(SpkArgs& a, int N, hipStream_t s) {
+    return a.residual ? spk_launch2<NMT, TERMS, true>(a, N, s) : spk_launch2<NMT, TERMS, false>(a, N, s);
+}
+
+extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d && d->wpack && (d->out_f32 || d->out_spk) && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
+    FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= SPK_MAX_GROUPS * 8 && d->cout > 0 && d->cout <= 96);
+    FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->H > 0 && d->W > 0);
+    FLDR_CHECK_ARG(!d->residual || d->out_f32);
+    SpkArgs a;
+    int gsum = 0, csum = 0;
+    for (int s = 0; s < d->n_src; ++s) {
+        FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0);
+        if (d->src_up2[s] && ((d->H | d->W) & 1)) return FLDR_E_SHAPE;
+        if (s + 1 < d->n_src && (d->src_c[s] & 7)) return FLDR_E_SHAPE;      // only the last source may have a partial group
+        const int ng = (d->src_c[s] + 7) / 8;
+        if (gsum + ng > SPK_MAX_GROUPS) return FLDR_E_ARG;
+        const int64_t plane = d->src_up2[s] ? (int64_t)(d->H >> 1) * (d->W >> 1) * 16 : (int64_t)d->H * d->W * 16;
+        for (int g = 0; g < ng; ++g) {
+            a.grp_ptr[gsum + g] = (unsigned long long)(reinterpret_cast<uintptr_t>(d->src[s]) + (uint64_t)g * 2 * plane) | (d->src_up2[s] ? 1ull : 0ull);
+            a.grp_bstride[gsum + g] = d->src_bstride[s];
+        }
+        gsum += ng; csum += d->src_c[s];
+    }
+    if (csum != d->cin) return FLDR_E_SHAPE;
+    for (int g = gsum; g < SPK_MAX_GROUPS; ++g) { a.grp_ptr[g] = 0ull; a.grp_bstride[g] = 0; }
+    a.wpack = d->wpack; a.bias = d->bias; a.residual = d->residual;
+    a.out_f32 = d->out_f32; a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
+    a.out_spk_bstride = fldr_spk_bytes(d->cout_store, d->H, d->W);
+    a.n_chunks = (d->cin + 15) / 16; a.cout = d->cout; a.cout_store = d->cout_store;
+    a.H = d->H; a.W = d->W; a.relu = d->relu;
+    int nmt, groups;
+    spk_geometry(d->cout, nmt, groups);
+    a.groups = groups;
+    hipStream_t s = fldr_s(stream);
+    if (d->precision == 1) {
+        if (nmt == 1) return spk_launch<1, 1>(a, d->N, s);
+        if (nmt == 2) return spk_launch<2, 1>(a, d->N, s);
+        return spk_launch<3, 1>(a, d->N, s);
+    }
+    if (nmt == 1) return spk_launch<1, 3>(a, d->N, s);
+    if (nmt == 2) return spk_launch<2, 3>(a, d->N, s);
+    return spk_launch<3, 3>(a, d->N, s);
+}

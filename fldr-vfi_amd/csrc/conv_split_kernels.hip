@@ -226,8 +226,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
         for (int s = 0; s < SP_STEPS; ++s) {
             if (s == SP_STEPS - 1) {
                 SSTAMP(t1)
+#if defined(SPLIT_ABLATE) && SPLIT_ABLATE >= 5
+#elif defined(SPLIT_ABLATE) && SPLIT_ABLATE == 3
+                if (ch + 2 < n_chunks) { issue_weights(ch + 2); }
+#elif defined(SPLIT_ABLATE) && SPLIT_ABLATE == 4
+                if (ch + 1 < n_chunks) store_inputs(ch + 1);
+                if (ch + 2 < n_chunks) { load_inputs(ch + 2); }
+#else
                 if (ch + 1 < n_chunks) store_inputs(ch + 1);
                 if (ch + 2 < n_chunks) { issue_weights(ch + 2); load_inputs(ch + 2); }
+#endif
                 SSTAMP(t2)
 #ifdef FLDR_STAMPS
                 st_mfma += t1 - t0; st_stage += t2 - t1; tb0 = t2;
@@ -261,7 +269,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
         }
         SSTAMP(t3)
         __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): my LDS writes are done (vmcnt left alone)
+#if !defined(SPLIT_ABLATE) || SPLIT_ABLATE != 6
         __builtin_amdgcn_s_barrier();
+#endif
         SSTAMP(t4)
 #ifdef FLDR_STAMPS
         st_last += t3 - tb0; st_bar += t4 - t3;

@@ -35,6 +35,23 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class SpkConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("src", ctypes.c_void_p * MAX_SRC),
+        ("src_bstride", ctypes.c_int64 * MAX_SRC),
+        ("src_c", ctypes.c_int32 * MAX_SRC),
+        ("src_up2", ctypes.c_int32 * MAX_SRC),
+        ("n_src", ctypes.c_int32),
+        ("wpack", ctypes.c_void_p),
+        ("bias", ctypes.c_void_p),
+        ("residual", ctypes.c_void_p),
+        ("out_f32", ctypes.c_void_p),
+        ("out_spk", ctypes.c_void_p),
+        ("N", ctypes.c_int32), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_store", ctypes.c_int32),
+        ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
+    ]
+
+
 _SIGNATURES = {
     "fldr_version": (ctypes.c_int, []),
     "fldr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
@@ -52,6 +69,13 @@ _SIGNATURES = {
     "fldr_conv_split_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
     "fldr_conv_split_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_conv_spk_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
+    "fldr_conv_spk_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
+    "fldr_conv2d_spk": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_void_p]),
+    "fldr_debug_spk_wgs_per_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_dec3_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
@@ -311,6 +335,113 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     else:
         _check(lib().fldr_conv2d(ctypes.byref(d), _stream()), "fldr_conv2d")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# split-packed activations (include/fldr_hip.h: fldr_spk_*): the layout between convolutions
+# ---------------------------------------------------------------------------------------------
+
+class Spk:
+    """A logical [N,C,H,W] fp32 activation stored split-packed: [N][ceil(C/8)][hi,lo][H*W][8 x fp16]."""
+    __slots__ = ("buf", "shape")
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, tuple(shape)
+
+    @property
+    def device(self):
+        return self.buf.device
+
+    def float(self):
+        """hi + lo as an fp32 NCHW tensor (22 significant bits; tests and debugging)."""
+        N, C, H, W = self.shape
+        out = torch.empty(N, C, H, W, device=self.buf.device, dtype=torch.float32)
+        _check(lib().fldr_spk_unpack(ctypes.c_void_p(self.buf.data_ptr()), _dev(out, "out"), N, C, H, W, _stream()), "fldr_spk_unpack")
+        return out
+
+
+def _spk_alloc(N, C, H, W, device):
+    nb = lib().fldr_spk_bytes(C, H, W)
+    return Spk(torch.empty(N * nb // 2, device=device, dtype=torch.float16), (N, C, H, W))
+
+
+def spk_pack(x):
+    """fp32 [N,C,H,W] (batch-strided views allowed) -> Spk."""
+    if isinstance(x, Spk):
+        return x
+    if not x.is_cuda:
+        raise NotImplementedError("fldr spk_pack has no CPU path")
+    if x.dtype != torch.float32:
+        raise TypeError("spk_pack source must be float32")
+    if not x[0].is_contiguous():
+        x = x.contiguous()
+    N, C, H, W = x.shape
+    out = _spk_alloc(N, C, H, W, x.device)
+    _check(lib().fldr_spk_pack(ctypes.c_void_p(x.data_ptr()), x.stride(0) if N > 1 else 0, ctypes.c_void_p(out.buf.data_ptr()),
+                               N, C, H, W, _stream()), "fldr_spk_pack")
+    return out
+
+
+def conv_spk_prepack(weight):
+    hit = getattr(weight, "_fldr_pack_spk", None)
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
+        return hit[1]
+    cout, cin, k, _ = weight.shape
+    n = lib().fldr_conv_spk_prepack_size(cout, cin)
+    if n < 0:
+        raise FldrError("unsupported convolution shape %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    _check(lib().fldr_conv_spk_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, _stream()), "fldr_conv_spk_prepack")
+    weight._fldr_pack_spk = ((weight._version, weight.data_ptr()), wp)
+    return wp
+
+
+def conv2d_spk(srcs, weight, bias, relu=False, residual=None, cout_store=None, up2=None, want_f32=True, want_spk=False,
+               precision=None):
+    """3x3 / stride-1 conv(cat(srcs, 1)) on split-packed sources (fp32 tensors are packed on the fly).  Returns the fp32
+    NCHW tensor, the Spk tensor, or (fp32, Spk) when both are asked for.  Same arithmetic as conv2d(precision='split')."""
+    cout, cin, k, _ = weight.shape
+    assert k == 3
+    up2 = up2 or [False] * len(srcs)
+    packed = [spk_pack(s) for s in srcs]
+    N = packed[0].shape[0]
+    H = packed[0].shape[2] * (2 if up2[0] else 1)
+    W = packed[0].shape[3] * (2 if up2[0] else 1)
+    d = SpkConvDesc()
+    csum = 0
+    for i, (s, u) in enumerate(zip(packed, up2)):
+        n, c, h, w = s.shape
+        assert n == N and h * (2 if u else 1) == H and w * (2 if u else 1) == W
+        if i + 1 < len(packed) and c % 8:
+            raise FldrError("every packed source but the last needs a multiple of 8 channels (got %d)" % c)
+        d.src[i] = s.buf.data_ptr()
+        d.src_bstride[i] = lib().fldr_spk_bytes(c, h, w) if N > 1 else 0
+        d.src_c[i] = c
+        d.src_up2[i] = int(bool(u))
+        csum += c
+    assert csum == cin, "concatenated channels %d != weight cin %d" % (csum, cin)
+    d.n_src = len(packed)
+    cs = cout if cout_store is None else cout_store
+    dev = packed[0].device
+    wp = conv_spk_prepack(weight)
+    d.wpack = wp.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    out32 = torch.empty(N, cs, H, W, device=dev, dtype=torch.float32) if (want_f32 or residual is not None) else None
+    outp = _spk_alloc(N, cs, H, W, dev) if want_spk else None
+    if residual is not None:
+        residual = residual.contiguous()
+        assert residual.shape == out32.shape
+        d.residual = residual.data_ptr()
+    d.out_f32 = out32.data_ptr() if out32 is not None else None
+    d.out_spk = outp.buf.data_ptr() if outp is not None else None
+    prec = precision or CONV_PRECISION
+    d.N, d.cin, d.cout, d.cout_store, d.H, d.W = N, cin, cout, cs, H, W
+    d.relu, d.precision = int(bool(relu)), (1 if prec == "fp16" else 0)
+    _check(lib().fldr_conv2d_spk(ctypes.byref(d), _stream()), "fldr_conv2d_spk")
+    if want_f32 and want_spk:
+        return out32, outp
+    return outp if want_spk else out32
 
 
 def synth_tail(refine, cands, t, T_param, out_dtype=torch.float64):

@@ -147,6 +147,37 @@ int64_t fldr_conv_split_prepack_size(int cout, int cin);
 int fldr_conv_split_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 
+/* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.
+ * A logical [N,C,H,W] fp32 tensor is stored as [N][G=ceil(C/8)][hi,lo][H*W][8 x fp16] (x = hi + lo, 22 significant
+ * bits; 4 B per element like fp32): the producer splits each value once and the consumer's staging becomes pure
+ * LDS-DMA.  fldr_conv2d_spk is the same convolution as fldr_conv2d_split (bit-identical results: same split, same
+ * MFMA order) with packed sources, a persistent software-pipelined workgroup per CU, and either or both of an fp32
+ * NCHW output (with the optional residual) and a packed output.  Replaces the same nn.Conv2d stacks. */
+typedef struct fldr_spk_conv_desc {
+    const void*  src[FLDR_CONV_MAX_SRC];        /* packed source s (fldr_spk_pack or a previous out_spk) */
+    int64_t      src_bstride[FLDR_CONV_MAX_SRC];/* bytes between samples */
+    int32_t      src_c[FLDR_CONV_MAX_SRC];      /* channels; every source but the last must have a multiple of 8 */
+    int32_t      src_up2[FLDR_CONV_MAX_SRC];    /* 1: stored at [H/2, W/2], read nearest x2 */
+    int32_t      n_src;
+    const float* wpack;        /* from fldr_conv_spk_prepack */
+    const float* bias;         /* [cout] or NULL */
+    const float* residual;     /* fp32 [N,cout_store,H,W], added after the activation (needs out_f32), or NULL */
+    float*       out_f32;      /* [N,cout_store,H,W] or NULL */
+    void*        out_spk;      /* packed [N, cout_store channels, H, W] (fldr_spk_bytes per sample) or NULL */
+    int32_t N, cin, cout, cout_store;
+    int32_t H, W;
+    int32_t relu;
+    int32_t precision;         /* 0: 3 x fp16 split (fp32-equivalent); 1: hi halves only (plain fp16 inputs) */
+} fldr_spk_conv_desc;
+
+int64_t fldr_spk_bytes(int C, int H, int W);                       /* bytes of one packed sample */
+int fldr_spk_pack(const float* src, int64_t src_bstride_floats, void* dst, int N, int C, int H, int W, fldr_stream_t stream);
+int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fldr_stream_t stream);   /* hi + lo, tests */
+int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
+int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
+int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
+
 /* ------------------------------------------------------------------------------------------
  * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.
  * ------------------------------------------------------------------------------------------ */
