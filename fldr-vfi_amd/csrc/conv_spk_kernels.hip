@@ -63,7 +63,7 @@ struct SpkCfg {
     static constexpr int NWI = (PIECES + 511) / 512;
     static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
     static constexpr int LDS_BYTES = 3 * STAGE;
-    static constexpr int K_MIN = 3 + PIECES / 512;                      // DMA instructions EVERY wave issues per iteration
+    static constexpr int K_MIN = 3 + NWI;                               // DMA instructions every wave issues per iteration
     static_assert(PIECES % 64 == 0, "weight slab must be a whole number of wave-wide DMA pieces");
 };
 
@@ -77,15 +77,52 @@ __device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo) {
 template <int N_MFMA, int N_DS, int I>
 struct SpkInterleave {
     static __device__ __forceinline__ void run() {
-        __builtin_amdgcn_sched_group_barrier(0x008, (N_MFMA * (I + 1)) / N_DS - (N_MFMA * I) / N_DS, 0);
+        constexpr int cnt = (N_MFMA * (I + 1)) / N_DS - (N_MFMA * I) / N_DS;
+        if constexpr (cnt > 0) __builtin_amdgcn_sched_group_barrier(0x008, cnt, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         SpkInterleave<N_MFMA, N_DS, I + 1>::run();
     }
+};
+template <int NV, int I>
+struct SpkInterleaveV {                                             // {1 MFMA, 1 vector-memory instruction} x NV
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        SpkInterleaveV<NV, I + 1>::run();
+    }
+};
+template <int NV>
+struct SpkInterleaveV<NV, NV> {
+    static __device__ __forceinline__ void run() {}
 };
 template <int N_MFMA, int N_DS>
 struct SpkInterleave<N_MFMA, N_DS, N_DS> {
     static __device__ __forceinline__ void run() {}
 };
+
+// One MFMA step: {1 MFMA, 1 DMA} per DMA instruction of the step, then the next step's LDS reads spread over all but
+// the last N_TAIL MFMAs (which cover the latency of the last read: the wait in front of the next step is an
+// lgkmcnt(0)); the last step has no reads.
+template <int N_MFMA, int N_DS, int N_TAIL, int NV>
+__device__ __forceinline__ void spk_step_pattern_n(bool reads) {
+    SpkInterleaveV<NV, 0>::run();
+    constexpr int rest = N_MFMA - NV;
+    if (reads) {
+        constexpr int tail = rest - N_TAIL >= N_DS / 2 ? N_TAIL : 0;
+        SpkInterleave<rest - tail, N_DS, 0>::run();
+        if constexpr (tail > 0) __builtin_amdgcn_sched_group_barrier(0x008, tail, 0);
+    } else {
+        if constexpr (rest > 0) __builtin_amdgcn_sched_group_barrier(0x008, rest, 0);
+    }
+}
+template <int N_MFMA, int N_DS, int N_TAIL, int K_DMA>
+__device__ __forceinline__ void spk_step_pattern(int s) {            // s is a constant after unrolling
+    const int nv = ((s + 1) * K_DMA + SPK_STEPS - 1) / SPK_STEPS - (s * K_DMA + SPK_STEPS - 1) / SPK_STEPS;
+    const bool reads = s + 1 < SPK_STEPS;
+    if (nv == 0) spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(reads);
+    else if (nv == 1) spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 1>(reads);
+    else spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 2>(reads);
+}
 
 template <int NMT, int TERMS, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
@@ -109,13 +146,24 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
 
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
-    // ---- issue side: which pieces of the input image this wave's three DMA instructions fill ----
+    // ---- issue side ----
+    // Every wave issues the same K_DMA = NWI + 3 LDS-DMA instructions per iteration, all lanes active, no branches
+    // (they are scheduled BETWEEN the MFMAs of the iteration, see the pipeline): NWI weight pieces (1 KB each; the
+    // waves that would run past the slab re-fetch its last pieces instead) and three 64-pixel pieces of one of the 4
+    // input planes (pieces [0,64) [64,128) [128,192) or [192,256) [256,320) [288,352): the overlap of the last two
+    // writes the same bytes twice instead of masking lanes).
+    constexpr int K_DMA = Cfg::NWI + 3;
     const int ip = wave >> 1;                                            // LDS plane: kind = ip >> 1, group of the chunk = ip & 1
     const int ikind = ip >> 1, igrp = ip & 1;
     const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
+    int w_piece[Cfg::NWI], x_piece[3];
+#pragma unroll
+    for (int i = 0; i < Cfg::NWI; ++i) w_piece[i] = min(i * 512 + wave * 64, Cfg::PIECES - 64);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) x_piece[i] = min(((wave & 1) * 3 + i) * 64, SPK_PLANE / 16 - 64);
     int iss_u = u_first, iss_c = 0;
     int g_full[3], g_half[3];
-    bool g_ok[3], g_act[3];
+    bool g_ok[3];
     int iss_n = 0;
     const float* iss_w = nullptr;
     auto issue_geometry = [&]() {
@@ -125,29 +173,28 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
         const int oy0 = (tile / a.tiles_x) * SPK_TH, ox0 = (tile % a.tiles_x) * SPK_TW;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int e = ((wave & 1) * 3 + i) * 64 + lane;
+            const int e = x_piece[i] + lane;
             const int y = e / SPK_IW, x = e % SPK_IW;
             const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
-            g_act[i] = e < SPK_PLANE / 16;
             g_ok[i] = e < SPK_IH * SPK_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             g_full[i] = g_ok[i] ? (gy * a.W + gx) * 16 : 0;
             g_half[i] = g_ok[i] ? ((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16 : 0;
         }
         iss_w = a.wpack + SPK_HDR + (int64_t)grp * n_chunks * (Cfg::W_BYTES / 4);
     };
-    auto issue = [&](int stage_idx) {                                    // DMA of (iss_u, iss_c) -> ring stage
-        // Past the workgroup's last iteration the same instructions are issued against the zero block (into a ring
-        // stage nobody reads any more), so that the counted vmcnt wait below holds in every iteration.
+    const char* dptr[K_DMA];                                             // per-lane source addresses of the next iteration to issue
+    auto issue_prepare = [&]() {
+        // Past the workgroup's last iteration the same instructions run against the zero block (into a ring stage
+        // nobody reads any more), so that the counted vmcnt wait holds in every iteration.
         const bool live = iss_u < u_end;                                 // workgroup-uniform
-        unsigned char* stage = smem + stage_idx * Cfg::STAGE;
         const float* g = iss_w + (int64_t)iss_c * (Cfg::W_BYTES / 4);
 #pragma unroll
         for (int i = 0; i < Cfg::NWI; ++i) {
-            const int piece = i * 512 + wave * 64;
-            if (piece < Cfg::PIECES) {
-                const float* src = live ? g + (piece + lane) * 4 : reinterpret_cast<const float*>(zero_blk);
-                __builtin_amdgcn_global_load_lds((kgptr_t)src, (klptr_t)(stage + piece * 16), 16, 0, 0);
-            }
+#if defined(SPK_ABLATE) && (SPK_ABLATE == 4 || SPK_ABLATE == 5)
+            dptr[i] = zero_blk;                                          // diagnostic: same instruction count, no traffic
+#else
+            dptr[i] = live ? reinterpret_cast<const char*>(g + (w_piece[i] + lane) * 4) : zero_blk;
+#endif
         }
         const int gi = live ? iss_c * 2 + igrp : 0;
         const unsigned long long e = live ? a.grp_ptr[gi] : 0ull;
@@ -155,14 +202,20 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
         const int64_t plane = up2 ? (int64_t)(a.H >> 1) * (a.W >> 1) * 16 : (int64_t)a.H * a.W * 16;
         const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * a.grp_bstride[gi]
                            + (ikind ? plane : 0);
-        unsigned char* dst = stage + Cfg::W_BYTES + ip * SPK_PLANE + (wave & 1) * 3 * 1024;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const char* p = (g_ok[i] && !nul) ? base + (up2 ? g_half[i] : g_full[i]) : zero_blk;
-            if (g_act[i])
-                __builtin_amdgcn_global_load_lds((kgptr_t)p, (klptr_t)(dst + i * 1024), 16, 0, 0);
+#if defined(SPK_ABLATE) && (SPK_ABLATE == 3 || SPK_ABLATE == 5)
+            dptr[Cfg::NWI + i] = zero_blk;
+#else
+            dptr[Cfg::NWI + i] = (g_ok[i] && !nul) ? base + (up2 ? g_half[i] : g_full[i]) : zero_blk;
+#endif
         }
         if (live && ++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
+    };
+    auto issue_fire = [&](int j, unsigned char* stage) {                 // j compile-time after unrolling
+        unsigned char* dst = j < Cfg::NWI ? stage + w_piece[j < Cfg::NWI ? j : 0] * 16
+                                          : stage + Cfg::W_BYTES + ip * SPK_PLANE + x_piece[j >= Cfg::NWI ? j - Cfg::NWI : 0] * 16;
+        __builtin_amdgcn_global_load_lds((kgptr_t)dptr[j], (klptr_t)dst, 16, 0, 0);
     };
 
     // ---- compute side ----
@@ -287,19 +340,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
 
     // ---- pipeline ----
     issue_geometry();
-    issue(0);
-    issue(1);                                          // (a dummy zero-block fill when the workgroup has one iteration)
+#pragma unroll
+    for (int st = 0; st < 2; ++st) {                   // (stage 1: a dummy zero-block fill when the workgroup has one iteration)
+        issue_prepare();
+#pragma unroll
+        for (int j = 0; j < K_DMA; ++j) issue_fire(j, smem + st * Cfg::STAGE);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): both prologue stages have landed
     __builtin_amdgcn_s_barrier();
 
     int st_cur = 0, st_iss = 2;
     bool store_pending = false;
     for (int g = 0; g < total; ++g) {
+#if !defined(SPK_ABLATE) || SPK_ABLATE != 7
         if (store_pending) { store(); store_pending = false; }
+#endif
         const bool last = cur_c == n_chunks - 1;       // workgroup-uniform
         if constexpr (HAS_RES) { if (last) residual_prefetch(); }
-        issue(st_iss);                                 // iteration g+2 (dummy zero-block fills past the end): every
-                                                       // iteration issues the same number of DMA instructions
+        issue_prepare();                               // addresses of iteration g+2's DMA (dummy zero-block fills past the
+                                                       // end); the K_DMA instructions themselves go between the MFMAs below
+        unsigned char* sdst = smem + st_iss * Cfg::STAGE;
         const unsigned char* sb = smem + st_cur * Cfg::STAGE;
         const unsigned char* win = sb + lane * 16;
         h8 bh[2][2], bl[2][2], ah[2][NMT], al[2][NMT];
@@ -327,7 +387,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
         __builtin_amdgcn_sched_barrier(0);                           // keep step 0's reads out of the interleave pattern below
 #pragma unroll
         for (int s = 0; s < SPK_STEPS; ++s) {
+            // this step's share of the DMA instructions: an LDS-DMA instruction holds its wave's issue for 60-180
+            // cycles; one at a time between MFMAs, the other wave of the SIMD keeps the matrix pipe busy meanwhile
+            const int j0 = (s * K_DMA + SPK_STEPS - 1) / SPK_STEPS, j1 = ((s + 1) * K_DMA + SPK_STEPS - 1) / SPK_STEPS;
+#pragma unroll
+            for (int j = 0; j < K_DMA; ++j)
+                if (j >= j0 && j < j1) issue_fire(j, sdst);
+#if defined(SPK_ABLATE) && SPK_ABLATE == 1
+            if (s + 1 < SPK_STEPS) { for (int p = 0; p < 2; ++p) { bh[(s + 1) & 1][p] = bh[s & 1][p]; bl[(s + 1) & 1][p] = bl[s & 1][p]; }
+                                    for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; al[(s + 1) & 1][m] = al[s & 1][m]; } }
+#else
             if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);           // lands while this step's MFMAs run
+#endif
 #pragma unroll
             for (int term = 0; term < TERMS; ++term)
 #pragma unroll
@@ -336,17 +407,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
                     for (int p = 0; p < 2; ++p) {
                         const h8 av = term == 2 ? al[s & 1][m] : ah[s & 1][m];
                         const h8 bv = term == 1 ? bl[s & 1][p] : bh[s & 1][p];
+#if defined(SPK_ABLATE) && SPK_ABLATE == 2
+                        asm volatile("" :: "v"(av), "v"(bv));
+#else
                         acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][p], 0, 0, 0);
+#endif
                     }
             // spread the next step's LDS reads evenly between this step's MFMAs
-            if (s + 1 < SPK_STEPS) {
-                // ... over all but the last N_TAIL MFMAs, which cover the latency of the last read (the wait in front
-                // of the next step is an lgkmcnt(0))
-                SpkInterleave<N_MFMA - N_TAIL, N_DS, 0>::run();
-                __builtin_amdgcn_sched_group_barrier(0x008, N_TAIL, 0);
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, N_MFMA, 0);
-            }
+            spk_step_pattern<N_MFMA, N_DS, N_TAIL, K_DMA>(s);
         }
         if (last) {
             finish();

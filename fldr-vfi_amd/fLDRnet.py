@@ -107,9 +107,17 @@ class DCTXVFInet(nn.Module):
 
     def extract_features(self, pca):
         """rec_ctx_ds(x) + x  (fLDRnet.py:44-49,162): two fused conv kernels."""
+        return self._extract_features(pca)[0]
+
+    def _extract_features(self, pca):
+        """-> (features fp32 NCHW, the same features split-packed or None).  The intermediate activation only exists
+        split-packed; the result is written in both layouts by one kernel (fp32 for the splats, packed for conv_flow1)."""
         c0, c2 = self.rec_ctx_ds[0], self.rec_ctx_ds[2]
-        y = fldr_hip.conv2d([pca], c0.weight, c0.bias, relu=True)
-        return fldr_hip.conv2d([y], c2.weight, c2.bias, relu=True, residual=pca)
+        if not fldr_hip.use_spk():
+            y = fldr_hip.conv2d([pca], c0.weight, c0.bias, relu=True)
+            return fldr_hip.conv2d([y], c2.weight, c2.bias, relu=True, residual=pca), None
+        y = fldr_hip.conv2d_spk([pca], c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
+        return fldr_hip.conv2d_spk([y], c2.weight, c2.bias, relu=True, residual=pca, want_f32=True, want_spk=True)
 
     def forward(self, input_gpuList, t_value, normInput=0, is_training=True, validation=False, epoch=0, frameT=None):
         """input_gpuList: ignored placeholders (the reference overwrites them, fLDRnet.py:134); t_value [B,1];
@@ -132,7 +140,7 @@ class DCTXVFInet(nn.Module):
                 B, _, _, h, w = x_l[i].shape
                 pca = to_pca_diff_f32(x_l[i].reshape(B * 6, h, w), self.params[i], a, self.pca_means[i8], self.EVs[i8],
                                       self.mean_vecs[i8]).view(B, a.dctvfi_nf * 6, h // 8, w // 8)  # :146
-                feats.append(self.extract_features(pca) if a.ref_feat_extrac else pca)
+                feats.append(self._extract_features(pca) if a.ref_feat_extrac else (pca, None))
             flow = None
             for level in range(a.S_tst, -1, -1):                                                       # :210-218
                 flow = self.vfinet.estimate_flow(feats[level], flow)
@@ -178,13 +186,19 @@ class DCTVFInet(nn.Module):
 
     @staticmethod
     def _chain(x_srcs, seq, idxs, final_store=None, final_residual=None):
-        """conv+ReLU chain over nn.Sequential `seq`; the last index gets no activation."""
+        """conv+ReLU chain over nn.Sequential `seq`; the last index gets no activation.  Activations between the
+        convolutions exist only split-packed (fldr_hip.Spk); the chain's result is fp32 NCHW."""
         x = x_srcs
+        spk = fldr_hip.use_spk()
         for n, i in enumerate(idxs):
             m = seq[i]
             last = n == len(idxs) - 1
-            y = fldr_hip.conv2d(x, m.weight, m.bias, relu=not last, cout_store=final_store if last else None,
-                                residual=final_residual if last else None)
+            if spk:
+                y = fldr_hip.conv2d_spk(x, m.weight, m.bias, relu=not last, cout_store=final_store if last else None,
+                                        residual=final_residual if last else None, want_f32=last, want_spk=not last)
+            else:
+                y = fldr_hip.conv2d(x, m.weight, m.bias, relu=not last, cout_store=final_store if last else None,
+                                    residual=final_residual if last else None)
             x = [y]
         return x[0]
 
@@ -200,18 +214,28 @@ class DCTVFInet(nn.Module):
     def estimate_flow(self, feat_x, flow_l_prev):
         """Flow estimation of one pyramid level (fLDRnet.py:368-391); t-independent."""
         a = self.args
+        feat_p = None
+        if isinstance(feat_x, tuple):                                  # (fp32 NCHW, split-packed twin) from _extract_features
+            feat_x, feat_p = feat_x
         B, C, H, W = feat_x.shape
         half = a.img_ch * a.dctvfi_nf
         feat0, feat1 = feat_x[:, :half], feat_x[:, half:]              # the F4 split of fLDRnet.py:368-370
+        spk = fldr_hip.use_spk()
+        if spk and feat_p is None:
+            feat_p = fldr_hip.spk_pack(feat_x)
         if flow_l_prev is None:
-            flow_l = self._chain([feat_x], self.conv_flow_bottom, (0, 2, 4, 6, 8), final_store=4)      # :379-380
+            flow_l = self._chain([feat_p if spk else feat_x], self.conv_flow_bottom, (0, 2, 4, 6, 8), final_store=4)   # :379-380
         else:
             up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])             # :384-385
             w1 = self.softsplat(feat1, up[:, :2])                                                      # :386
             w0 = self.softsplat(feat0, up[:, 2:])                                                      # :387
             f1 = self.conv_flow1
-            ca = fldr_hip.conv2d([feat0, w1], f1.weight, f1.bias)
-            cb = fldr_hip.conv2d([feat1, w0], f1.weight, f1.bias)
+            if spk:
+                ca = fldr_hip.conv2d_spk([feat_p.narrow(0, half), w1], f1.weight, f1.bias, want_f32=False, want_spk=True)
+                cb = fldr_hip.conv2d_spk([feat_p.narrow(half, half), w0], f1.weight, f1.bias, want_f32=False, want_spk=True)
+            else:
+                ca = fldr_hip.conv2d([feat0, w1], f1.weight, f1.bias)
+                cb = fldr_hip.conv2d([feat1, w0], f1.weight, f1.bias)
             flow_l = self._chain([ca, cb, up], self.conv_flow2, (0, 2, 4, 6, 8), final_residual=up)    # :389-391
         return flow_l
 
@@ -309,6 +333,11 @@ class PCARefineUNet(nn.Module):
         enc1 = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True)
         enc2 = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True)
         out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True)
+        if fldr_hip.use_spk():                                        # decoder activations stay split-packed
+            cs = fldr_hip.conv2d_spk
+            out = cs([out], self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
+            out = cs([out, enc2], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
+            return cs([out, enc1], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])
         out = cv([out], self.dec0.weight, self.dec0.bias, relu=True)
         out = cv([out, enc2], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False])     # NN + cat (:632-634)
         return cv([out, enc1], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])    # :638-640

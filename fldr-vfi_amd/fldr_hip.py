@@ -262,6 +262,11 @@ def conv_prepack(weight):
 CONV_PRECISION = os.environ.get("FLDR_CONV_PRECISION", "split")
 
 
+def use_spk():
+    """True when the 3x3 stride-1 convolutions run on split-packed activations (every precision but exact fp32)."""
+    return CONV_PRECISION in ("split", "fp16")
+
+
 def conv_split_prepack(weight):
     hit = getattr(weight, "_fldr_pack_split", None)
     if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
@@ -343,18 +348,32 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
 
 class Spk:
     """A logical [N,C,H,W] fp32 activation stored split-packed: [N][ceil(C/8)][hi,lo][H*W][8 x fp16]."""
-    __slots__ = ("buf", "shape")
+    __slots__ = ("buf", "shape", "offset", "bstride")
 
-    def __init__(self, buf, shape):
-        self.buf, self.shape = buf, tuple(shape)
+    def __init__(self, buf, shape, offset=0, bstride=None):
+        self.buf, self.shape, self.offset = buf, tuple(shape), offset
+        N, C, H, W = self.shape
+        self.bstride = ((C + 7) // 8) * 2 * H * W * 16 if bstride is None else bstride      # bytes between samples
 
     @property
     def device(self):
         return self.buf.device
 
+    @property
+    def ptr(self):
+        return self.buf.data_ptr() + self.offset
+
+    def narrow(self, c0, c):
+        """Channels [c0, c0+c) as a view (the feat[:, :48] / feat[:, 48:] split of fLDRnet.py:368-370): c0 must be a
+        multiple of 8; a view that does not end on a group boundary must end at the tensor's last channel."""
+        N, C, H, W = self.shape
+        assert c0 % 8 == 0 and c > 0 and c0 + c <= C and (c % 8 == 0 or c0 + c == C)
+        return Spk(self.buf, (N, c, H, W), self.offset + (c0 // 8) * 2 * H * W * 16, self.bstride)
+
     def float(self):
         """hi + lo as an fp32 NCHW tensor (22 significant bits; tests and debugging)."""
         N, C, H, W = self.shape
+        assert self.offset == 0 and self.bstride == ((C + 7) // 8) * 2 * H * W * 16, "float() of a channel view is not supported"
         out = torch.empty(N, C, H, W, device=self.buf.device, dtype=torch.float32)
         _check(lib().fldr_spk_unpack(ctypes.c_void_p(self.buf.data_ptr()), _dev(out, "out"), N, C, H, W, _stream()), "fldr_spk_unpack")
         return out
@@ -415,8 +434,8 @@ def conv2d_spk(srcs, weight, bias, relu=False, residual=None, cout_store=None, u
         assert n == N and h * (2 if u else 1) == H and w * (2 if u else 1) == W
         if i + 1 < len(packed) and c % 8:
             raise FldrError("every packed source but the last needs a multiple of 8 channels (got %d)" % c)
-        d.src[i] = s.buf.data_ptr()
-        d.src_bstride[i] = lib().fldr_spk_bytes(c, h, w) if N > 1 else 0
+        d.src[i] = s.ptr
+        d.src_bstride[i] = s.bstride if N > 1 else 0
         d.src_c[i] = c
         d.src_up2[i] = int(bool(u))
         csum += c
