@@ -33,34 +33,37 @@ from fldr_harness import shard_pairs, host_cores, max_over_ranks  # noqa: E402
 
 def dominant_conv_roofline(model, pyr, steps):
     """Roofline of the dominant kernel: the 96->96 3x3 convolution at the level-0 feature map (rec_ctx_ds.0/.2,
-    conv_flow2.0/.2 launch this instance; 32 % of the GPU time).  It runs on the fp16 matrix cores with the 3 x fp16
-    split (fp32-equivalent accuracy), i.e. it issues THREE fp16 MFMA flops per algorithmic flop.
-    algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels; achieved = 3 x that / launch time, against the dense
-    fp16 MFMA peak.  Duration measured with HIP events on the launch stream.  The exact fp32-MFMA kernel of the same
-    layer (FLDR_CONV_PRECISION=fp32) is timed beside it."""
+    conv_flow2.0/.2 launch this instance of conv3x3_spk_kernel; the 3x3 convolutions are ~30 % of the GPU time).  It
+    runs on the fp16 matrix cores with the 3 x fp16 split (fp32-equivalent accuracy), i.e. it issues THREE fp16 MFMA
+    flops per algorithmic flop.  algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels; achieved = 3 x that /
+    launch time, against the dense fp16 MFMA peak.  Duration measured with HIP events on the launch stream, operands
+    split-packed in HBM as inside the model.  The exact fp32-MFMA kernel of the same layer (FLDR_CONV_PRECISION=fp32)
+    is timed beside it."""
     import fldr_hip
     h, w = pyr[0].shape[3] // 8, pyr[0].shape[4] // 8
     x = torch.rand(1, 96, h, w, device=pyr[0].device) * 2 - 1
+    xp = fldr_hip.spk_pack(x)
     conv = model.rec_ctx_ds[0]
     out = torch.empty(1, 96, h, w, device=x.device)
     n = max(10, steps)
 
-    def timed(prec):
+    def timed(fn):
         for _ in range(3):
-            fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision=prec)
+            fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for _ in range(n):
-            fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision=prec)
+            fn()
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    ms, ms32 = timed("split"), timed("fp32")
+    ms = timed(lambda: fldr_hip.conv2d_spk([xp], conv.weight, conv.bias, relu=True, want_f32=False, want_spk=True))
+    ms32 = timed(lambda: fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision="fp32"))
     flops = 2.0 * 96 * 96 * 9 * h * w
     ach = 3.0 * flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv3x3_split_kernel<3> (3x3 96->96 @%dx%d, 2 groups of 48 output channels, "
+    return {"bound": "mfma", "kernel": "conv3x3_spk_kernel<3,3> (3x3 96->96 @%dx%d, persistent workgroups, split-packed operands, "
                                        "3 x fp16-split v_mfma_f32_16x16x32_f16)" % (h, w),
             "achieved": round(ach, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4),
             "traffic": _measured_traffic(), "launch_ms": round(ms, 4), "flops_per_launch": flops,
@@ -72,7 +75,7 @@ def dominant_conv_roofline(model, pyr, steps):
 def _measured_traffic():
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None when no measurement is on file."""
-    p = os.path.join(ROOT, "profiles", "r01_conv96_split_traffic.json")
+    p = os.path.join(ROOT, "profiles", "r01_conv96_spk_traffic.json")
     try:
         return json.load(open(p))["hbm_bytes_per_launch"]
     except Exception:

@@ -24,6 +24,18 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 
+#ifdef SPK_STAMPS
+// Diagnostic build only (tools/stamps): per-phase s_memtime sums of waves 0 and 4 of two workgroups, written to a
+// buffer no kernel reads.
+__device__ unsigned long long fldr_spk_stamp_buf[4 * 8];
+#define KSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int fldr_debug_read_spk_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_spk_stamp_buf), sizeof(unsigned long long) * 32);
+}
+#else
+#define KSTAMP(var)
+#endif
+
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -54,6 +66,7 @@ struct SpkArgs {
     int32_t relu;
     int32_t tiles_x, n_tiles, groups;
     int32_t n_units, units_per_xcd, wgs_per_xcd;
+    uint32_t m_groups, m_tiles, m_tiles_x;        // floor(2^32 / d) + 1: u / d == umulhi(u, m) for u * d < 2^32 (d > 1)
 };
 
 template <int NMT>
@@ -66,6 +79,10 @@ struct SpkCfg {
     static constexpr int K_MIN = 3 + NWI;                               // DMA instructions every wave issues per iteration
     static_assert(PIECES % 64 == 0, "weight slab must be a whole number of wave-wide DMA pieces");
 };
+
+__device__ __forceinline__ int spk_div(int u, uint32_t m, int d) {     // exact for 0 <= u, u * d < 2^32 (host-checked)
+    return d == 1 ? u : (int)__umulhi((uint32_t)u, m);
+}
 
 __device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo) {
     const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);     // 11 significant bits: exact in fp16
@@ -144,7 +161,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     const int my_units = (u_end - u_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
     const int total = my_units * n_chunks;
 
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    // The two waves of a SIMD are skewed: waves 4-7 ("early", MFMA priority) enter an iteration's MFMA steps right
+    // after the barrier and do their bookkeeping (epilogue stores, address generation of the next DMA) after their
+    // last MFMA, while they would otherwise idle at the barrier; waves 0-3 ("late") do theirs first, under the early
+    // wave's MFMAs.  Measured before the skew: ~1,200 cycles per iteration in which neither wave issued an MFMA.
+    const bool early = wave >= 4;                                        // wave-uniform
+    if (early) __builtin_amdgcn_s_setprio(1);
 
     // ---- issue side ----
     // Every wave issues the same K_DMA = NWI + 3 LDS-DMA instructions per iteration, all lanes active, no branches
@@ -157,65 +179,87 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     const int ikind = ip >> 1, igrp = ip & 1;
     const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
     int w_piece[Cfg::NWI], x_piece[3];
+    uint32_t w_voff[Cfg::NWI];
 #pragma unroll
-    for (int i = 0; i < Cfg::NWI; ++i) w_piece[i] = min(i * 512 + wave * 64, Cfg::PIECES - 64);
+    for (int i = 0; i < Cfg::NWI; ++i) {
+        w_piece[i] = min(i * 512 + wave * 64, Cfg::PIECES - 64);
+        w_voff[i] = (uint32_t)(w_piece[i] + lane) * 16u;
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) x_piece[i] = min(((wave & 1) * 3 + i) * 64, SPK_PLANE / 16 - 64);
+    // The input-group table lives in VGPR lanes (lane l = group l, already advanced to this wave's hi or lo plane):
+    // one v_readlane per iteration instead of dependent scalar loads from the kernel arguments (measured: the scalar
+    // loads + waits cost ~1,000 cycles per iteration in which neither wave of a SIMD issued MFMAs).
+    unsigned long long tab_ptr;
+    long long tab_bs;
+    {
+        const auto* kt = (const __attribute__((address_space(4))) unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();
+        const int l = lane < SPK_MAX_GROUPS ? lane : 0;
+        unsigned long long e = kt[l];
+        tab_bs = (long long)kt[SPK_MAX_GROUPS + l];
+        const bool up2 = (e & 1ull) != 0ull;
+        const long long plane = up2 ? (long long)(a.H >> 1) * (a.W >> 1) * 16 : (long long)a.H * a.W * 16;
+        if (e != 0ull && ikind) e += (unsigned long long)plane;
+        tab_ptr = e;
+    }
     int iss_u = u_first, iss_c = 0;
-    int g_full[3], g_half[3];
-    bool g_ok[3];
+    uint32_t g_full[3], g_half[3];                                       // byte offsets in a plane; ~0u = outside the image
     int iss_n = 0;
-    const float* iss_w = nullptr;
+    const char* iss_w = nullptr;
     auto issue_geometry = [&]() {
-        const int grp = iss_u % a.groups, t = iss_u / a.groups;
-        const int tile = t % a.n_tiles;
-        iss_n = t / a.n_tiles;
-        const int oy0 = (tile / a.tiles_x) * SPK_TH, ox0 = (tile % a.tiles_x) * SPK_TW;
+        const int t = spk_div(iss_u, a.m_groups, a.groups), grp = iss_u - t * a.groups;
+        iss_n = spk_div(t, a.m_tiles, a.n_tiles);
+        const int tile = t - iss_n * a.n_tiles;
+        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+        const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const int e = x_piece[i] + lane;
             const int y = e / SPK_IW, x = e % SPK_IW;
             const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
-            g_ok[i] = e < SPK_IH * SPK_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-            g_full[i] = g_ok[i] ? (gy * a.W + gx) * 16 : 0;
-            g_half[i] = g_ok[i] ? ((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16 : 0;
+            const bool ok = e < SPK_IH * SPK_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            g_full[i] = ok ? (uint32_t)(gy * a.W + gx) * 16u : ~0u;
+            g_half[i] = ok ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : ~0u;
         }
-        iss_w = a.wpack + SPK_HDR + (int64_t)grp * n_chunks * (Cfg::W_BYTES / 4);
+        iss_w = reinterpret_cast<const char*>(a.wpack + SPK_HDR) + (int64_t)grp * n_chunks * Cfg::W_BYTES;
     };
-    const char* dptr[K_DMA];                                             // per-lane source addresses of the next iteration to issue
+    const char* wbase = nullptr;                                         // workgroup-uniform source of the next weight slab
+    const char* dptr[3];                                                 // per-lane source addresses of the next input pieces
     auto issue_prepare = [&]() {
-        // Past the workgroup's last iteration the same instructions run against the zero block (into a ring stage
-        // nobody reads any more), so that the counted vmcnt wait holds in every iteration.
+        // Past the workgroup's last iteration the same instructions run against dummy sources (weight slab 0, the zero
+        // block) into a ring stage nobody reads any more, so that the counted vmcnt wait holds in every iteration.
         const bool live = iss_u < u_end;                                 // workgroup-uniform
-        const float* g = iss_w + (int64_t)iss_c * (Cfg::W_BYTES / 4);
-#pragma unroll
-        for (int i = 0; i < Cfg::NWI; ++i) {
 #if defined(SPK_ABLATE) && (SPK_ABLATE == 4 || SPK_ABLATE == 5)
-            dptr[i] = zero_blk;                                          // diagnostic: same instruction count, no traffic
+        wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR);        // diagnostic: always the same (cached) slab
 #else
-            dptr[i] = live ? reinterpret_cast<const char*>(g + (w_piece[i] + lane) * 4) : zero_blk;
+        wbase = live ? iss_w + (int64_t)iss_c * Cfg::W_BYTES : reinterpret_cast<const char*>(a.wpack + SPK_HDR);
 #endif
-        }
         const int gi = live ? iss_c * 2 + igrp : 0;
-        const unsigned long long e = live ? a.grp_ptr[gi] : 0ull;
-        const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
-        const int64_t plane = up2 ? (int64_t)(a.H >> 1) * (a.W >> 1) * 16 : (int64_t)a.H * a.W * 16;
-        const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * a.grp_bstride[gi]
-                           + (ikind ? plane : 0);
+        const uint32_t e_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_ptr, gi), e_hi = __builtin_amdgcn_readlane((int)(uint32_t)(tab_ptr >> 32), gi);
+        const uint32_t b_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_bs, gi), b_hi = __builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)tab_bs >> 32), gi);
+        const unsigned long long e = ((unsigned long long)e_hi << 32) | e_lo;
+        const long long bs = (long long)(((unsigned long long)b_hi << 32) | b_lo);
+        const bool nul = e == 0ull || !live, up2 = (e & 1ull) != 0ull;
+        const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * bs;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #if defined(SPK_ABLATE) && (SPK_ABLATE == 3 || SPK_ABLATE == 5)
-            dptr[Cfg::NWI + i] = zero_blk;
+            dptr[i] = zero_blk;
 #else
-            dptr[Cfg::NWI + i] = (g_ok[i] && !nul) ? base + (up2 ? g_half[i] : g_full[i]) : zero_blk;
+            const uint32_t off = up2 ? g_half[i] : g_full[i];
+            dptr[i] = (off != ~0u && !nul) ? base + off : zero_blk;
 #endif
         }
         if (live && ++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
     };
     auto issue_fire = [&](int j, unsigned char* stage) {                 // j compile-time after unrolling
-        unsigned char* dst = j < Cfg::NWI ? stage + w_piece[j < Cfg::NWI ? j : 0] * 16
-                                          : stage + Cfg::W_BYTES + ip * SPK_PLANE + x_piece[j >= Cfg::NWI ? j - Cfg::NWI : 0] * 16;
-        __builtin_amdgcn_global_load_lds((kgptr_t)dptr[j], (klptr_t)dst, 16, 0, 0);
+        if (j < Cfg::NWI) {
+            const int jj = j < Cfg::NWI ? j : 0;
+            __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_voff[jj]), (klptr_t)(stage + w_piece[jj] * 16), 16, 0, 0);
+        } else {
+            const int jj = j >= Cfg::NWI ? j - Cfg::NWI : 0;
+            __builtin_amdgcn_global_load_lds((kgptr_t)dptr[jj], (klptr_t)(stage + Cfg::W_BYTES + ip * SPK_PLANE + x_piece[jj] * 16), 16, 0, 0);
+        }
     };
 
     // ---- compute side ----
@@ -253,25 +297,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     //                      next DMA and have a whole iteration to retire before the next counted wait).
     float res_r[NMT][2][4];
     float ov[NMT][2][4];
-    int64_t st_po[2];
-    bool st_ok[2];
+    h4 ohi[NMT][2], olo[NMT][2];
+    uint32_t st_po[2];                                  // pixel index of my two output pixels (~0u when out of the image)
     int st_n = 0;
-    auto unit_pixels = [&](int u, int64_t (&po)[2], bool (&ok)[2], int& n) {
-        const int t = u / a.groups;
-        const int tile = t % a.n_tiles;
-        n = t / a.n_tiles;
-        const int oy = (tile / a.tiles_x) * SPK_TH + wave;
-        const int ox0 = (tile % a.tiles_x) * SPK_TW;
+    // byte offsets below fit 32 bits (host-checked: cout_store*H*W*4 and the packed sample size < 2^32)
+    const uint32_t HW32 = (uint32_t)HW;
+    auto unit_pixels = [&](int u, uint32_t (&po)[2], int& n) {
+        const int t = spk_div(u, a.m_groups, a.groups);
+        n = spk_div(t, a.m_tiles, a.n_tiles);
+        const int tile = t - n * a.n_tiles;
+        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+        const int oy = ty * SPK_TH + wave;
+        const int ox0 = (tile - ty * a.tiles_x) * SPK_TW;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int ox = ox0 + p * 16 + lj;
-            ok[p] = oy < a.H && ox < a.W;
-            po[p] = ok[p] ? (int64_t)oy * a.W + ox : 0;
+            po[p] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
         }
     };
     auto residual_prefetch = [&]() {
-        int64_t po[2]; bool ok[2]; int n;
-        unit_pixels(cur_u, po, ok, n);
+        uint32_t po[2]; int n;
+        unit_pixels(cur_u, po, n);
         const float* resn = a.residual + (int64_t)n * a.cout_store * HW;
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
@@ -281,15 +327,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
                 for (int r = 0; r < 4; ++r) {
                     int co = cbase + m * 16 + lg * 4 + r;
                     co = co < a.cout_store ? co : a.cout_store - 1;
-                    res_r[m][p][r] = resn[(int64_t)co * HW + po[p]];
+                    res_r[m][p][r] = resn[(uint32_t)co * HW32 + (po[p] != ~0u ? po[p] : 0u)];
                 }
     };
     auto finish = [&]() {
-        unit_pixels(cur_u, st_po, st_ok, st_n);
+        unit_pixels(cur_u, st_po, st_n);
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < 2; ++p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = acc[m][p][r] * inv_scale + bias_r[m][r];
@@ -297,45 +343,49 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
                     if constexpr (HAS_RES) v += res_r[m][p][r];
                     ov[m][p][r] = v;
                     acc[m][p][r] = 0.0f;
+                    const float x = cbase + m * 16 + lg * 4 + r < a.cout_store ? v : 0.0f;
+                    _Float16 h, l;
+                    spk_split(x, h, l);
+                    ohi[m][p][r] = h; olo[m][p][r] = l;
                 }
+            }
     };
     auto store = [&]() {
-        float* outn = a.out_f32 ? a.out_f32 + (int64_t)st_n * a.cout_store * HW : nullptr;
-        unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)st_n * a.out_spk_bstride : nullptr;
+        if (a.out_f32) {
+            char* outn = reinterpret_cast<char*>(a.out_f32 + (int64_t)st_n * a.cout_store * HW);
+            const bool quads = !(a.cout_store & 3);                      // whole quads of channels: one predicate per 4 stores
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+            for (int p = 0; p < 2; ++p)
 #pragma unroll
-            for (int m = 0; m < NMT; ++m) {
-                const int co0 = cbase + m * 16 + lg * 4;
-                if (outn) {
-                    if (!(a.cout_store & 3)) {                       // whole quads of channels: one predicate per 4 stores
-                        if (co0 < a.cout_store && st_ok[p]) {
+                for (int m = 0; m < NMT; ++m) {
+                    const int co0 = cbase + m * 16 + lg * 4;
+                    const uint32_t off = ((uint32_t)co0 * HW32 + st_po[p]) * 4u;
+                    if (quads) {
+                        if (co0 < a.cout_store && st_po[p] != ~0u) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) outn[(int64_t)(co0 + r) * HW + st_po[p]] = ov[m][p][r];
+                            for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[m][p][r];
                         }
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (co0 + r < a.cout_store && st_ok[p]) outn[(int64_t)(co0 + r) * HW + st_po[p]] = ov[m][p][r];
+                            if (co0 + r < a.cout_store && st_po[p] != ~0u) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[m][p][r];
                     }
                 }
-                if (spkn) {
-                    const int go = co0 >> 3;
-                    h4 hi, lo;
+        }
+        if (a.out_spk) {
+            char* spkn = reinterpret_cast<char*>(a.out_spk) + (int64_t)st_n * a.out_spk_bstride;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = co0 + r < a.cout_store ? ov[m][p][r] : 0.0f;
-                        _Float16 h, l;
-                        spk_split(x, h, l);
-                        hi[r] = h; lo[r] = l;
-                    }
-                    if (go < gout && st_ok[p]) {
-                        unsigned char* q = spkn + ((int64_t)go * 2 * HW + st_po[p]) * 16 + (lg & 1) * 8;
-                        *reinterpret_cast<h4*>(q) = hi;
-                        *reinterpret_cast<h4*>(q + HW * 16) = lo;
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    const int go = (cbase + m * 16 + lg * 4) >> 3;
+                    if (go < gout && st_po[p] != ~0u) {
+                        const uint32_t off = ((uint32_t)go * 2u * HW32 + st_po[p]) * 16u + (uint32_t)(lg & 1) * 8u;
+                        *reinterpret_cast<h4*>(spkn + off) = ohi[m][p];
+                        *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo[m][p];
                     }
                 }
-            }
+        }
     };
 
     // ---- pipeline ----
@@ -346,19 +396,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
 #pragma unroll
         for (int j = 0; j < K_DMA; ++j) issue_fire(j, smem + st * Cfg::STAGE);
     }
+    if (early) issue_prepare();                        // iteration 0 fires the DMA of iteration 2
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0): both prologue stages have landed
     __builtin_amdgcn_s_barrier();
 
     int st_cur = 0, st_iss = 2;
     bool store_pending = false;
-    for (int g = 0; g < total; ++g) {
-#if !defined(SPK_ABLATE) || SPK_ABLATE != 7
-        if (store_pending) { store(); store_pending = false; }
+#ifdef SPK_STAMPS
+    unsigned long long ks_top = 0, ks_steps = 0, ks_fin = 0, ks_wait = 0, ks_bar = 0;
+    KSTAMP(k_begin)
 #endif
+    for (int g = 0; g < total; ++g) {
+        KSTAMP(k0)
         const bool last = cur_c == n_chunks - 1;       // workgroup-uniform
+        if (!early) {
+#if !defined(SPK_ABLATE) || SPK_ABLATE != 7
+            if (store_pending) { store(); store_pending = false; }
+#endif
+            issue_prepare();                           // addresses of iteration g+2's DMA (dummy fills past the end); the
+                                                       // K_DMA instructions themselves go between the MFMAs below
+        }
         if constexpr (HAS_RES) { if (last) residual_prefetch(); }
-        issue_prepare();                               // addresses of iteration g+2's DMA (dummy zero-block fills past the
-                                                       // end); the K_DMA instructions themselves go between the MFMAs below
         unsigned char* sdst = smem + st_iss * Cfg::STAGE;
         const unsigned char* sb = smem + st_cur * Cfg::STAGE;
         const unsigned char* win = sb + lane * 16;
@@ -383,6 +441,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
         };
         constexpr int N_MFMA = 2 * TERMS * NMT, N_DS = TERMS > 1 ? 4 + 2 * NMT : 2 + NMT;
         constexpr int N_TAIL = N_MFMA >= 12 ? 4 : (N_MFMA >= 6 ? 2 : 0);
+        KSTAMP(k1)
         ld(0, 0);
         __builtin_amdgcn_sched_barrier(0);                           // keep step 0's reads out of the interleave pattern below
 #pragma unroll
@@ -416,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
             // spread the next step's LDS reads evenly between this step's MFMAs
             spk_step_pattern<N_MFMA, N_DS, N_TAIL, K_DMA>(s);
         }
+        KSTAMP(k2)
         if (last) {
             finish();
             store_pending = true;
@@ -423,14 +483,34 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
         } else {
             ++cur_c;
         }
+        KSTAMP(k3)
         // Iteration g+1's DMA (issued one iteration ago) must have landed; this iteration's may stay in flight.  Loads
-        // retire in order, so "at most K_MIN of my vector-memory operations outstanding" implies it.
+        // retire in order, so "at most K_MIN of my vector-memory operations outstanding" implies it.  An early wave
+        // that has just stored a unit drains everything instead (it has ~1,500 idle cycles before the late waves arrive).
+        if (early) {
+#if !defined(SPK_ABLATE) || SPK_ABLATE != 7
+            if (store_pending) { store(); store_pending = false; __builtin_amdgcn_s_waitcnt(0x0F70); }
+#endif
+            issue_prepare();
+        }
         __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_MIN);
+        KSTAMP(k4)
         __builtin_amdgcn_s_barrier();
+        KSTAMP(k5)
+#ifdef SPK_STAMPS
+        ks_top += k1 - k0; ks_steps += k2 - k1; ks_fin += k3 - k2; ks_wait += k4 - k3; ks_bar += k5 - k4;
+#endif
         st_cur = st_cur == 2 ? 0 : st_cur + 1;
         st_iss = st_iss == 2 ? 0 : st_iss + 1;
     }
     if (store_pending) store();
+#ifdef SPK_STAMPS
+    KSTAMP(k_end)
+    if ((blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == 4) && lane == 0) {
+        unsigned long long* o = fldr_spk_stamp_buf + ((blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1)) * 8;
+        o[0] = ks_top; o[1] = ks_steps; o[2] = ks_fin; o[3] = ks_wait; o[4] = ks_bar; o[5] = total; o[6] = k_end - k_begin;
+    }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -586,6 +666,11 @@ static int spk_launch2(SpkArgs& a, int N, hipStream_t s) {
     a.wgs_per_xcd = a.units_per_xcd < g_spk_wgs_per_xcd ? a.units_per_xcd : g_spk_wgs_per_xcd;
     a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;                           // one output group per workgroup (bias kept in registers)
     if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
+    const int64_t dmax = a.n_tiles > a.groups ? a.n_tiles : a.groups;
+    if (((int64_t)a.n_units + 8 * a.units_per_xcd) * dmax >= (1ll << 32)) return FLDR_E_SHAPE;      // exactness of spk_div
+    a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
+    a.m_tiles = (uint32_t)((1ull << 32) / (uint32_t)a.n_tiles) + 1u;
+    a.m_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x) + 1u;
     hipLaunchKernelGGL((conv3x3_spk_kernel<NMT, TERMS, HAS_RES>), dim3(8 * a.wgs_per_xcd), dim3(512), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }
@@ -600,6 +685,7 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= SPK_MAX_GROUPS * 8 && d->cout > 0 && d->cout <= 96);
     FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->H > 0 && d->W > 0);
     FLDR_CHECK_ARG(!d->residual || d->out_f32);
+    if ((int64_t)d->cout_store * d->H * d->W * 4 >= (1ll << 32) || fldr_spk_bytes(96, d->H, d->W) >= (1ll << 32)) return FLDR_E_SHAPE;
     SpkArgs a;
     int gsum = 0, csum = 0;
     for (int s = 0; s < d->n_src; ++s) {
