@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ plan
     bool live = bx < BW && by < BH;
     double y[K];
     if (live) pca_block<K>(planes + (int64_t)p * H * W, W, bx, by, ev, mean, mv, y);
-    if (PASS == 0) {
+    if (PASS == 0 || PASS == 2) {
         double lo = 1.0e300, hi = -1.0e300;
         if (live) {
 #pragma unroll
@@ -90,6 +90,12 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ plan
             atomic_min_f64(mm, lo);
             atomic_max_f64(mm + 1, hi);
         }
+        if (PASS == 2 && live) {                                        // raw projections for pca_rescale_kernel
+            const int64_t BHW = (int64_t)BH * BW;
+            const int64_t o = ((int64_t)p * K) * BHW + (int64_t)by * BW + bx;
+#pragma unroll
+            for (int k = 0; k < K; ++k) out64[o + (int64_t)k * BHW] = y[k];
+        }
     } else {
 #pragma clang fp contract(off)
         if (!live) return;
@@ -105,6 +111,59 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ plan
     }
 }
 
+// Second pass when the caller provides the fp64 output buffer: pass 0 leaves the raw projections y there and this
+// kernel rescales them in place (pca_comp.py:521-526) and emits the fp32 cast (fLDRnet.py:146) and, optionally, the
+// split-packed twin the convolutions consume — a pure stream (8 B in, 8 + 4 [+ 4] B out per value) instead of a second
+// projection of the input planes.  The arithmetic on y is the one pass 1 applies, so results are identical.
+// One thread = one feature-map pixel x 8 consecutive channels (one split-packed group).
+__global__ __launch_bounds__(256) void pca_rescale_kernel(double* __restrict__ y64, const double* __restrict__ mm,
+                                                          float* __restrict__ out32, unsigned char* __restrict__ spk,
+                                                          int C, int64_t BHW) {
+#pragma clang fp contract(off)
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y;
+    if (pix >= BHW) return;
+    const double mi = mm[0], range = mm[1] - mm[0];
+    float f[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = g * 8 + k;
+        f[k] = 0.0f;
+        if (c < C) {
+            const int64_t o = (int64_t)c * BHW + pix;
+            const double v = ((y64[o] - mi) / range) * 2.0 - 1.0;
+            y64[o] = v;
+            f[k] = (float)v;
+            if (out32) out32[o] = f[k];
+        }
+    }
+    if (spk) {
+        typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+        h8 hi, lo;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float t = __uint_as_float(__float_as_uint(f[k]) & 0xFFFFE000u);      // the split of conv_spk_kernels.hip
+            hi[k] = (_Float16)t;
+            lo[k] = (_Float16)(f[k] - t);
+        }
+        unsigned char* d = spk + ((int64_t)g * 2 * BHW + pix) * 16;
+        *reinterpret_cast<h8*>(d) = hi;
+        *reinterpret_cast<h8*>(d + BHW * 16) = lo;
+    }
+}
+
+template <int K>
+static void pca_launch_stream(const float* planes, const double* ev, const double* mean, const double* mv, float* o32,
+                              double* o64, void* spk, double* mm, int P, int H, int W, hipStream_t s) {
+    dim3 grid(fldr_cdiv(W / 8, 64), fldr_cdiv(H / 8, 4), P);
+    hipLaunchKernelGGL(pca_init_minmax, dim3(1), dim3(1), 0, s, mm);
+    hipLaunchKernelGGL((pca_kernel<K, 2>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, (float*)nullptr, o64, H, W);
+    const int64_t BHW = (int64_t)(H / 8) * (W / 8);
+    const int C = P * K;
+    hipLaunchKernelGGL(pca_rescale_kernel, dim3(fldr_cdiv(BHW, 256), (C + 7) / 8), dim3(256), 0, s, o64, mm, o32,
+                       reinterpret_cast<unsigned char*>(spk), C, BHW);
+}
+
 template <int K>
 static void pca_launch(const float* planes, const double* ev, const double* mean, const double* mv, float* o32, double* o64,
                        double* mm, int P, int H, int W, hipStream_t s) {
@@ -112,6 +171,24 @@ static void pca_launch(const float* planes, const double* ev, const double* mean
     hipLaunchKernelGGL(pca_init_minmax, dim3(1), dim3(1), 0, s, mm);
     hipLaunchKernelGGL((pca_kernel<K, 0>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W);
     hipLaunchKernelGGL((pca_kernel<K, 1>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W);
+}
+
+// fldr_pca_project with the fp64 output buffer as the intermediate (one projection instead of two) and an optional
+// split-packed twin of the fp32 output (fldr_spk_bytes(P*K, H/8, W/8) bytes) for the convolutions that follow.
+extern "C" int fldr_pca_project_stream(const float* planes, const double* ev, const double* mean, const double* meanvec,
+                                       float* out_f32_or_null, double* out_f64, void* out_spk_or_null, double* minmax_ws,
+                                       int P, int K, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(planes && ev && mean && meanvec && minmax_ws && out_f64 && P > 0 && H > 0 && W > 0);
+    if (H % 8 != 0 || W % 8 != 0) return FLDR_E_SHAPE;
+    if (((uintptr_t)planes & 15) != 0) return FLDR_E_ARG;
+    hipStream_t s = fldr_s(stream);
+    switch (K) {
+        case 16: pca_launch_stream<16>(planes, ev, mean, meanvec, out_f32_or_null, out_f64, out_spk_or_null, minmax_ws, P, H, W, s); break;
+        case 8:  pca_launch_stream<8>(planes, ev, mean, meanvec, out_f32_or_null, out_f64, out_spk_or_null, minmax_ws, P, H, W, s); break;
+        case 4:  pca_launch_stream<4>(planes, ev, mean, meanvec, out_f32_or_null, out_f64, out_spk_or_null, minmax_ws, P, H, W, s); break;
+        default: return FLDR_E_ARG;
+    }
+    FLDR_LAUNCH_RET();
 }
 
 extern "C" int fldr_pca_project(const float* planes, const double* ev, const double* mean, const double* meanvec,

@@ -109,14 +109,14 @@ class DCTXVFInet(nn.Module):
         """rec_ctx_ds(x) + x  (fLDRnet.py:44-49,162): two fused conv kernels."""
         return self._extract_features(pca)[0]
 
-    def _extract_features(self, pca):
+    def _extract_features(self, pca, pca_spk=None):
         """-> (features fp32 NCHW, the same features split-packed or None).  The intermediate activation only exists
         split-packed; the result is written in both layouts by one kernel (fp32 for the splats, packed for conv_flow1)."""
         c0, c2 = self.rec_ctx_ds[0], self.rec_ctx_ds[2]
         if not fldr_hip.use_spk():
             y = fldr_hip.conv2d([pca], c0.weight, c0.bias, relu=True)
             return fldr_hip.conv2d([y], c2.weight, c2.bias, relu=True, residual=pca), None
-        y = fldr_hip.conv2d_spk([pca], c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
+        y = fldr_hip.conv2d_spk([pca if pca_spk is None else pca_spk], c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
         return fldr_hip.conv2d_spk([y], c2.weight, c2.bias, relu=True, residual=pca, want_f32=True, want_spk=True)
 
     def forward(self, input_gpuList, t_value, normInput=0, is_training=True, validation=False, epoch=0, frameT=None):
@@ -138,9 +138,15 @@ class DCTXVFInet(nn.Module):
             feats = []
             for i in range(n_levels):
                 B, _, _, h, w = x_l[i].shape
+                spk = fldr_hip.use_spk()
                 pca = to_pca_diff_f32(x_l[i].reshape(B * 6, h, w), self.params[i], a, self.pca_means[i8], self.EVs[i8],
-                                      self.mean_vecs[i8]).view(B, a.dctvfi_nf * 6, h // 8, w // 8)  # :146
-                feats.append(self._extract_features(pca) if a.ref_feat_extrac else (pca, None))
+                                      self.mean_vecs[i8], want_spk=spk)                              # :146
+                pca_p = None
+                if spk:                                   # [1, 96B, h, w] packed == [B, 96, h, w] packed (12 whole groups per sample)
+                    pca, pca_p = pca
+                    pca_p = fldr_hip.Spk(pca_p.buf, (B, a.dctvfi_nf * 6, h // 8, w // 8))
+                pca = pca.view(B, a.dctvfi_nf * 6, h // 8, w // 8)
+                feats.append(self._extract_features(pca, pca_p) if a.ref_feat_extrac else (pca, pca_p))
             flow = None
             for level in range(a.S_tst, -1, -1):                                                       # :210-218
                 flow = self.vfinet.estimate_flow(feats[level], flow)

@@ -57,8 +57,11 @@ _SIGNATURES = {
     "fldr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "fldr_softsplat_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_softsplat_fused": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_pca_project_stream": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "fldr_resize_bilinear": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
@@ -149,13 +152,29 @@ def softsplat_fwd(inp, flow):
 _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 
 
-def softsplat_fused(img, flow, metric, mode, out=None, scratch=None):
+# "strip": the global-atomic strip scatter + normalisation pass (default);
+# "tile": destination-owned tiles accumulated in LDS (no global atomics, no accumulator tensor).  Exact, but slower on
+# gfx950: ds_add_f32 retires one wave-instruction per ~190 cycles per CU (tools/ubench/lds_atomic_bench.hip; the
+# integer ds_add_u32 takes 4), i.e. LDS float atomics are slower than the memory-side ones the strip kernel uses.
+SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "strip")
+
+
+def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None):
     """FunctionSoftsplat (softSplat.py:320-352)."""
     N, C, H, W = img.shape
     assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W
     img, flow = img.contiguous(), flow.contiguous()
     if metric is not None:
         metric = metric.contiguous()
+    if (kernel or SPLAT_KERNEL) == "tile":
+        ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
+        _check(lib().fldr_softsplat_tile(_dev(img, "img"), _dev(flow, "flow"),
+                                         _dev(metric, "metric") if metric is not None else None,
+                                         _dev(out, "out"), _dev(ws, "ws"), N, C, H, W, _MODES[mode], _stream()),
+               "fldr_softsplat_tile")
+        return out
     ca = C + (0 if mode == "summation" else 1)
     if scratch is None:
         scratch = torch.empty(N * ca * H * W, device=img.device, dtype=torch.float32)
@@ -193,6 +212,26 @@ def pca_project(planes, ev, mean, meanvec, want_f64=False, want_f32=True):
         raise Exception("in to_pca_diff the image is not padded right." + str(H) + " " + str(W))   # pca_comp.py:487
     _check(code, "fldr_pca_project")
     return o32, o64, mm
+
+
+def pca_project_stream(planes, ev, mean, meanvec, want_spk=False):
+    """One-pass projection: -> (fp32 [P*K,h,w], fp64 [P*K,h,w], minmax, Spk of shape [1,P*K,h,w] or None)."""
+    P, H, W = planes.shape
+    K = ev.shape[0]
+    planes = planes.contiguous()
+    h, w = H // 8, W // 8
+    o32 = torch.empty(P * K, h, w, device=planes.device, dtype=torch.float32)
+    o64 = torch.empty(P * K, h, w, device=planes.device, dtype=torch.float64)
+    mm = torch.empty(2, device=planes.device, dtype=torch.float64)
+    spk = _spk_alloc(1, P * K, h, w, planes.device) if want_spk else None
+    code = lib().fldr_pca_project_stream(_dev(planes, "planes"), _dev(ev, "EV", torch.float64), _dev(mean, "mean", torch.float64),
+                                         _dev(meanvec, "mean_vec", torch.float64), _dev(o32, "out"), _dev(o64, "out64", torch.float64),
+                                         ctypes.c_void_p(spk.buf.data_ptr()) if want_spk else None,
+                                         _dev(mm, "minmax", torch.float64), P, K, H, W, _stream())
+    if code == -2:
+        raise Exception("in to_pca_diff the image is not padded right." + str(H) + " " + str(W))   # pca_comp.py:487
+    _check(code, "fldr_pca_project_stream")
+    return o32, o64, mm, spk
 
 
 def bwarp(x, flo, withmask=True):

@@ -33,8 +33,11 @@ def to_pca_diff(im, params, args, mean, EV, mean_vec):
     return o64
 
 
-def to_pca_diff_f32(im, params, args, mean, EV, mean_vec):
-    """Same projection, emitting directly the fp32 cast the model applies right after (fLDRnet.py:146)."""
+def to_pca_diff_f32(im, params, args, mean, EV, mean_vec, want_spk=False):
+    """Same projection, emitting directly the fp32 cast the model applies right after (fLDRnet.py:146): one pass over
+    the planes (raw fp64 projections parked in a scratch buffer, rescaled by a streaming kernel).  With want_spk the
+    split-packed twin the convolutions consume comes out of the same kernel: -> (fp32, fldr_hip.Spk [1, P*K, h, w])."""
     k = _check(im, params, args, mean_vec)
-    o32, _, _ = fldr_hip.pca_project(im, EV.detach()[:k].contiguous(), mean.detach(), mean_vec.detach()[:k].contiguous())
-    return o32
+    o32, _, _, spk = fldr_hip.pca_project_stream(im, EV.detach()[:k].contiguous(), mean.detach(),
+                                                 mean_vec.detach()[:k].contiguous(), want_spk=want_spk)
+    return (o32, spk) if want_spk else o32

@@ -52,6 +52,16 @@ int fldr_softsplat_fused(const float* img, const float* flow, const float* metri
                          float* out, float* scratch, int N, int C, int H, int W, int mode,
                          fldr_stream_t stream);
 
+/* The same operator with destination-owned tiles (csrc/splat_tile_kernels.hip): each workgroup owns an output tile,
+ * accumulates the sources that reach it with LDS atomics and writes the normalised tile once — no global atomics, no
+ * accumulator tensor, no normalisation pass; exact for arbitrary flows (flow bounds per 64x4 block and 256x64
+ * super-block select the candidate sources; a full scan is the fallback).  ws: fldr_softsplat_tile_ws_floats(N,H,W)
+ * floats of workspace.  Results equal fldr_softsplat_fused up to fp32 summation order (the reference's own atomics are
+ * unordered). */
+int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W);
+int fldr_softsplat_tile(const float* img, const float* flow, const float* metric_or_null, float* out, float* ws,
+                        int N, int C, int H, int W, int mode, fldr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * PWC cost volume — replaces OpticalFlow/correlation.py (forward only).
  * ------------------------------------------------------------------------------------------ */
@@ -76,6 +86,13 @@ int fldr_correlation_fwd(const float* a, const float* b, float* out,
 int fldr_pca_project(const float* planes, const double* ev, const double* mean, const double* meanvec,
                      float* out_f32, double* out_f64_or_null, double* minmax_ws,
                      int P, int K, int H, int W, fldr_stream_t stream);
+
+/* The same projection with ONE pass over the planes: the raw fp64 projections are parked in out_f64 (required) and
+ * rescaled in place by a streaming kernel that also emits the fp32 cast and, when out_spk is given, its split-packed
+ * twin (fldr_spk_bytes(P*K, H/8, W/8) bytes; see the convolution section).  Identical results. */
+int fldr_pca_project_stream(const float* planes, const double* ev, const double* mean, const double* meanvec,
+                            float* out_f32_or_null, double* out_f64, void* out_spk_or_null, double* minmax_ws,
+                            int P, int K, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Gathers and resizes — replace DCTVFInet.bwarp and the F.interpolate calls of fLDRnet.py.

@@ -80,6 +80,62 @@ def test_function_softsplat_modes(hip, oracle, dev, mode):
         _cmp(out, oracle.function_softsplat(x, flow, None, mode), atol=3e-5, what="softmax no metric")
 
 
+def test_pca_stream_equals_two_pass(hip, dev, model):
+    """One-pass projection (raw fp64 parked, streaming rescale) == two-pass kernel bit for bit; its split-packed twin ==
+    fldr_spk_pack of the fp32 output."""
+    m, _ = model
+    g = _gen(5)
+    pl = (torch.rand(12, 72, 136, generator=g) * 2 - 1).to(dev)
+    o32, o64, mm = hip.pca_project(pl, m.EV8.detach(), m.Mean8.detach(), m.meanVec8.detach(), want_f64=True)
+    s32, s64, smm, spk = hip.pca_project_stream(pl, m.EV8.detach(), m.Mean8.detach(), m.meanVec8.detach(), want_spk=True)
+    assert torch.equal(o32, s32) and torch.equal(o64, s64) and torch.equal(mm, smm)
+    assert torch.equal(hip.spk_pack(o32.view(1, 192, 9, 17)).buf, spk.buf)
+
+
+@pytest.mark.parametrize("shape", [(1, [96], [0], 96, None, 9, 15, True, True), (2, [96], [0], 48, None, 20, 37, True, False),
+                                   (1, [48, 48, 4], [0, 0, 0], 96, None, 36, 60, True, False), (1, [48], [0], 6, 4, 9, 15, False, False),
+                                   (1, [64, 32], [1, 0], 32, None, 24, 40, True, False), (1, [32, 16], [1, 0], 16, None, 48, 80, True, False),
+                                   (1, [96], [0], 96, None, 72, 120, True, True)])
+def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape):
+    """The persistent split-packed convolution (fldr_conv2d_spk) against the register-staged split convolution
+    (fldr_conv2d_split): same hi/lo split, same MFMA order => bit-identical fp32 output; its packed output equals
+    fldr_spk_pack of that output; a chain through the packed tensor equals the chain through fp32."""
+    N, cs, ups, cout, cst, H, W, relu, res = shape
+    g = _gen(21)
+    srcs = [torch.randn(N, c, H // (2 if u else 1), W // (2 if u else 1), generator=g).to(dev) for c, u in zip(cs, ups)]
+    wt = (torch.randn(cout, sum(cs), 3, 3, generator=g) / 20).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    rs = torch.randn(N, cst or cout, H, W, generator=g).to(dev) if res else None
+    up2 = [bool(u) for u in ups]
+    ref = hip.conv2d(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=up2, precision="split")
+    got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=up2, want_f32=True, want_spk=True)
+    assert torch.equal(ref, got)
+    assert torch.equal(hip.spk_pack(ref).buf, gp.buf)
+    if len(cs) == 1 and cst is None and cout % 8 == 0:
+        w2 = (torch.randn(48, cout, 3, 3, generator=g) / 20).to(dev)
+        assert torch.equal(hip.conv2d([ref], w2, None, precision="split"), hip.conv2d_spk([gp], w2, None))
+        half = cout // 2
+        if half % 8 == 0:                                  # channel views of a packed tensor (feat[:, :48] / feat[:, 48:])
+            w3 = (torch.randn(16, half, 3, 3, generator=g) / 20).to(dev)
+            assert torch.equal(hip.conv2d([ref[:, half:]], w3, None, precision="split"), hip.conv2d_spk([gp.narrow(half, half)], w3, None))
+
+
+@pytest.mark.parametrize("mode", ["summation", "average", "linear", "softmax"])
+@pytest.mark.parametrize("shape", [(2, 4, 33, 70, 9.0), (1, 3, 70, 300, 40.0), (1, 13, 40, 130, 600.0)])
+def test_tile_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
+    """The destination-owned (LDS tile) splat, opt-in via FLDR_SPLAT=tile: the same operator without global atomics.
+    Flows range from coherent to wild (600 px: every tile falls back to the full block scan or the queue path)."""
+    N, C, H, W, amp = shape
+    g = _gen(11)
+    x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+    flow = (torch.rand(N, 2, H, W, generator=g) - 0.5) * amp
+    z = torch.randn(N, 1, H, W, generator=g) if mode in ("linear", "softmax") else None
+    if mode == "linear":
+        z = z.abs() + 0.1
+    out = hip.softsplat_fused(x.to(dev), flow.to(dev), None if z is None else z.to(dev), mode, kernel="tile")
+    _cmp(out, oracle.function_softsplat(x, flow, z, mode), atol=3e-5, rtol=1e-5, what="tile " + mode)
+
+
 def test_splat_known_answers(hip, dev):
     import softSplat
     sp = softSplat.Softsplat()
