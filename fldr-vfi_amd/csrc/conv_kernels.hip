@@ -45,7 +45,8 @@ struct ConvArgs {
     const float* wpack;
     const float* bias;
     const float* residual;
-    float* out;
+    float* out;                // fp32 NCHW output or null
+    unsigned char* out_spk;    // split-packed output (conv_spk_kernels.hip) or null
     int32_t cin, cout, cout_store;
     int32_t Hin, Win, Hout, Wout;
     int32_t relu;
@@ -271,7 +272,8 @@ __global__ __launch_bounds__(256, (MT == 16 && NMT == 3) ? 3 : 2) void conv_mfma
     // All bias / residual loads are issued first (clamped addresses, no branches), then combined and stored.
     constexpr int NR = MT == 32 ? 16 : 4;
     const int64_t HWo = (int64_t)a.Hout * a.Wout;
-    float* outn = a.out + (int64_t)n * a.cout_store * HWo;
+    float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
+    unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
     const float* resn = a.residual ? a.residual + (int64_t)n * a.cout_store * HWo : nullptr;
     float bias_r[NMT][NR];
 #pragma unroll
@@ -315,13 +317,37 @@ __global__ __launch_bounds__(256, (MT == 16 && NMT == 3) ? 3 : 2) void conv_mfma
         }
 #pragma unroll
         for (int m = 0; m < NMT; ++m) {
+            float vv[NR];
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
                 const int co = cbase + (MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r);
                 float v = acc[m][p][r] + bias_r[m][r];
                 if (a.relu) v = fmaxf(v, 0.0f);
                 v += res_r[m][r];
-                if (co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+                vv[r] = v;
+                if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+            }
+            if (spkn) {
+                // registers r0..r0+3 are four consecutive channels = half of a split-packed group: one 8-byte store of
+                // the hi halves and one of the lo halves (the same split as conv_spk_kernels.hip)
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int r0 = 0; r0 < NR; r0 += 4) {
+                    const int co0 = cbase + (MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4);
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                        const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+                        hi[r] = (_Float16)t;
+                        lo[r] = (_Float16)(x - t);
+                    }
+                    if (co0 < a.cout_store && pix_ok) {
+                        unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
+                        *reinterpret_cast<h4*>(q) = hi;
+                        *reinterpret_cast<h4*>(q + HWo * 16) = lo;
+                    }
+                }
             }
         }
     }
@@ -400,7 +426,8 @@ static int conv_launch(const ConvArgs& a, int N, hipStream_t s) {
 }
 
 extern "C" int fldr_conv2d(const fldr_conv_desc* d, fldr_stream_t stream) {
-    FLDR_CHECK_ARG(d && d->wpack && d->out && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
+    FLDR_CHECK_ARG(d && d->wpack && (d->out || d->out_spk) && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
+    FLDR_CHECK_ARG(!d->residual || d->out);
     FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cout > 0 && d->cout <= 96 && d->cout_store > 0 && d->cout_store <= d->cout);
     FLDR_CHECK_ARG((d->ksize == 3 && d->stride == 1) || (d->ksize == 4 && d->stride == 2));
     FLDR_CHECK_ARG(d->Hin > 0 && d->Win > 0);
@@ -426,6 +453,7 @@ extern "C" int fldr_conv2d(const fldr_conv_desc* d, fldr_stream_t stream) {
     if (csum != d->cin) return FLDR_E_SHAPE;
     a.n_src = d->n_src;
     a.wpack = d->wpack; a.bias = d->bias; a.residual = d->residual; a.out = d->out;
+    a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
     a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
     a.Hin = d->Hin; a.Win = d->Win; a.Hout = d->Hout; a.Wout = d->Wout; a.relu = d->relu; a.tiles_x = 0;
     hipStream_t s = fldr_s(stream);

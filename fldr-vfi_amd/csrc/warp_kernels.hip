@@ -208,6 +208,40 @@ __global__ __launch_bounds__(256) void splat_finish_kernel(const float* __restri
     }
 }
 
+// The same normalisation writing the split-packed layout the convolutions consume (conv_spk_kernels.hip) instead of
+// fp32 NCHW: thread = one pixel x 8 consecutive channels.
+template <bool NORMALISE>
+__global__ __launch_bounds__(256) void splat_finish_spk_kernel(const float* __restrict__ acc, unsigned char* __restrict__ out,
+                                                               int C, int64_t HW) {
+#pragma clang fp contract(off)
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int g = blockIdx.y, n = blockIdx.z;
+    if (i >= HW) return;
+    const int CA = NORMALISE ? C + 1 : C;
+    const int G = (C + 7) >> 3;
+    const float* a = acc + (int64_t)n * CA * HW + i;
+    float norm = 1.0f;
+    if (NORMALISE) { norm = a[(int64_t)C * HW]; if (norm == 0.0f) norm = 1.0f; }
+    h8 hi, lo;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = g * 8 + k;
+        float v = 0.0f;
+        if (c < C) {
+            v = a[(int64_t)c * HW];
+            if (NORMALISE) v = v / norm;
+            v = (v - 0.5f) * 2.0f;
+        }
+        const float t = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
+        hi[k] = (_Float16)t;
+        lo[k] = (_Float16)(v - t);
+    }
+    unsigned char* d = out + (((int64_t)n * G + g) * 2 * HW + i) * 16;
+    *reinterpret_cast<h8*>(d) = hi;
+    *reinterpret_cast<h8*>(d + HW * 16) = lo;
+}
+
 extern "C" int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
                                   int N, int C, int H, int W, fldr_stream_t stream) {
     FLDR_CHECK_ARG(in && flow && out_zeroed && N > 0 && C > 0 && H > 0 && W > 0);
@@ -232,6 +266,28 @@ extern "C" int fldr_softsplat_fused(const float* img, const float* flow, const f
     dim3 g2(fldr_cdiv(HW, 256), N);
     if (mode == 0) hipLaunchKernelGGL(splat_finish_kernel<false>, g2, dim3(256), 0, fldr_s(stream), scratch, out, C, HW);
     else           hipLaunchKernelGGL(splat_finish_kernel<true>, g2, dim3(256), 0, fldr_s(stream), scratch, out, C, HW);
+    FLDR_LAUNCH_RET();
+}
+
+// fldr_softsplat_fused with a split-packed result (no fp32 tensor is written): the warped features feed conv_flow1 only.
+extern "C" int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric, void* out_spk, float* scratch,
+                                        int N, int C, int H, int W, int mode, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(img && flow && out_spk && scratch && N > 0 && C > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 3);
+    FLDR_CHECK_ARG(mode != 2 || metric != nullptr);
+    const int64_t HW = (int64_t)H * W;
+    const int CA = mode >= 1 ? C + 1 : C;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)N * CA * HW, fldr_s(stream));
+    if (e != hipSuccess) return (int)e;
+    switch (mode) {
+        case 0: splat_launch<0>(img, flow, metric, scratch, N, C, H, W, fldr_s(stream)); break;
+        case 1: splat_launch<1>(img, flow, metric, scratch, N, C, H, W, fldr_s(stream)); break;
+        case 2: splat_launch<2>(img, flow, metric, scratch, N, C, H, W, fldr_s(stream)); break;
+        default: splat_launch<3>(img, flow, metric, scratch, N, C, H, W, fldr_s(stream)); break;
+    }
+    dim3 g2(fldr_cdiv(HW, 256), (C + 7) / 8, N);
+    unsigned char* o = reinterpret_cast<unsigned char*>(out_spk);
+    if (mode == 0) hipLaunchKernelGGL(splat_finish_spk_kernel<false>, g2, dim3(256), 0, fldr_s(stream), scratch, o, C, HW);
+    else           hipLaunchKernelGGL(splat_finish_spk_kernel<true>, g2, dim3(256), 0, fldr_s(stream), scratch, o, C, HW);
     FLDR_LAUNCH_RET();
 }
 

@@ -233,9 +233,13 @@ class DCTVFInet(nn.Module):
             flow_l = self._chain([feat_p if spk else feat_x], self.conv_flow_bottom, (0, 2, 4, 6, 8), final_store=4)   # :379-380
         else:
             up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])             # :384-385
-            w1 = self.softsplat(feat1, up[:, :2])                                                      # :386
-            w0 = self.softsplat(feat0, up[:, 2:])                                                      # :387
             f1 = self.conv_flow1
+            if spk:                                                    # the warped features only feed conv_flow1: split-packed
+                w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True)        # :386
+                w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True)        # :387
+            else:
+                w1 = self.softsplat(feat1, up[:, :2])                                                  # :386
+                w0 = self.softsplat(feat0, up[:, 2:])                                                  # :387
             if spk:
                 ca = fldr_hip.conv2d_spk([feat_p.narrow(0, half), w1], f1.weight, f1.bias, want_f32=False, want_spk=True)
                 cb = fldr_hip.conv2d_spk([feat_p.narrow(half, half), w0], f1.weight, f1.bias, want_f32=False, want_spk=True)
@@ -336,14 +340,19 @@ class PCARefineUNet(nn.Module):
         """Everything up to and including dec2 + ReLU (fLDRnet.py:621-640), at half resolution."""
         srcs = list(concat) if isinstance(concat, (list, tuple)) else [concat]
         cv = fldr_hip.conv2d
+        if fldr_hip.use_spk():
+            # the encoders (exact fp32-MFMA stride-2 kernels) emit the split-packed twins the decoder reads; decoder
+            # activations only exist split-packed
+            cs = fldr_hip.conv2d_spk
+            enc1, enc1p = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True, want_spk=True)
+            enc2, enc2p = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True, want_spk=True)
+            out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)
+            out = cs([out], self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
+            out = cs([out, enc2p], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
+            return cs([out, enc1p], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])
         enc1 = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True)
         enc2 = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True)
         out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True)
-        if fldr_hip.use_spk():                                        # decoder activations stay split-packed
-            cs = fldr_hip.conv2d_spk
-            out = cs([out], self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
-            out = cs([out, enc2], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
-            return cs([out, enc1], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])
         out = cv([out], self.dec0.weight, self.dec0.bias, relu=True)
         out = cv([out, enc2], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False])     # NN + cat (:632-634)
         return cv([out, enc1], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])    # :638-640

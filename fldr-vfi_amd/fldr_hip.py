@@ -32,6 +32,7 @@ class ConvDesc(ctypes.Structure):
         ("N", ctypes.c_int32), ("cin", ctypes.c_int32), ("cout", ctypes.c_int32), ("cout_store", ctypes.c_int32),
         ("Hin", ctypes.c_int32), ("Win", ctypes.c_int32), ("Hout", ctypes.c_int32), ("Wout", ctypes.c_int32),
         ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
+        ("out_spk", ctypes.c_void_p),
     ]
 
 
@@ -57,6 +58,7 @@ _SIGNATURES = {
     "fldr_error_string": (ctypes.c_char_p, [ctypes.c_int]),
     "fldr_softsplat_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_softsplat_fused": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_softsplat_fused_spk": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -79,6 +81,7 @@ _SIGNATURES = {
     "fldr_conv_spk_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_spk": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_void_p]),
     "fldr_debug_spk_wgs_per_xcd": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_sizeof_desc": (ctypes.c_int, [ctypes.c_int]),
     "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_dec3_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
@@ -159,13 +162,22 @@ _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "strip")
 
 
-def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None):
-    """FunctionSoftsplat (softSplat.py:320-352)."""
+def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False):
+    """FunctionSoftsplat (softSplat.py:320-352).  want_spk: return the result split-packed (Spk) instead of fp32 NCHW."""
     N, C, H, W = img.shape
     assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W
     img, flow = img.contiguous(), flow.contiguous()
     if metric is not None:
         metric = metric.contiguous()
+    if want_spk:
+        ca = C + (0 if mode == "summation" else 1)
+        scratch = torch.empty(N * ca * H * W, device=img.device, dtype=torch.float32)
+        outp = _spk_alloc(N, C, H, W, img.device)
+        _check(lib().fldr_softsplat_fused_spk(_dev(img, "img"), _dev(flow, "flow"),
+                                              _dev(metric, "metric") if metric is not None else None,
+                                              ctypes.c_void_p(outp.buf.data_ptr()), _dev(scratch, "scratch"), N, C, H, W,
+                                              _MODES[mode], _stream()), "fldr_softsplat_fused_spk")
+        return outp
     if (kernel or SPLAT_KERNEL) == "tile":
         ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
         if out is None:
@@ -321,8 +333,11 @@ def conv_split_prepack(weight):
     return wp
 
 
-def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=None, up2=None, out=None, precision=None):
+def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=None, up2=None, out=None, precision=None,
+           want_f32=True, want_spk=False):
     """conv(cat(srcs, 1)) with optional fused nearest-x2 read per source, ReLU and post-activation residual.
+    want_spk (exact fp32-MFMA kernels only, i.e. the stride-2 encoders): also / only emit the split-packed twin of the
+    output for a following conv2d_spk; returns fp32, Spk or (fp32, Spk) like conv2d_spk.
 
     srcs: list of [N,c_s,H_s,W_s] fp32 tensors whose (N, c, h, w) block may be a batch-strided view
     (e.g. feat[:, :48]) as long as each sample's [c,h,w] block is contiguous."""
@@ -357,12 +372,16 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     else:
         raise FldrError("unsupported convolution k=%d stride=%d" % (k, stride))
     cs = cout if cout_store is None else cout_store
-    if out is None:
-        out = torch.empty(N, cs, Hout, Wout, device=srcs[0].device, dtype=torch.float32)
     prec = precision or CONV_PRECISION
     if prec not in ("split", "fp32", "fp16"):
         raise ValueError("precision must be split, fp32 or fp16")
     split = prec in ("split", "fp16") and k == 3 and stride == 1
+    if want_spk and split:
+        raise FldrError("a split-packed output of a 3x3 stride-1 convolution comes from conv2d_spk")
+    want_f32 = want_f32 or not want_spk or residual is not None
+    outp = _spk_alloc(N, cs, Hout, Wout, srcs[0].device) if want_spk else None
+    if out is None and want_f32:
+        out = torch.empty(N, cs, Hout, Wout, device=srcs[0].device, dtype=torch.float32)
     wp = conv_split_prepack(weight) if split else conv_prepack(weight)
     d.wpack = wp.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -370,7 +389,8 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
         residual = residual.contiguous()
         assert residual.shape == out.shape
         d.residual = residual.data_ptr()
-    d.out = _dev(out, "out").value
+    d.out = _dev(out, "out").value if out is not None else None
+    d.out_spk = outp.buf.data_ptr() if outp is not None else None
     d.N, d.cin, d.cout, d.cout_store = N, cin, cout, cs
     d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
     d.ksize, d.stride, d.relu, d.precision = k, stride, int(bool(relu)), (1 if (split and prec == "fp16") else 0)
@@ -378,6 +398,8 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
         _check(lib().fldr_conv2d_split(ctypes.byref(d), _stream()), "fldr_conv2d_split")
     else:
         _check(lib().fldr_conv2d(ctypes.byref(d), _stream()), "fldr_conv2d")
+    if want_spk:
+        return (out, outp) if out is not None else outp
     return out
 
 

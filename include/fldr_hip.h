@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define FLDR_VERSION 100          /* major*10000 + minor*100 + patch */
+#define FLDR_VERSION 101          /* major*10000 + minor*100 + patch */
 
 #define FLDR_E_ARG   (-1)         /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define FLDR_E_SHAPE (-2)         /* shape constraint violated (e.g. H,W not multiples of 8 for the PCA) */
@@ -51,6 +51,11 @@ int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
 int fldr_softsplat_fused(const float* img, const float* flow, const float* metric_or_null,
                          float* out, float* scratch, int N, int C, int H, int W, int mode,
                          fldr_stream_t stream);
+
+/* fldr_softsplat_fused with the result in the split-packed layout of the convolution section (fldr_spk_bytes(C,H,W) bytes
+ * per sample) instead of fp32 NCHW: the warped feature maps of fLDRnet.py:386-387 are read by conv_flow1 only. */
+int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric_or_null, void* out_spk,
+                             float* scratch, int N, int C, int H, int W, int mode, fldr_stream_t stream);
 
 /* The same operator with destination-owned tiles (csrc/splat_tile_kernels.hip): each workgroup owns an output tile,
  * accumulates the sources that reach it with LDS atomics and writes the normalised tile once — no global atomics, no
@@ -148,6 +153,8 @@ typedef struct fldr_conv_desc {
     int32_t stride;
     int32_t relu;
     int32_t precision;         /* 0: fp32 MFMA (exact fp32 products, default); 1: fp16 inputs, fp32 accumulate */
+    void*   out_spk;           /* fldr_conv2d only: optional split-packed twin of the output (fldr_spk_* below; the layout
+                                  the 3x3 convolutions consume); `out` may then be NULL.  NULL for fldr_conv2d_split. */
 } fldr_conv_desc;
 
 /* Number of floats fldr_conv_prepack writes for a [cout,cin,k,k] weight. */
@@ -193,6 +200,7 @@ int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fld
 int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
 int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
+int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: sizeof(fldr_spk_conv_desc) — binding self-check */
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 
 /* ------------------------------------------------------------------------------------------

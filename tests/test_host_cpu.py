@@ -22,14 +22,17 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libfldr_hip.so does not export " + name
     assert declared == set(fldr_hip.EXPORTS), (declared ^ set(fldr_hip.EXPORTS))
-    assert fldr_hip.lib().fldr_version() == 100
+    assert fldr_hip.lib().fldr_version() == 101
     assert fldr_hip.lib().fldr_error_string(-2) == b"fldr: shape constraint violated"
 
 
 def test_conv_desc_layout_matches_header():
     import fldr_hip
-    # 12 ptr + 12 i64 + 12 i32 + 12 i32 + i32 (+pad) + 4 ptr + 12 i32
-    assert ctypes.sizeof(fldr_hip.ConvDesc) == 12 * 8 + 12 * 8 + 12 * 4 + 12 * 4 + 8 + 4 * 8 + 12 * 4
+    # 12 ptr + 12 i64 + 12 i32 + 12 i32 + i32 (+pad) + 4 ptr + 12 i32 + 1 ptr
+    assert ctypes.sizeof(fldr_hip.ConvDesc) == 12 * 8 + 12 * 8 + 12 * 4 + 12 * 4 + 8 + 4 * 8 + 12 * 4 + 8
+    # the ctypes mirrors against the structs the library was compiled with
+    assert ctypes.sizeof(fldr_hip.ConvDesc) == fldr_hip.lib().fldr_sizeof_desc(0)
+    assert ctypes.sizeof(fldr_hip.SpkConvDesc) == fldr_hip.lib().fldr_sizeof_desc(1)
     assert fldr_hip.lib().fldr_conv_prepack_size(96, 100, 3) == 104 * 9 * 96
     assert fldr_hip.lib().fldr_conv_prepack_size(6, 16, 3) == 16 * 9 * 16
     assert fldr_hip.lib().fldr_conv_prepack_size(16, 26, 4) == 28 * 272      # channel rows padded to 16 mod 32 floats
