@@ -264,6 +264,321 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Band splat: destination-owned, NO atomics at all.
+//
+// ds_add_f32 retires one wave-instruction per ~190 cycles per CU on gfx950 (tools/ubench/lds_atomic_bench.hip; the
+// integer ds_add_u32 takes 4), so the tile kernel above is slower than the global-atomic strip kernel.  Plain LDS
+// read-modify-write is fast, but only legal when no two lanes of a wave-instruction hit the same cell and no other
+// wave touches it.  Hence:
+//   * every WAVE owns a private TW x TH band of the output in LDS (no other wave ever touches it);
+//   * per source row (64 pixels, one per lane) and bilinear corner, the lanes CLAIM their cell (ds_write of the lane id
+//     to a claim array, read back: for lanes that collide exactly one reads its own id); owners add their contribution
+//     with ds_read / v_add / ds_write, the others retry in the next round.  Coherent flows need one round; any flow
+//     terminates (each contested cell gets one owner per round) and the sum is exact.
+// The candidate search (flow bounds per block / super-block) is the tile kernel's, done per wave with ballots.
+// ------------------------------------------------------------------------------------------------
+
+#define SB_LIST 128
+
+// Wave-wide shift by one lane as a DPP move (gfx9 wave_shr:1 / wave_shl:1): a VALU cycle instead of the LDS round trip of
+// ds_bpermute (__shfl_up / __shfl_down).  Lane 0 (shr) / lane 63 (shl) keep their own value.  All lanes must be active.
+__device__ __forceinline__ int st_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ int st_shl1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ float st_shr1(float v) { return __int_as_float(st_shr1(__float_as_int(v))); }
+
+template <int MODE, int CB, int TW, int TH>
+__global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+                                                         const float* __restrict__ metric, const float* __restrict__ blk,
+                                                         const float* __restrict__ sbt, float* __restrict__ out,
+                                                         int C, int H, int W, int groups, int nsb_x, int nsb) {
+#pragma clang fp contract(off)
+    constexpr int CA = MODE >= 1 ? CB + 1 : CB;
+    constexpr int CELLS = TW * TH;
+    __shared__ float acc_all[4][CA * CELLS];
+    __shared__ unsigned short claim_all[4][CELLS];
+    __shared__ unsigned short sbl_all[4][SB_LIST];                // matching super-blocks of each wave (nsb < 65536: host-checked)
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = blockIdx.z / groups, grp = blockIdx.z % groups;
+    const int cbase = grp * CB;
+    const int tx0 = blockIdx.x * TW, ty0 = (blockIdx.y * 4 + wv) * TH;
+    if (ty0 >= H) return;                                         // wave-uniform; the kernel has no workgroup barrier
+    float* acc = acc_all[wv];
+    volatile unsigned short* claim = claim_all[wv];               // volatile: the write / read-back pair must reach the LDS
+    unsigned short* sbl = sbl_all[wv];
+    const int64_t HW = (int64_t)H * W;
+    const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fty0 = (float)ty0, fty1 = (float)(ty0 + TH - 1);
+
+    for (int i = lane; i < CA * CELLS / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+
+    const float* sbn = sbt + (int64_t)n * nsb * 4;
+    const float* bkn = blk + (int64_t)n * nsb * ST_SB_BLOCKS * 4;
+
+    const float* fl = flow + (int64_t)n * 2 * HW;
+    const float* mt = metric ? metric + (int64_t)n * HW : nullptr;
+    const float* inn = in + (int64_t)n * C * HW;
+
+    // one corner of one source row: claim, then read-modify-write by the owners; repeat for the lanes that lost
+    auto scatter = [&](bool active, int cell, float w, const float (&v)[CA]) __attribute__((always_inline)) {
+        bool pending = active;
+        while (__ballot(pending)) {
+            if (pending) claim[cell] = (unsigned short)lane;
+            bool owner = false;
+            if (pending) owner = claim[cell] == (unsigned short)lane;
+            if (owner) {
+                float cur[CA];
+#pragma unroll
+                for (int c = 0; c < CA; ++c) cur[c] = acc[c * CELLS + cell];
+#pragma unroll
+                for (int c = 0; c < CA; ++c) acc[c * CELLS + cell] = cur[c] + v[c] * w;
+            }
+            pending = pending && !owner;
+        }
+    };
+
+    // ---- accumulate: lane = one source pixel of a 64-pixel row; the next block's 4 rows are loaded ahead ----
+    float fx[2][ST_BH], fy[2][ST_BH], mv[2][ST_BH], val[2][ST_BH][CB];
+    int bxy[2] = {0, 0};
+    auto load_block = [&](int buf, int e) __attribute__((always_inline)) {   // e = (block row << 16) | block column
+        bxy[buf] = e;
+        const int px = (e & 0xFFFF) * ST_BW + lane;
+#pragma unroll
+        for (int r = 0; r < ST_BH; ++r) {
+            const int py = (e >> 16) * ST_BH + r;
+            const bool ok = px < W && py < H;
+            const int64_t pix = ok ? (int64_t)py * W + px : 0;
+            fx[buf][r] = fl[pix]; fy[buf][r] = fl[HW + pix];
+            mv[buf][r] = 0.0f;
+            if ((MODE == 2 || MODE == 3) && mt != nullptr) mv[buf][r] = mt[pix];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int cc = cbase + c < C ? cbase + c : C - 1;
+                val[buf][r][c] = inn[(int64_t)cc * HW + pix];
+            }
+        }
+    };
+    // plain read-modify-write of one cell per active lane: ONLY for sets of lanes whose cells are pairwise distinct
+    auto rmw = [&](bool active, int cell, const float (&v)[CA]) __attribute__((always_inline)) {
+        if (!__ballot(active)) return;                            // wave-uniform
+        if (active) {
+            float cur[CA];
+#pragma unroll
+            for (int c = 0; c < CA; ++c) cur[c] = acc[c * CELLS + cell];
+#pragma unroll
+            for (int c = 0; c < CA; ++c) acc[c * CELLS + cell] = cur[c] + v[c];
+        }
+    };
+
+    // One block = 4 consecutive source rows of 64 pixels.  Fast path per row (the strip kernel's register merging, with
+    // LDS read-modify-write instead of atomics), valid when the target columns x0 are non-decreasing over the lanes
+    // with no run of three equal values — any locally smooth flow:
+    //   * a lane whose right neighbour lands in the SAME cell (x0, y0 equal: compression) hands it all four corners;
+    //   * a lane whose right neighbour lands one cell to the right hands it its right-hand column (NE, SE), which is
+    //     the neighbour's left-hand column;
+    //   * the bottom-left cell stays pending in registers and joins the next row's top-left cell when that lands one
+    //     row lower (the normal case), so a row costs ONE read-modify-write per channel.
+    // Under the precondition the emitting lanes of each set address pairwise distinct cells (x0 strictly increases over
+    // them), so no claim round is needed.  Any other row takes the claim path above (exact for every flow).
+    auto process_block = [&](int buf) __attribute__((always_inline)) {
+        const int e = bxy[buf];
+        const int px = (e & 0xFFFF) * ST_BW + lane;
+        float pend[CA];
+        int pend_cell = -1;
+#pragma unroll
+        for (int c = 0; c < CA; ++c) pend[c] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < ST_BH; ++r) {
+            const int py = (e >> 16) * ST_BH + r;
+            const bool ok = px < W && py < H;
+            const StGeom g = st_geom(px, py, fx[buf][r], fy[buf][r], W, H);
+            const int lx = g.x0 - tx0, ly = g.y0 - ty0;          // band-local north-west corner
+            const bool hit = ok && lx >= -1 && lx < TW && ly >= -1 && ly < TH;
+            // a corner counts here when it lies in this band AND in the image (band origins are >= 0)
+            const bool cx0 = hit && lx >= 0 && g.x0 < W, cx1 = hit && lx + 1 < TW && g.x0 + 1 < W;
+            const bool cy0 = ly >= 0 && g.y0 < H, cy1 = ly + 1 < TH && g.y0 + 1 < H;
+            const bool vnw = cx0 && cy0, vne = cx1 && cy0, vsw = cx0 && cy1, vse = cx1 && cy1;
+            if (!__ballot(vnw || vne || vsw || vse)) {            // wave-uniform: this row misses the band
+                rmw(pend_cell >= 0, pend_cell, pend);
+                pend_cell = -1;
+                continue;
+            }
+            float wgt = 1.0f;
+            if (MODE == 2) wgt = mv[buf][r];
+            if (MODE == 3 && mt != nullptr) wgt = expf(mv[buf][r]);
+            float v[CA];
+#pragma unroll
+            for (int c = 0; c < CA; ++c) {
+                if (c < CB) {
+                    float t = val[buf][r][c];
+                    if (MODE == 3) t = (t + 1.0f) / 2.0f;         // softSplat.py:334
+                    if (MODE >= 2) t = t * wgt;                   // :328 / :338
+                    if (cbase + c >= C) t = 0.0f;
+                    v[c] = t;
+                } else {
+                    v[c] = wgt;                                   // normalisation accumulator
+                }
+            }
+            const int cell = ly * TW + lx;
+            // precondition of the fast path (lanes past the right image border count as far to the right)
+            const int xk = ok ? g.x0 : 0x3fffffff;
+            const int xl = st_shr1(xk), xll = st_shr1(xl);       // (lane 1's xll is lane 0's value: the test below needs lane >= 2)
+            const bool bad = (lane >= 1 && xk < xl) || (lane >= 2 && xk == xl && xl == xll && xk != 0x3fffffff);
+            if (__ballot(bad)) {                                  // wave-uniform: claim path for this row
+                scatter(pend_cell >= 0, pend_cell, 1.0f, pend);
+                pend_cell = -1;
+                scatter(vnw, cell, g.wnw, v);
+                scatter(vne, cell + 1, g.wne, v);
+                scatter(vsw, cell + TW, g.wsw, v);
+                scatter(vse, cell + TW + 1, g.wse, v);
+                continue;
+            }
+            // (every lane shift below is executed by ALL lanes)
+            const int xr = st_shl1(g.x0), yr = st_shl1(g.y0);
+            const int hr_i = st_shl1((int)hit);
+            const bool hr = hr_i != 0 && lane < 63;
+            const bool giver = hit && hr && xr == g.x0 && yr == g.y0;             // right neighbour: same cell
+            const bool mright = hit && hr && xr == g.x0 + 1 && yr == g.y0;        // right neighbour: one cell to the right
+            const int lg_i = st_shr1((int)giver), lm_i = st_shr1((int)mright);
+            const bool lgiver = lane > 0 && lg_i != 0;
+            const bool lmright = lane > 0 && lm_i != 0;
+            float top[CA], bot[CA], rtop[CA], rbot[CA];
+#pragma unroll
+            for (int c = 0; c < CA; ++c) {
+                float nw = vnw ? v[c] * g.wnw : 0.0f, ne = vne ? v[c] * g.wne : 0.0f;
+                float sw = vsw ? v[c] * g.wsw : 0.0f, se = vse ? v[c] * g.wse : 0.0f;
+                // (1) same-cell neighbour: right-hand column first ...
+                const float dne = st_shr1(giver ? ne : 0.0f), dse = st_shr1(giver ? se : 0.0f);
+                if (giver) { ne = 0.0f; se = 0.0f; }
+                if (lgiver) { ne += dne; se += dse; }
+                // (2) ... then right-hand columns move into the neighbour's left-hand column ...
+                const float ane = st_shr1(mright ? ne : 0.0f), ase = st_shr1(mright ? se : 0.0f);
+                if (mright) { ne = 0.0f; se = 0.0f; }
+                if (lmright) { nw += ane; sw += ase; }
+                // (3) ... then the left-hand column of a same-cell giver (with what it received in (2))
+                const float dnw = st_shr1(giver ? nw : 0.0f), dsw = st_shr1(giver ? sw : 0.0f);
+                if (giver) { nw = 0.0f; sw = 0.0f; }
+                if (lgiver) { nw += dnw; sw += dsw; }
+                top[c] = nw; bot[c] = sw; rtop[c] = ne; rbot[c] = se;
+            }
+            const bool emit = hit && !giver;
+            // pending bottom cells of the previous row: join this row's top-left cell when aligned, else go out on their own
+            const bool aligned = emit && vnw && pend_cell == cell;
+            rmw(pend_cell >= 0 && !aligned, pend_cell, pend);
+            if (aligned) {
+#pragma unroll
+                for (int c = 0; c < CA; ++c) top[c] += pend[c];
+            }
+            rmw(emit && vnw, cell, top);
+            rmw(emit && vne && !mright, cell + 1, rtop);
+            rmw(emit && vse && !mright, cell + TW + 1, rbot);
+            pend_cell = (emit && vsw) ? cell + TW : -1;
+#pragma unroll
+            for (int c = 0; c < CA; ++c) pend[c] = bot[c];
+        }
+        rmw(pend_cell >= 0, pend_cell, pend);
+    };
+
+    // ---- find the super-blocks whose flow bounds reach this band (8 x 64 tested per trip, all loads issued first), list
+    //      them in LDS, then walk their blocks (the next super-block's block bounds and the next block's rows are loaded
+    //      ahead).  Any number of candidates is handled: when the list is full the scan stops, the list is walked, and
+    //      the scan resumes where it stopped. ----
+    auto walk_sb = [&](int sbi, unsigned long long mk) __attribute__((always_inline)) {
+        const int bx0 = (sbi % nsb_x) * ST_SBX, by0 = (sbi / nsb_x) * ST_SBY;
+        auto pop = [&]() __attribute__((always_inline)) -> int {  // next matching block of this super-block
+            const int bit = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            return ((by0 + bit / ST_SBX) << 16) | (bx0 + bit % ST_SBX);
+        };
+        if (!mk) return;
+        load_block(0, pop());
+        for (;;) {
+            const bool more1 = mk != 0;
+            if (more1) load_block(1, pop());
+            process_block(0);
+            if (!more1) break;
+            const bool more0 = mk != 0;
+            if (more0) load_block(0, pop());
+            process_block(1);
+            if (!more0) break;
+        }
+    };
+    auto sb_blocks = [&](int sbi, const float4 bb) __attribute__((always_inline)) -> unsigned long long {
+        const int sx = ((sbi % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, sy = ((sbi / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
+        return __ballot(st_match(bb, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fty0, fty1));
+    };
+    int s_start = 0;
+    do {
+        // scan [s_start, nsb) until the list is full
+        int n_list = 0, s_resume = nsb;
+        for (int s0 = s_start; s0 < nsb && s_resume == nsb; s0 += 64 * 8) {
+            float4 sb8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k * 64 + lane;
+                sb8[k] = *reinterpret_cast<const float4*>(sbn + (s < nsb ? s : nsb - 1) * 4);
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int s = s0 + k * 64 + lane;
+                const int sx = (s % nsb_x) * (ST_SBX * ST_BW), sy = (s / nsb_x) * (ST_SBY * ST_BH);
+                const bool m = s < nsb && st_match(sb8[k], (float)sx, (float)(sx + ST_SBX * ST_BW - 1), (float)sy,
+                                                   (float)(sy + ST_SBY * ST_BH - 1), ftx0, ftx1, fty0, fty1);
+                const unsigned long long mask = __ballot(m);
+                if (mask && s_resume == nsb) {                    // wave-uniform
+                    if (n_list + __popcll(mask) > SB_LIST) {
+                        s_resume = s0 + k * 64;                   // resume with this chunk after the walk
+                    } else {
+                        if (m) sbl[n_list + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)s;
+                        n_list += __popcll(mask);
+                    }
+                }
+            }
+        }
+        // walk the list
+        if (n_list > 0) {
+            int sbi = sbl[0];
+            float4 bb = *reinterpret_cast<const float4*>(bkn + ((int64_t)sbi * ST_SB_BLOCKS + lane) * 4);
+            for (int i = 0; i < n_list; ++i) {
+                const int nsbi = sbl[i + 1 < n_list ? i + 1 : i];
+                const float4 nbb = *reinterpret_cast<const float4*>(bkn + ((int64_t)nsbi * ST_SB_BLOCKS + lane) * 4);
+                walk_sb(sbi, sb_blocks(sbi, bb));
+                sbi = nsbi; bb = nbb;
+            }
+        }
+        s_start = s_resume;
+    } while (s_start < nsb);
+
+    // ---- finish and write the band: (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349) ----
+    float* on = out + (int64_t)n * C * HW;
+    for (int i = lane; i < CELLS; i += 64) {
+        const int x = tx0 + i % TW, y = ty0 + i / TW;
+        if (x >= W || y >= H) continue;
+        float norm = 1.0f;
+        if (MODE >= 1) { norm = acc[CB * CELLS + i]; if (norm == 0.0f) norm = 1.0f; }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            if (cbase + c >= C) break;
+            float v = acc[c * CELLS + i];
+            if (MODE >= 1) v = v / norm;
+            on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x] = (v - 0.5f) * 2.0f;
+        }
+    }
+}
+
+template <int MODE>
+static void splat_band_launch(const float* img, const float* flow, const float* metric, const float* blk, const float* sbt,
+                              float* out, int N, int C, int H, int W, int nsb_x, int nsb, hipStream_t s) {
+    if (C <= 3) {                  // images: 3 channels + normalisation, 128 x 8 band per wave (18 KB of LDS per wave)
+        dim3 grid(fldr_cdiv(W, 128), fldr_cdiv(H, 4 * 8), N);
+        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, 128, 8>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
+    } else {                       // feature maps: groups of 12 channels, 64 x 4 band per wave (13.5 KB)
+        const int groups = fldr_cdiv(C, 12);
+        dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 4), N * groups);
+        hipLaunchKernelGGL((splat_band_kernel<MODE, 12, 64, 4>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
+    }
+}
+
 extern "C" int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return FLDR_E_ARG;
     const int64_t nsb = (int64_t)fldr_cdiv(W, ST_SBX * ST_BW) * fldr_cdiv(H, ST_SBY * ST_BH);
@@ -284,16 +599,29 @@ static void splat_tile_launch(const float* img, const float* flow, const float* 
 }
 
 // FunctionSoftsplat (softSplat.py:320-352) end to end, destination-owned.  ws: fldr_softsplat_tile_ws_floats floats.
+static int g_splat_tile_variant = 1;     // 0: LDS-atomic tiles, 1: claim-and-add bands
+extern "C" int fldr_debug_splat_tile_variant(int v) { if (v == 0 || v == 1) g_splat_tile_variant = v; return g_splat_tile_variant; }
+
 extern "C" int fldr_softsplat_tile(const float* img, const float* flow, const float* metric, float* out, float* ws,
                                    int N, int C, int H, int W, int mode, fldr_stream_t stream) {
     FLDR_CHECK_ARG(img && flow && out && ws && N > 0 && C > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 3);
     FLDR_CHECK_ARG(mode != 2 || metric != nullptr);
     if (W > 65535 * ST_BW || H > 32767 * ST_BH) return FLDR_E_SHAPE;
+    if ((int64_t)fldr_cdiv(W, ST_SBX * ST_BW) * fldr_cdiv(H, ST_SBY * ST_BH) > 65535) return FLDR_E_SHAPE;
     const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
     float* blk = ws;
     float* sbt = ws + (int64_t)N * nsb * ST_SB_BLOCKS * 4;
     hipStream_t s = fldr_s(stream);
     hipLaunchKernelGGL(splat_bounds_kernel, dim3(nsb, N), dim3(256), 0, s, flow, blk, sbt, H, W, nsb_x, nsb);
+    if (g_splat_tile_variant == 1) {
+        switch (mode) {
+            case 0: splat_band_launch<0>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            case 1: splat_band_launch<1>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            case 2: splat_band_launch<2>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            default: splat_band_launch<3>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+        }
+        FLDR_LAUNCH_RET();
+    }
     switch (mode) {
         case 0: splat_tile_launch<0>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
         case 1: splat_tile_launch<1>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
