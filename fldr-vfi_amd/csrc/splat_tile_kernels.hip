@@ -281,6 +281,14 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
 
 #define SB_LIST 128
 
+#ifdef ST_STAMPS
+__device__ unsigned long long st_stamp_buf[16];
+#define TSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int fldr_debug_read_st_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(st_stamp_buf), sizeof(unsigned long long) * 16); }
+#else
+#define TSTAMP(var)
+#endif
+
 // Wave-wide shift by one lane as a DPP move (gfx9 wave_shr:1 / wave_shl:1): a VALU cycle instead of the LDS round trip of
 // ds_bpermute (__shfl_up / __shfl_down).  Lane 0 (shr) / lane 63 (shl) keep their own value.  All lanes must be active.
 __device__ __forceinline__ int st_shr1(int v) { return __builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false); }
@@ -310,7 +318,12 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     const int64_t HW = (int64_t)H * W;
     const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fty0 = (float)ty0, fty1 = (float)(ty0 + TH - 1);
 
+    TSTAMP(t_begin)
     for (int i = lane; i < CA * CELLS / 4; i += 64) reinterpret_cast<float4*>(acc)[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    TSTAMP(t_init)
+#ifdef ST_STAMPS
+    unsigned long long c_proc = 0, c_blocks = 0, c_rows = 0, c_fast = 0, c_slow = 0, c_walk = 0;
+#endif
 
     const float* sbn = sbt + (int64_t)n * nsb * 4;
     const float* bkn = blk + (int64_t)n * nsb * ST_SB_BLOCKS * 4;
@@ -403,6 +416,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
                 pend_cell = -1;
                 continue;
             }
+#ifdef ST_STAMPS
+            ++c_rows;
+#endif
             float wgt = 1.0f;
             if (MODE == 2) wgt = mv[buf][r];
             if (MODE == 3 && mt != nullptr) wgt = expf(mv[buf][r]);
@@ -424,6 +440,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
             const int xk = ok ? g.x0 : 0x3fffffff;
             const int xl = st_shr1(xk), xll = st_shr1(xl);       // (lane 1's xll is lane 0's value: the test below needs lane >= 2)
             const bool bad = (lane >= 1 && xk < xl) || (lane >= 2 && xk == xl && xl == xll && xk != 0x3fffffff);
+#ifdef ST_STAMPS
+            if (__ballot(bad)) ++c_slow; else ++c_fast;
+#endif
             if (__ballot(bad)) {                                  // wave-uniform: claim path for this row
                 scatter(pend_cell >= 0, pend_cell, 1.0f, pend);
                 pend_cell = -1;
@@ -495,11 +514,19 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
         for (;;) {
             const bool more1 = mk != 0;
             if (more1) load_block(1, pop());
-            process_block(0);
+            { TSTAMP(p0) process_block(0); TSTAMP(p1)
+#ifdef ST_STAMPS
+              c_proc += p1 - p0; ++c_blocks;
+#endif
+            }
             if (!more1) break;
             const bool more0 = mk != 0;
             if (more0) load_block(0, pop());
-            process_block(1);
+            { TSTAMP(p0) process_block(1); TSTAMP(p1)
+#ifdef ST_STAMPS
+              c_proc += p1 - p0; ++c_blocks;
+#endif
+            }
             if (!more0) break;
         }
     };
@@ -507,6 +534,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
         const int sx = ((sbi % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, sy = ((sbi / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
         return __ballot(st_match(bb, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fty0, fty1));
     };
+    TSTAMP(t_scan0)
     int s_start = 0;
     do {
         // scan [s_start, nsb) until the list is full
@@ -536,6 +564,10 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
             }
         }
         // walk the list
+        TSTAMP(t_w0)
+#ifdef ST_STAMPS
+        c_walk -= t_w0;
+#endif
         if (n_list > 0) {
             int sbi = sbl[0];
             float4 bb = *reinterpret_cast<const float4*>(bkn + ((int64_t)sbi * ST_SB_BLOCKS + lane) * 4);
@@ -546,8 +578,13 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
                 sbi = nsbi; bb = nbb;
             }
         }
+        TSTAMP(t_w1)
+#ifdef ST_STAMPS
+        c_walk += t_w1;
+#endif
         s_start = s_resume;
     } while (s_start < nsb);
+    TSTAMP(t_scan1)
 
     // ---- finish and write the band: (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349) ----
     float* on = out + (int64_t)n * C * HW;
@@ -564,6 +601,14 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
             on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x] = (v - 0.5f) * 2.0f;
         }
     }
+#ifdef ST_STAMPS
+    TSTAMP(t_end)
+    if (blockIdx.x == gridDim.x / 2 && blockIdx.y == gridDim.y / 2 && wv == 1 && lane == 0) {
+        unsigned long long* o = st_stamp_buf;
+        o[0] = t_init - t_begin; o[1] = t_scan1 - t_scan0; o[2] = c_walk; o[3] = c_proc; o[4] = c_blocks; o[5] = c_rows;
+        o[6] = c_fast; o[7] = c_slow; o[8] = t_end - t_scan1; o[9] = t_end - t_begin;
+    }
+#endif
 }
 
 template <int MODE>

@@ -155,11 +155,14 @@ def softsplat_fwd(inp, flow):
 _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 
 
-# "strip": the global-atomic strip scatter + normalisation pass (default);
-# "tile": destination-owned tiles accumulated in LDS (no global atomics, no accumulator tensor).  Exact, but slower on
-# gfx950: ds_add_f32 retires one wave-instruction per ~190 cycles per CU (tools/ubench/lds_atomic_bench.hip; the
-# integer ds_add_u32 takes 4), i.e. LDS float atomics are slower than the memory-side ones the strip kernel uses.
-SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "strip")
+# Forward-splat kernels (FLDR_SPLAT = auto | strip | tile):
+#   "strip": global float atomics with in-register merging + a normalisation pass (warp_kernels.hip);
+#   "tile":  destination-owned bands, no atomics (splat_tile_kernels.hip): every wave owns a 128x8 band of the output in
+#            LDS, finds the sources that reach it through per-block flow bounds and adds them with plain LDS
+#            read-modify-write (register-merged fast path, claim rounds otherwise); writes the normalised band once;
+#   "auto" (default): tile for <= 3 channels (the level-0 image splats: 360 -> 190 us each incl. memset/normalisation),
+#            strip for feature maps (the 12-channel band variant needs > 256 VGPRs and is slower).
+SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 
 
 def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False):
@@ -178,7 +181,10 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
                                               ctypes.c_void_p(outp.buf.data_ptr()), _dev(scratch, "scratch"), N, C, H, W,
                                               _MODES[mode], _stream()), "fldr_softsplat_fused_spk")
         return outp
-    if (kernel or SPLAT_KERNEL) == "tile":
+    kern = kernel or SPLAT_KERNEL
+    if kern == "auto":
+        kern = "tile" if C <= 3 else "strip"
+    if kern == "tile":
         ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
         if out is None:
             out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
