@@ -265,31 +265,27 @@ class DCTVFInet(nn.Module):
         if validation:
             assert (H, W) == tuple(self.output_size_val), "validation crop differs from the input size"
         flow_10_lo, flow_01_lo = flow_l[:, :2], flow_l[:, 2:]
-        # t-scaling happens on the low-resolution flows, then x`up` bilinear upsampling times `up` (:404-422)
+        mask = not a.outMaskLess
+        # One kernel (fldr_level0_prep) produces everything between the level-0 flow and the UNet input that is not a
+        # splat: the x`up` upsampled flows are never materialised, z0 / z1 (t-independent, cached per pair when enabled)
+        # come out of the same pass.  t-scaling happens on the low-resolution flows as in the reference (:404-422).
         inv = cache.get("level0") if cache is not None else None
-        if inv is None:                                   # t-independent part (cached per pair when enabled)
-            both = fldr_hip.resize_bilinear(flow_l, H, W, mul=float(up))
-            flow_10, flow_01 = both[:, :2], both[:, 2:]
+        if inv is None:
             I0 = x_l[:, :, 0].contiguous()
             I1 = x_l[:, :, 1].contiguous()
-            if a.impmasksoftsplat:
-                z0 = fldr_hip.zmetric(I0, I1, flow_01, za0)                                            # :442-443
-                z1 = fldr_hip.zmetric(I1, I0, flow_10, za1)                                            # :445-446
-            else:
-                z0 = z1 = None
-            inv = (flow_10, flow_01, I0, I1, z0, z1)
+        else:
+            I0, I1, z0, z1 = inv
+        r = fldr_hip.level0_prep(flow_l, I0, I1, t4, H, W, za0, za1, withmask=mask,
+                                 want_z=bool(a.impmasksoftsplat) and inv is None)
+        if inv is None:
+            z0, z1 = r["z0"], r["z1"]                                                                   # :442-446
             if cache is not None:
-                cache["level0"] = inv
-        flow_10, flow_01, I0, I1, z0, z1 = inv
-        tl = fldr_hip.resize_bilinear(torch.cat([t4 * flow_01_lo, (1 - t4) * flow_10_lo], 1), H, W, mul=float(up))
-        flow_t0, flow_t1 = tl[:, 0:2], tl[:, 2:4]
+                cache["level0"] = (I0, I1, z0, z1)
+        flow_t0, flow_t1 = r["flow_t0"], r["flow_t1"]                                                   # :404-405,419-422
+        flowback_0, flowback_1 = r["flowback_0"], r["flowback_1"]                                       # :474-475
+        im0_tot, im1_tot = r["im0_tot"], r["im1_tot"]                                                   # :478-479
         warped0 = self.softsplat(I0, flow_t0, z=z0)                                                    # :449
         warped1 = self.softsplat(I1, flow_t1, z=z1)                                                    # :450
-        mask = not a.outMaskLess
-        flowback_0 = fldr_hip.bwarp_tscaled(flow_10, flow_01, t4, "t", "1-t", withmask=mask)           # :474
-        flowback_1 = fldr_hip.bwarp_tscaled(flow_01, flow_10, t4, "1-t", "t", withmask=mask)           # :475
-        im0_tot = self.bwarp(I0, flowback_0, withmask=mask)                                            # :478
-        im1_tot = self.bwarp(I1, flowback_1, withmask=mask)                                            # :479
         srcs = [I0, I1, warped0, warped1, flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot]  # :480 (no cat)
         cands = [warped0, warped1, im0_tot, im1_tot, I0, I1]
         unet = self.refine_unet

@@ -36,6 +36,18 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class PrepDesc(ctypes.Structure):
+    _fields_ = [
+        ("flow_lo", ctypes.c_void_p), ("I0", ctypes.c_void_p), ("I1", ctypes.c_void_p),
+        ("i0_bstride", ctypes.c_int64), ("i1_bstride", ctypes.c_int64),
+        ("t", ctypes.c_void_p), ("z0", ctypes.c_void_p), ("z1", ctypes.c_void_p),
+        ("flow_t0", ctypes.c_void_p), ("flow_t1", ctypes.c_void_p), ("flowback_0", ctypes.c_void_p), ("flowback_1", ctypes.c_void_p),
+        ("im0_tot", ctypes.c_void_p), ("im1_tot", ctypes.c_void_p),
+        ("N", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("mul", ctypes.c_float), ("z_alpha0", ctypes.c_float), ("z_alpha1", ctypes.c_float), ("withmask", ctypes.c_int32),
+    ]
+
+
 class SpkConvDesc(ctypes.Structure):
     _fields_ = [
         ("src", ctypes.c_void_p * MAX_SRC),
@@ -67,6 +79,7 @@ _SIGNATURES = {
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "fldr_resize_bilinear": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
+    "fldr_level0_prep": (ctypes.c_int, [ctypes.POINTER(PrepDesc), ctypes.c_void_p]),
     "fldr_zmetric": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_float, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_conv_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_conv_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
@@ -283,6 +296,37 @@ def resize_bilinear(x, H, W, mul=1.0):
     out = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
     _check(lib().fldr_resize_bilinear(_dev(x, "in"), _dev(out, "out"), N * C, h, w, H, W, float(mul), _stream()),
            "fldr_resize_bilinear")
+    return out
+
+
+def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True):
+    """fLDRnet.py:400-479 minus the splats in one kernel.  flow_lo [N,4,h,w]; I0 / I1 [N,3,H,W] (batch-strided views of
+    the [N,3,2,H,W] level-0 tensor are fine when each sample's [3,H,W] block is contiguous).
+    -> dict(z0, z1 (None unless want_z), flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot)."""
+    N, four, h, w = flow_lo.shape
+    assert four == 4 and I0.shape == (N, 3, H, W) and I1.shape == (N, 3, H, W)
+    flow_lo = flow_lo.contiguous()
+    if not I0[0].is_contiguous():
+        I0 = I0.contiguous()
+    if not I1[0].is_contiguous():
+        I1 = I1.contiguous()
+    dev = flow_lo.device
+    e = lambda c: torch.empty(N, c, H, W, device=dev, dtype=torch.float32)
+    out = {"z0": e(1) if want_z else None, "z1": e(1) if want_z else None, "flow_t0": e(2), "flow_t1": e(2),
+           "flowback_0": e(2), "flowback_1": e(2), "im0_tot": e(3), "im1_tot": e(3)}
+    t = t.reshape(N).contiguous().float()
+    d = PrepDesc()
+    d.flow_lo = _dev(flow_lo, "flow_lo").value
+    d.I0, d.I1 = I0.data_ptr(), I1.data_ptr()
+    d.i0_bstride = I0.stride(0) if N > 1 else 0
+    d.i1_bstride = I1.stride(0) if N > 1 else 0
+    d.t = _dev(t, "t").value
+    for k, v in out.items():
+        setattr(d, k, v.data_ptr() if v is not None else None)
+    d.N, d.h, d.w, d.H, d.W = N, h, w, H, W
+    d.mul, d.z_alpha0, d.z_alpha1, d.withmask = float(H / h), float(za0), float(za1), int(bool(withmask))
+    _check(lib().fldr_level0_prep(ctypes.byref(d), _stream()), "fldr_level0_prep")
+    out["_keep"] = (I0, I1, t)
     return out
 
 

@@ -124,6 +124,26 @@ int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int 
 int fldr_zmetric(const float* self_img, const float* other_img, const float* flow, float alpha, float* z,
                  int N, int C, int H, int W, fldr_stream_t stream);
 
+/* Everything of fLDRnet.py:400-479 between the level-0 flow and the UNet input that is not a splat, in one pass over the
+ * frame: x`mul` bilinear flow upsampling (:419-422, never materialised), the splat metrics z0 / z1 (:442-446, optional:
+ * both pointers or neither), flow_t0 = up(t*flow_01), flow_t1 = up((1-t)*flow_10) (:404-405), flowback_0 / flowback_1
+ * (:474-475) and im0_tot / im1_tot (:478-479).  Bit-identical to the sequence fldr_resize_bilinear / fldr_zmetric /
+ * fldr_bwarp_tscaled / fldr_bwarp it replaces (same device functions and operation order). */
+typedef struct fldr_prep_desc {
+    const float* flow_lo;            /* [N,4,h,w]: flow_10 (x,y), flow_01 (x,y) at the level-0 feature resolution */
+    const float* I0; const float* I1;/* frames, sample n at I + n*bstride, each [3,H,W] contiguous */
+    int64_t i0_bstride, i1_bstride;  /* floats */
+    const float* t;                  /* [N] */
+    float* z0; float* z1;            /* [N,1,H,W] or NULL */
+    float* flow_t0; float* flow_t1; float* flowback_0; float* flowback_1;   /* [N,2,H,W] */
+    float* im0_tot; float* im1_tot;  /* [N,3,H,W] */
+    int32_t N, h, w, H, W;
+    float mul;                       /* upscale factor H/h (the flow is multiplied by it, :420,:422) */
+    float z_alpha0, z_alpha1;
+    int32_t withmask;                /* not args.outMaskLess */
+} fldr_prep_desc;
+int fldr_level0_prep(const fldr_prep_desc* desc, fldr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Convolutions — replace the nn.Conv2d stacks of fLDRnet.py (:44-49, :318-345, :611-617).
  * ------------------------------------------------------------------------------------------ */

@@ -80,6 +80,29 @@ def test_function_softsplat_modes(hip, oracle, dev, mode):
         _cmp(out, oracle.function_softsplat(x, flow, None, mode), atol=3e-5, what="softmax no metric")
 
 
+@pytest.mark.parametrize("shape", [(1, 9, 15, 8, 0.5), (2, 12, 20, 8, 0.125), (1, 36, 60, 4, 0.875)])
+def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
+    """fldr_level0_prep (one pass) against the kernels it fuses: resize_bilinear, zmetric, bwarp_tscaled, bwarp."""
+    N, h, w, up, tv = shape
+    H, W = h * up, w * up
+    g = _gen(31)
+    flow_lo = ((torch.rand(N, 4, h, w, generator=g) - 0.5) * 6).to(dev)
+    x = (torch.rand(N, 3, 2, H, W, generator=g) * 2 - 1).to(dev)
+    I0, I1 = x[:, :, 0].contiguous(), x[:, :, 1].contiguous()
+    t4 = torch.full((N, 1, 1, 1), tv).to(dev)
+    za0, za1 = -1.894, -1.8942
+    r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, za0, za1, withmask=True, want_z=True)
+    both = hip.resize_bilinear(flow_lo, H, W, mul=float(up))
+    f10, f01 = both[:, :2], both[:, 2:]
+    assert torch.equal(r["z0"], hip.zmetric(I0, I1, f01, za0)) and torch.equal(r["z1"], hip.zmetric(I1, I0, f10, za1))
+    tl = hip.resize_bilinear(torch.cat([t4 * flow_lo[:, 2:], (1 - t4) * flow_lo[:, :2]], 1), H, W, mul=float(up))
+    assert torch.equal(r["flow_t0"], tl[:, 0:2]) and torch.equal(r["flow_t1"], tl[:, 2:4])
+    fb0 = hip.bwarp_tscaled(f10, f01, t4, "t", "1-t", withmask=True)
+    fb1 = hip.bwarp_tscaled(f01, f10, t4, "1-t", "t", withmask=True)
+    assert torch.equal(r["flowback_0"], fb0) and torch.equal(r["flowback_1"], fb1)
+    assert torch.equal(r["im0_tot"], hip.bwarp(I0, fb0, True)) and torch.equal(r["im1_tot"], hip.bwarp(I1, fb1, True))
+
+
 def test_pca_stream_equals_two_pass(hip, dev, model):
     """One-pass projection (raw fp64 parked, streaming rescale) == two-pass kernel bit for bit; its split-packed twin ==
     fldr_spk_pack of the fp32 output."""
