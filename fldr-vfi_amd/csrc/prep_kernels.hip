@@ -11,7 +11,7 @@
 #include "common.h"
 
 struct PrepArgs {
-    const float* flow_lo;          // [N,4,h,w]: flow_10 (x,y), flow_01 (x,y)
+    const float4* flow_lo4;        // [N,h,w] x (flow_10.x, flow_10.y, flow_01.x, flow_01.y): one 16-B load per low-resolution pixel
     const float* I0; const float* I1;
     int64_t i0_bstride, i1_bstride;   // floats between samples ([3,H,W] blocks are contiguous)
     const float* t;                // [N]
@@ -23,37 +23,70 @@ struct PrepArgs {
     int withmask;
 };
 
-// F.interpolate(bilinear, align_corners=False)(scale * plane)[Y, X] * mul — the arithmetic of resize_bilinear_kernel on
-// a low-resolution plane that was first multiplied by `scale` (pre != 0) in fp32, as `t4 * flow_01_lo` does.
-__device__ __forceinline__ float prep_up(const float* __restrict__ p, int h, int w, int X, int Y, float sx, float sy, float mul,
-                                         int pre, float scale) {
-#pragma clang fp contract(off)
-    int x0, x1, y0, y1; float lx, ly;
-    fldr_lin_src(X, sx, w, x0, x1, lx);
-    fldr_lin_src(Y, sy, h, y0, y1, ly);
-    float a00 = p[(int64_t)y0 * w + x0], a01 = p[(int64_t)y0 * w + x1];
-    float a10 = p[(int64_t)y1 * w + x0], a11 = p[(int64_t)y1 * w + x1];
-    if (pre) { a00 = scale * a00; a01 = scale * a01; a10 = scale * a10; a11 = scale * a11; }
-    const float wx0 = 1.0f - lx, wy0 = 1.0f - ly;
-    const float top = wx0 * a00 + lx * a01;
-    const float bot = wx0 * a10 + lx * a11;
-    return (wy0 * top + ly * bot) * mul;
+// Source indices / weight of F.interpolate(bilinear, align_corners=False) along one axis (fldr_lin_src), computed once
+// and shared by every plane and tap that is evaluated at the same coordinate.
+struct PrepLin { int i0, i1; float l; };
+__device__ __forceinline__ PrepLin prep_lin(int o, float scale, int in_size) {
+    PrepLin r;
+    fldr_lin_src(o, scale, in_size, r.i0, r.i1, r.l);
+    return r;
 }
 
-// bwarp_tscaled of a full-resolution flow field that only exists as its low-resolution source: sample (xs * up(plane)) at
-// the tap `tp` with the arithmetic of bwarp_kernel's scaled branch.
-__device__ __forceinline__ float prep_sample_up(const FldrTap& tp, const float* __restrict__ p, const PrepArgs& a, float xs) {
+// The four low-resolution neighbours of one full-resolution coordinate, all 4 flow channels each (4 loads of 16 B).
+struct PrepQuad { float4 a00, a01, a10, a11; };
+__device__ __forceinline__ PrepQuad prep_quad(const float4* __restrict__ p, int w, const PrepLin& ix, const PrepLin& iy) {
+    PrepQuad q;
+    q.a00 = p[(int64_t)iy.i0 * w + ix.i0]; q.a01 = p[(int64_t)iy.i0 * w + ix.i1];
+    q.a10 = p[(int64_t)iy.i1 * w + ix.i0]; q.a11 = p[(int64_t)iy.i1 * w + ix.i1];
+    return q;
+}
+__device__ __forceinline__ float prep_ch(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// F.interpolate(bilinear, align_corners=False)(scale * plane)[Y, X] * mul — the arithmetic of resize_bilinear_kernel on
+// channel c of the low-resolution flow, first multiplied by `scale` (pre != 0) in fp32 as `t4 * flow_01_lo` does.
+__device__ __forceinline__ float prep_up(const PrepQuad& q, int c, const PrepLin& ix, const PrepLin& iy, float mul, int pre, float scale) {
+#pragma clang fp contract(off)
+    float a00 = prep_ch(q.a00, c), a01 = prep_ch(q.a01, c), a10 = prep_ch(q.a10, c), a11 = prep_ch(q.a11, c);
+    if (pre) { a00 = scale * a00; a01 = scale * a01; a10 = scale * a10; a11 = scale * a11; }
+    const float wx0 = 1.0f - ix.l, wy0 = 1.0f - iy.l;
+    const float top = wx0 * a00 + ix.l * a01;
+    const float bot = wx0 * a10 + ix.l * a11;
+    return (wy0 * top + iy.l * bot) * mul;
+}
+
+// bwarp_tscaled of a full-resolution 2-channel flow field (channels c0, c0+1 of the low-resolution flow) that only exists
+// as its low-resolution source: sample (xs * up(channel)) at the tap `tp` with the arithmetic of bwarp_kernel's scaled branch.
+__device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const float4* __restrict__ lo4, int c0, const PrepArgs& a, float xs,
+                                                float& ox, float& oy) {
 #pragma clang fp contract(off)
     const int xa = min(max(tp.x0, 0), a.W - 1), xb = min(max(tp.x0 + 1, 0), a.W - 1);
     const int ya = min(max(tp.y0, 0), a.H - 1), yb = min(max(tp.y0 + 1, 0), a.H - 1);
-    const float pnw = prep_up(p, a.h, a.w, xa, ya, a.sx, a.sy, a.mul, 0, 1.0f), pne = prep_up(p, a.h, a.w, xb, ya, a.sx, a.sy, a.mul, 0, 1.0f);
-    const float psw = prep_up(p, a.h, a.w, xa, yb, a.sx, a.sy, a.mul, 0, 1.0f), pse = prep_up(p, a.h, a.w, xb, yb, a.sx, a.sy, a.mul, 0, 1.0f);
-    float v = 0.0f;
-    v += tp.vnw ? (pnw * xs) * tp.wnw : 0.0f;
-    v += tp.vne ? (pne * xs) * tp.wne : 0.0f;
-    v += tp.vsw ? (psw * xs) * tp.wsw : 0.0f;
-    v += tp.vse ? (pse * xs) * tp.wse : 0.0f;
-    return v;
+    const PrepLin lxa = prep_lin(xa, a.sx, a.w), lxb = prep_lin(xb, a.sx, a.w);
+    const PrepLin lya = prep_lin(ya, a.sy, a.h), lyb = prep_lin(yb, a.sy, a.h);
+    const PrepQuad qnw = prep_quad(lo4, a.w, lxa, lya), qne = prep_quad(lo4, a.w, lxb, lya);
+    const PrepQuad qsw = prep_quad(lo4, a.w, lxa, lyb), qse = prep_quad(lo4, a.w, lxb, lyb);
+    float o[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float pnw = prep_up(qnw, c0 + k, lxa, lya, a.mul, 0, 1.0f), pne = prep_up(qne, c0 + k, lxb, lya, a.mul, 0, 1.0f);
+        const float psw = prep_up(qsw, c0 + k, lxa, lyb, a.mul, 0, 1.0f), pse = prep_up(qse, c0 + k, lxb, lyb, a.mul, 0, 1.0f);
+        float v = 0.0f;
+        v += tp.vnw ? (pnw * xs) * tp.wnw : 0.0f;
+        v += tp.vne ? (pne * xs) * tp.wne : 0.0f;
+        v += tp.vsw ? (psw * xs) * tp.wsw : 0.0f;
+        v += tp.vse ? (pse * xs) * tp.wse : 0.0f;
+        o[k] = v;
+    }
+    ox = o[0]; oy = o[1];
+}
+
+// [N,4,h,w] -> [N,h,w] x float4
+__global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __restrict__ lo, float4* __restrict__ lo4, int64_t hw) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (i >= hw) return;
+    const float* p = lo + (int64_t)n * 4 * hw + i;
+    lo4[(int64_t)n * hw + i] = make_float4(p[0], p[hw], p[2 * hw], p[3 * hw]);
 }
 
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
@@ -64,8 +97,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     if (px >= a.W || py >= a.H) return;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
     const int64_t pix = (int64_t)py * a.W + px;
-    const float* lo = a.flow_lo + (int64_t)n * 4 * hw;
-    const float* l10x = lo, *l10y = lo + hw, *l01x = lo + 2 * hw, *l01y = lo + 3 * hw;
+    const float4* lo4 = a.flow_lo4 + (int64_t)n * hw;        // channels: 0,1 = flow_10 (x,y); 2,3 = flow_01 (x,y)
     const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
     const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
     const float tv = a.t[n], omt = 1.0f - tv;
@@ -76,8 +108,10 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     for (int c = 0; c < 3; ++c) { c0[c] = i0[(int64_t)c * HW + pix]; c1[c] = i1[(int64_t)c * HW + pix]; }
 
     // upsampled flows at this pixel (fLDRnet.py:419-422)
-    const float f10x = prep_up(l10x, a.h, a.w, px, py, a.sx, a.sy, a.mul, 0, 1.0f), f10y = prep_up(l10y, a.h, a.w, px, py, a.sx, a.sy, a.mul, 0, 1.0f);
-    const float f01x = prep_up(l01x, a.h, a.w, px, py, a.sx, a.sy, a.mul, 0, 1.0f), f01y = prep_up(l01y, a.h, a.w, px, py, a.sx, a.sy, a.mul, 0, 1.0f);
+    const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
+    const PrepQuad q = prep_quad(lo4, a.w, lx, ly);
+    const float f10x = prep_up(q, 0, lx, ly, a.mul, 0, 1.0f), f10y = prep_up(q, 1, lx, ly, a.mul, 0, 1.0f);
+    const float f01x = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f), f01y = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
 
     // splat metrics (fLDRnet.py:442-446 = zmetric_kernel): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10)
     if (a.z0) {
@@ -98,18 +132,20 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 
     // t-scaled forward flows (fLDRnet.py:404-405,419-422): upsampling of (t * flow_01_lo) and ((1-t) * flow_10_lo)
     const int64_t o2 = (int64_t)n * 2 * HW + pix;
-    a.flow_t0[o2] = prep_up(l01x, a.h, a.w, px, py, a.sx, a.sy, a.mul, 1, tv);
-    a.flow_t0[o2 + HW] = prep_up(l01y, a.h, a.w, px, py, a.sx, a.sy, a.mul, 1, tv);
-    a.flow_t1[o2] = prep_up(l10x, a.h, a.w, px, py, a.sx, a.sy, a.mul, 1, omt);
-    a.flow_t1[o2 + HW] = prep_up(l10y, a.h, a.w, px, py, a.sx, a.sy, a.mul, 1, omt);
+    a.flow_t0[o2] = prep_up(q, 2, lx, ly, a.mul, 1, tv);
+    a.flow_t0[o2 + HW] = prep_up(q, 3, lx, ly, a.mul, 1, tv);
+    a.flow_t1[o2] = prep_up(q, 0, lx, ly, a.mul, 1, omt);
+    a.flow_t1[o2 + HW] = prep_up(q, 1, lx, ly, a.mul, 1, omt);
 
     // backward flows (fLDRnet.py:474-475 = bwarp_kernel with scales): flowback_0 = bwarp(t * flow_10, (1-t) * flow_01),
     // flowback_1 = bwarp((1-t) * flow_01, t * flow_10)
     const FldrTap tb0 = fldr_grid_tap((float)px, (float)py, omt * f01x, omt * f01y, a.W, a.H, a.inv_wm1, a.inv_hm1);
     const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1);
     const float mb0 = a.withmask ? fldr_tap_mask(tb0) : 1.0f, mb1 = a.withmask ? fldr_tap_mask(tb1) : 1.0f;
-    const float fb0x = prep_sample_up(tb0, l10x, a, tv) * mb0, fb0y = prep_sample_up(tb0, l10y, a, tv) * mb0;
-    const float fb1x = prep_sample_up(tb1, l01x, a, omt) * mb1, fb1y = prep_sample_up(tb1, l01y, a, omt) * mb1;
+    float fb0x, fb0y, fb1x, fb1y;
+    prep_sample_up2(tb0, lo4, 0, a, tv, fb0x, fb0y);
+    prep_sample_up2(tb1, lo4, 2, a, omt, fb1x, fb1y);
+    fb0x = fb0x * mb0; fb0y = fb0y * mb0; fb1x = fb1x * mb1; fb1y = fb1y * mb1;
     a.flowback_0[o2] = fb0x; a.flowback_0[o2 + HW] = fb0y;
     a.flowback_1[o2] = fb1x; a.flowback_1[o2 + HW] = fb1y;
 
@@ -126,16 +162,19 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 }
 
 extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
-    FLDR_CHECK_ARG(d && d->flow_lo && d->I0 && d->I1 && d->t && d->flow_t0 && d->flow_t1 && d->flowback_0 && d->flowback_1);
+    FLDR_CHECK_ARG(d && d->ws && d->flow_lo && d->I0 && d->I1 && d->t && d->flow_t0 && d->flow_t1 && d->flowback_0 && d->flowback_1);
     FLDR_CHECK_ARG(d->im0_tot && d->im1_tot && (!d->z0 == !d->z1) && d->N > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0);
     PrepArgs a;
-    a.flow_lo = d->flow_lo; a.I0 = d->I0; a.I1 = d->I1; a.i0_bstride = d->i0_bstride; a.i1_bstride = d->i1_bstride;
+    a.flow_lo4 = reinterpret_cast<const float4*>(d->ws); a.I0 = d->I0; a.I1 = d->I1; a.i0_bstride = d->i0_bstride; a.i1_bstride = d->i1_bstride;
     a.t = d->t; a.z0 = d->z0; a.z1 = d->z1; a.flow_t0 = d->flow_t0; a.flow_t1 = d->flow_t1;
     a.flowback_0 = d->flowback_0; a.flowback_1 = d->flowback_1; a.im0_tot = d->im0_tot; a.im1_tot = d->im1_tot;
     a.h = d->h; a.w = d->w; a.H = d->H; a.W = d->W;
     a.sy = (float)d->h / (float)d->H; a.sx = (float)d->w / (float)d->W; a.mul = d->mul;
     a.inv_wm1 = (float)(d->W - 1 > 1 ? d->W - 1 : 1); a.inv_hm1 = (float)(d->H - 1 > 1 ? d->H - 1 : 1);
     a.za0 = d->z_alpha0; a.za1 = d->z_alpha1; a.withmask = d->withmask;
+    const int64_t hw = (int64_t)d->h * d->w;
+    hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
+                       reinterpret_cast<float4*>(d->ws), hw);
     dim3 grid(fldr_cdiv(d->W, 64), fldr_cdiv(d->H, 4), d->N);
     hipLaunchKernelGGL(level0_prep_kernel, grid, dim3(256), 0, fldr_s(stream), a);
     FLDR_LAUNCH_RET();

@@ -45,6 +45,7 @@ class PrepDesc(ctypes.Structure):
         ("im0_tot", ctypes.c_void_p), ("im1_tot", ctypes.c_void_p),
         ("N", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
         ("mul", ctypes.c_float), ("z_alpha0", ctypes.c_float), ("z_alpha1", ctypes.c_float), ("withmask", ctypes.c_int32),
+        ("ws", ctypes.c_void_p),
     ]
 
 
@@ -325,8 +326,10 @@ def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True):
         setattr(d, k, v.data_ptr() if v is not None else None)
     d.N, d.h, d.w, d.H, d.W = N, h, w, H, W
     d.mul, d.z_alpha0, d.z_alpha1, d.withmask = float(H / h), float(za0), float(za1), int(bool(withmask))
+    ws = torch.empty(N * h * w * 4, device=dev, dtype=torch.float32)
+    d.ws = ws.data_ptr()
     _check(lib().fldr_level0_prep(ctypes.byref(d), _stream()), "fldr_level0_prep")
-    out["_keep"] = (I0, I1, t)
+    out["_keep"] = (I0, I1, t, ws)
     return out
 
 

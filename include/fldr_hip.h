@@ -141,6 +141,7 @@ typedef struct fldr_prep_desc {
     float mul;                       /* upscale factor H/h (the flow is multiplied by it, :420,:422) */
     float z_alpha0, z_alpha1;
     int32_t withmask;                /* not args.outMaskLess */
+    float* ws;                       /* workspace: N*h*w*4 floats (the low-resolution flow, channel-interleaved), 16-B aligned */
 } fldr_prep_desc;
 int fldr_level0_prep(const fldr_prep_desc* desc, fldr_stream_t stream);
 
