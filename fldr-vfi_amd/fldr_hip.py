@@ -75,6 +75,8 @@ _SIGNATURES = {
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_softsplat_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project_stream": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
@@ -164,6 +166,34 @@ def softsplat_fwd(inp, flow):
     _check(lib().fldr_softsplat_fwd(_dev(inp, "input"), _dev(flow, "flow"), _dev(out, "output"), N, C, H, W, _stream()),
            "fldr_softsplat_fwd")
     return out
+
+
+def softsplat_bwd(inp, flow, grad_out, need_input=True, need_flow=True):
+    """_FunctionSoftsplat.backward (softSplat.py:259-318) -> (gradInput or None, gradFlow or None)."""
+    N, C, H, W = inp.shape
+    inp, flow, grad_out = inp.contiguous(), flow.contiguous(), grad_out.contiguous()
+    gi = torch.empty_like(inp) if need_input else None
+    gf = torch.empty_like(flow) if need_flow else None
+    if gi is None and gf is None:
+        return None, None
+    _check(lib().fldr_softsplat_bwd(_dev(inp, "input"), _dev(flow, "flow"), _dev(grad_out, "gradOutput"),
+                                    _dev(gi, "gradInput") if gi is not None else None,
+                                    _dev(gf, "gradFlow") if gf is not None else None, N, C, H, W, _stream()), "fldr_softsplat_bwd")
+    return gi, gf
+
+
+def correlation_bwd(first, second, grad_out, need_first=True, need_second=True):
+    """_FunctionCorrelation.backward (correlation.py:350-410) -> (gradFirst or None, gradSecond or None)."""
+    N, C, H, W = first.shape
+    first, second, grad_out = first.contiguous(), second.contiguous(), grad_out.contiguous()
+    g1 = torch.empty_like(first) if need_first else None
+    g2 = torch.empty_like(second) if need_second else None
+    if g1 is None and g2 is None:
+        return None, None
+    _check(lib().fldr_correlation_bwd(_dev(first, "first"), _dev(second, "second"), _dev(grad_out, "gradOutput"),
+                                      _dev(g1, "gradFirst") if g1 is not None else None,
+                                      _dev(g2, "gradSecond") if g2 is not None else None, N, C, H, W, _stream()), "fldr_correlation_bwd")
+    return g1, g2
 
 
 _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}

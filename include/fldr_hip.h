@@ -79,6 +79,20 @@ int fldr_correlation_fwd(const float* a, const float* b, float* out,
                          int N, int C, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Backward operators — replace the backward kernels of softSplat.py / correlation.py.
+ * ------------------------------------------------------------------------------------------ */
+
+/* _FunctionSoftsplat.backward (softSplat.py:259-318; kernels :54-158): gradients of fldr_softsplat_fwd with respect to its
+ * input ([N,C,H,W]) and flow ([N,2,H,W]); either output may be NULL.  One pass produces both. */
+int fldr_softsplat_bwd(const float* in, const float* flow, const float* grad_out, float* grad_in_or_null,
+                       float* grad_flow_or_null, int N, int C, int H, int W, fldr_stream_t stream);
+
+/* _FunctionCorrelation.backward (correlation.py:350-410; kernels :114-242): gradients of fldr_correlation_fwd with respect
+ * to first / second ([N,C,H,W]); grad_out [N,81,H,W]; either output may be NULL. */
+int fldr_correlation_bwd(const float* first, const float* second, const float* grad_out, float* grad_first_or_null,
+                         float* grad_second_or_null, int N, int C, int H, int W, fldr_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Low-dimensional feature projection — replaces pca_comp.to_pca_diff (pca_comp.py:473-528).
  * ------------------------------------------------------------------------------------------ */
 

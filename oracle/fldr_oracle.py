@@ -66,6 +66,57 @@ def splat_forward(inp, flow):
     return out.float().view(N, C, H, W)
 
 
+def splat_backward(inp, flow, grad_out):
+    """_FunctionSoftsplat.backward: kernel_Softsplat_updateGradInput (softSplat.py:54-100) and
+    kernel_Softsplat_updateGradFlow (:102-158), restated from the kernel text.  -> (gradInput, gradFlow).
+    fp32 products in the reference's factorisation, accumulated in fp64 over corners / channels and rounded once."""
+    N, C, H, W = inp.shape
+    inp, flow, g = inp.float(), flow.float(), grad_out.float()
+    xs = torch.arange(W, dtype=torch.float32).view(1, 1, W).expand(N, H, W)
+    ys = torch.arange(H, dtype=torch.float32).view(1, H, 1).expand(N, H, W)
+    fx, fy = xs + flow[:, 0], ys + flow[:, 1]                         # :67-68, :115-116
+    x0, y0 = torch.floor(fx), torch.floor(fy)
+    x1, y1 = x0 + 1, y0 + 1
+    w = {"nw": (x1 - fx) * (y1 - fy), "ne": (fx - x0) * (y1 - fy), "sw": (x1 - fx) * (fy - y0), "se": (fx - x0) * (fy - y0)}   # :79-82
+    dx = {"nw": -1.0 * (y1 - fy), "ne": +1.0 * (y1 - fy), "sw": -1.0 * (fy - y0), "se": +1.0 * (fy - y0)}                 # :131-135
+    dy = {"nw": (x1 - fx) * -1.0, "ne": (fx - x0) * -1.0, "sw": (x1 - fx) * +1.0, "se": (fx - x0) * +1.0}                 # :136-141
+    pos = {"nw": (x0, y0), "ne": (x1, y0), "sw": (x0, y1), "se": (x1, y1)}
+    gin = torch.zeros(N, C, H, W, dtype=torch.float64)
+    gfx = torch.zeros(N, H, W, dtype=torch.float64)
+    gfy = torch.zeros(N, H, W, dtype=torch.float64)
+    gflat = g.reshape(N, C, H * W)
+    for k in ("nw", "ne", "sw", "se"):
+        tx, ty = pos[k]
+        ok = (tx >= 0) & (tx < W) & (ty >= 0) & (ty < H)                # :83-94, :144-155
+        idx = (ty.clamp(0, H - 1) * W + tx.clamp(0, W - 1)).long().view(N, 1, H * W).expand(N, C, H * W)
+        gk = torch.gather(gflat, 2, idx).view(N, C, H, W) * ok.unsqueeze(1)
+        gin += (gk * w[k].unsqueeze(1)).double()
+        gfx += ((inp * gk) * dx[k].unsqueeze(1)).double().sum(1)
+        gfy += ((inp * gk) * dy[k].unsqueeze(1)).double().sum(1)
+    return gin.float(), torch.stack([gfx, gfy], 1).float()
+
+
+def correlation_backward(first, second, grad_out):
+    """_FunctionCorrelation.backward: kernel_Correlation_updateGradFirst (correlation.py:114-168) and
+    kernel_Correlation_updateGradSecond (:170-242) for stride 1 / kernel 1 / pad 4, restated from the kernel text.
+    -> (gradFirst, gradSecond)."""
+    N, C, H, W = first.shape
+    g = grad_out.double()
+    f, sp = first.double(), F.pad(second.double(), (4, 4, 4, 4))
+    gpad = F.pad(g, (4, 4, 4, 4))
+    fpad = F.pad(f, (4, 4, 4, 4))
+    g1 = torch.zeros(N, C, H, W, dtype=torch.float64)
+    g2 = torch.zeros(N, C, H, W, dtype=torch.float64)
+    for p in range(-4, 5):
+        for o in range(-4, 5):
+            op = (p + 4) * 9 + (o + 4)
+            # gradFirst[y,x] += gradOut[op,y,x] * second[y+p,x+o]                       (:150-163)
+            g1 += g[:, op:op + 1] * sp[:, :, 4 + p:4 + p + H, 4 + o:4 + o + W]
+            # gradSecond[y,x] += gradOut[op,y-p,x-o] * first[y-p,x-o] where in range     (:205-235)
+            g2 += gpad[:, op:op + 1, 4 - p:4 - p + H, 4 - o:4 - o + W] * fpad[:, :, 4 - p:4 - p + H, 4 - o:4 - o + W]
+    return (g1 / C).float(), (g2 / C).float()                                        # :166, :240
+
+
 def function_softsplat(img, flow, metric, mode="softmax"):
     """FunctionSoftsplat (softSplat.py:320-352), including its quirks:
     the (x+1)/2 pre-scale happens only for 'softmax' (:334) while the

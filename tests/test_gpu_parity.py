@@ -143,6 +143,44 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape):
             assert torch.equal(hip.conv2d([ref[:, half:]], w3, None, precision="split"), hip.conv2d_spk([gp.narrow(half, half)], w3, None))
 
 
+def test_splat_and_correlation_backward(hip, oracle, dev):
+    """fldr_softsplat_bwd / fldr_correlation_bwd against the oracle's restatement of the reference's backward kernels, and
+    autograd through FunctionSoftsplat / FunctionCorrelation (the training-side use of the operators)."""
+    import softSplat
+    from OpticalFlow import correlation
+    g = _gen(41)
+    x = torch.rand(2, 5, 37, 70, generator=g) * 2 - 1
+    flow = (torch.rand(2, 2, 37, 70, generator=g) - 0.5) * 12
+    go = torch.randn(2, 5, 37, 70, generator=g)
+    gi, gf = hip.softsplat_bwd(x.to(dev), flow.to(dev), go.to(dev))
+    ri, rf = oracle.splat_backward(x, flow, go)
+    _cmp(gi, ri, atol=2e-6, rtol=1e-5, what="splat gradInput")
+    _cmp(gf, rf, atol=3e-5, rtol=1e-5, what="splat gradFlow")
+    # autograd through the composed softmax splat == autograd through the oracle's forward restatement
+    xd, fd = x.to(dev).requires_grad_(True), flow.to(dev).requires_grad_(True)
+    zd = torch.randn(2, 1, 37, 70, generator=g)
+    zg = zd.to(dev).requires_grad_(True)
+    out = softSplat.FunctionSoftsplat(xd, fd, zg, "softmax")
+    w = torch.randn(out.shape, generator=g)
+    (out * w.to(dev)).sum().backward()
+    xc, fc, zc = x.clone().requires_grad_(True), flow.clone().requires_grad_(True), zd.clone().requires_grad_(True)
+    (oracle.function_softsplat(xc, fc, zc, "softmax") * w).sum().backward()
+    _cmp(xd.grad, xc.grad, atol=3e-5, rtol=1e-4, what="d softsplat / d input")
+    _cmp(zg.grad, zc.grad, atol=3e-5, rtol=1e-4, what="d softsplat / d metric")
+    _cmp(fd.grad, fc.grad, atol=2e-3, rtol=2e-3, what="d softsplat / d flow")     # fp32 chain through the normalisation; the oracle sums in fp64
+    a = torch.randn(2, 7, 21, 33, generator=g)
+    b = torch.randn(2, 7, 21, 33, generator=g)
+    gc = torch.randn(2, 81, 21, 33, generator=g)
+    ga, gb = hip.correlation_bwd(a.to(dev), b.to(dev), gc.to(dev))
+    ra, rb = oracle.correlation_backward(a, b, gc)
+    _cmp(ga, ra, atol=3e-6, rtol=1e-5, what="correlation gradFirst")
+    _cmp(gb, rb, atol=3e-6, rtol=1e-5, what="correlation gradSecond")
+    ad, bd = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    (correlation.FunctionCorrelation(ad, bd) * gc.to(dev)).sum().backward()
+    _cmp(ad.grad, ra, atol=3e-6, rtol=1e-5, what="autograd correlation first")
+    _cmp(bd.grad, rb, atol=3e-6, rtol=1e-5, what="autograd correlation second")
+
+
 @pytest.mark.parametrize("mode", ["summation", "average", "linear", "softmax"])
 @pytest.mark.parametrize("shape", [(2, 4, 33, 70, 9.0), (1, 3, 70, 300, 40.0), (1, 13, 40, 130, 600.0)])
 def test_tile_softsplat_matches_oracle(hip, oracle, dev, mode, shape):

@@ -160,3 +160,24 @@ def test_psnr_known_answer(oracle):
     b = np.full((4, 4, 3), 5.0)
     assert math.isclose(oracle.psnr(a, b), 10 * math.log10(255 ** 2 / 25.0))
     assert oracle.psnr(a, a) == float("inf")
+
+
+def test_oracle_backward_restatements_match_autograd_of_the_forward():
+    """The backward kernels of the two custom ops (softSplat.py:54-158, correlation.py:114-242) restated from the kernel text
+    must equal the autograd gradients of the forward restatements (the forward ops are what the reference's tests pin)."""
+    import fldr_oracle as O
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 3, 13, 17, generator=g) * 2 - 1).requires_grad_(True)
+    flow = ((torch.rand(2, 2, 13, 17, generator=g) - 0.5) * 7).requires_grad_(True)
+    out = O.splat_forward(x, flow)
+    go = torch.randn(out.shape, generator=g)
+    gx, gf = torch.autograd.grad(out, [x, flow], go)
+    rx, rf = O.splat_backward(x.detach(), flow.detach(), go)
+    assert (gx - rx).abs().max() < 2e-6 and (gf - rf).abs().max() < 2e-5
+    a = torch.randn(1, 5, 11, 14, generator=g).requires_grad_(True)
+    b = torch.randn(1, 5, 11, 14, generator=g).requires_grad_(True)
+    c = O.correlation(a, b)
+    gc = torch.randn(c.shape, generator=g)
+    ga, gb = torch.autograd.grad(c, [a, b], gc)
+    ra, rb = O.correlation_backward(a.detach(), b.detach(), gc)
+    assert (ga - ra).abs().max() < 2e-6 and (gb - rb).abs().max() < 2e-6
