@@ -76,7 +76,8 @@ struct ConvCfg {
     static constexpr int CPW = CC / 4;                   // channels staged per wave
     static constexpr int WSLAB = CC * WCH;               // weight floats per chunk (contiguous in wpack)
     static constexpr int NWI = (WSLAB / 4 + 255) / 256;  // 16-B LDS-DMA pieces per thread per chunk
-    static constexpr int W_LDS = NWI * 256 * 4;          // weight region rounded up to whole pieces
+    static constexpr int W_LDS = (WSLAB + 63) / 64 * 64;  // weight region (the DMA lanes past the slab are masked off): a tight
+                                                         // region lets three enc1 workgroups share a CU's 160 KB instead of two
     static constexpr int BUF_FLOATS = W_LDS + CC * ICH;  // one pipeline stage: [weights | input]
     static constexpr int TAB_FLOATS = 2 * 112;           // per-channel plane pointers (64-bit), cin_pad <= 112
     static constexpr int LDS_FLOATS = 2 * BUF_FLOATS + TAB_FLOATS;
@@ -92,7 +93,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 //     selection resolved at load time) and written to LDS after the MFMA phase,
 // and ONE barrier per chunk separates the stages.
 template <int KS, int STRIDE, int MT, int NMT, int PT, int CC_>
-__global__ __launch_bounds__(256, (MT == 16 && NMT == 3) ? 3 : 2) void conv_mfma_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, ((MT == 16 && NMT == 3) || (KS == 4 && MT == 16)) ? 3 : 2) void conv_mfma_kernel(ConvArgs a) {
     using Cfg = ConvCfg<KS, STRIDE, MT, NMT, PT, CC_>;
     constexpr int CC = Cfg::CC, IH = Cfg::IH, IW = Cfg::IW, IWP = Cfg::IWP, IWH = Cfg::IWH, ICH = Cfg::ICH;
     constexpr int TAPS = Cfg::TAPS, MTOT = Cfg::MTOT, WCH = Cfg::WCH, KG = Cfg::KG;
@@ -169,9 +170,9 @@ __global__ __launch_bounds__(256, (MT == 16 && NMT == 3) ? 3 : 2) void conv_mfma
 #pragma unroll
         for (int i = 0; i < NWI; ++i) {
             const int piece = i * 256 + wave * 64;                    // wave-uniform piece base (x16 B)
-            int src = (piece + lane) * 4;
-            src = src < Cfg::WSLAB ? src : 0;                        // tail pieces re-read the slab start (never consumed)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + src), (lptr_t)(stage + piece * 4), 16, 0, 0);
+            const int src = (piece + lane) * 4;
+            if (src < Cfg::WSLAB)                                     // lanes past the slab write nothing
+                __builtin_amdgcn_global_load_lds((gptr_t)(g + src), (lptr_t)(stage + piece * 4), 16, 0, 0);
         }
     };
     auto load_inputs = [&](int c0) {
