@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     constexpr int CA = MODE >= 1 ? CB + 1 : CB;
     constexpr int CELLS = TW * TH;
     __shared__ float acc_all[4][CA * CELLS];
-    __shared__ unsigned short claim_all[4][CELLS];
+    __shared__ unsigned char claim_all[4][CELLS];                 // lane ids (< 64)
     __shared__ unsigned short sbl_all[4][SB_LIST];                // matching super-blocks of each wave (nsb < 65536: host-checked)
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     const int tx0 = blockIdx.x * TW, ty0 = (blockIdx.y * 4 + wv) * TH;
     if (ty0 >= H) return;                                         // wave-uniform; the kernel has no workgroup barrier
     float* acc = acc_all[wv];
-    volatile unsigned short* claim = claim_all[wv];               // volatile: the write / read-back pair must reach the LDS
+    volatile unsigned char* claim = claim_all[wv];                // volatile: the write / read-back pair must reach the LDS
     unsigned short* sbl = sbl_all[wv];
     const int64_t HW = (int64_t)H * W;
     const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fty0 = (float)ty0, fty1 = (float)(ty0 + TH - 1);
@@ -336,9 +336,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     auto scatter = [&](bool active, int cell, float w, const float (&v)[CA]) __attribute__((always_inline)) {
         bool pending = active;
         while (__ballot(pending)) {
-            if (pending) claim[cell] = (unsigned short)lane;
+            if (pending) claim[cell] = (unsigned char)lane;
             bool owner = false;
-            if (pending) owner = claim[cell] == (unsigned short)lane;
+            if (pending) owner = claim[cell] == (unsigned char)lane;
             if (owner) {
                 float cur[CA];
 #pragma unroll
@@ -614,9 +614,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 template <int MODE>
 static void splat_band_launch(const float* img, const float* flow, const float* metric, const float* blk, const float* sbt,
                               float* out, int N, int C, int H, int W, int nsb_x, int nsb, hipStream_t s) {
-    if (C <= 3) {                  // images: 3 channels + normalisation, 128 x 8 band per wave (18 KB of LDS per wave)
-        dim3 grid(fldr_cdiv(W, 128), fldr_cdiv(H, 4 * 8), N);
-        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, 128, 8>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
+    if (C <= 3) {                  // images: 3 channels + normalisation, 128 x 6 band per wave (12.75 KB of LDS per wave: 3 workgroups per CU)
+        dim3 grid(fldr_cdiv(W, 128), fldr_cdiv(H, 4 * 6), N);
+        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, 128, 6>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
     } else {                       // feature maps: groups of 12 channels, 64 x 4 band per wave (13.5 KB)
         const int groups = fldr_cdiv(C, 12);
         dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 4), N * groups);
