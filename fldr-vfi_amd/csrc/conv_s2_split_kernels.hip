@@ -1,0 +1,407 @@
+// 4x4 / stride 2 / pad 1 convolutions (the UNet encoders, fLDRnet.py:611-613) on the fp16 matrix cores with the 3 x fp16
+// split of conv_split_kernels.hip (x = hi + lo, hi*hi + hi*lo + lo*hi, fp32 accumulation: fp32-equivalent accuracy).
+//
+// The exact fp32-MFMA kernel (conv_kernels.hip) is matrix-pipe bound on these layers (enc1: 76 % pipe busy at the clock the
+// chip holds, 474 us against a 210 us HBM floor); here the matrix time drops 5.3x and the layer is bound by its 1 GB of
+// plane traffic.  Same workgroup geometry as that kernel: 256 threads = 4 waves, an 8 x 32 output tile x all (<= 64)
+// output channels, input channels in chunks of 4 staged through two LDS stages (weights by LDS-DMA, inputs prefetched into
+// registers one chunk ahead: multi-source concat and zero padding resolved at load time).
+//
+// LDS input image per channel and per half (hi, lo): dwords [row pair][column parity][column / 2], each dword = the two rows of
+// the pair as halves.  An output pixel (y, x) reads input rows 2y-1..2y+2 = row pairs y, y+1 and columns 2x-1..2x+2 =
+// {even plane, odd plane} x indices {x, x+1} of the tile-local image, so ONE MFMA B operand (8 halves = 4 dwords) is a row
+// pair x 4 columns = two ds_read2_b32 with no VALU work: the split happens once per staged element, not per use.
+//   16x16x32 (cout <= 16): lane group g = lane / 16 -> (channel g / 2 of the step's pair, row pair g % 2): 2 steps per chunk
+//   32x32x16 (cout <= 64): lane group g = lane / 32 -> row pair g of the step's channel:                    4 steps per chunk
+// k slot j of a lane: dword j / 2 in the order (even x, even x+1, odd x, odd x+1) = kernel column dx {1, 3, 0, 2}... see
+// s2_tap() — the weight prepack uses the same function, so any consistent order works.
+#include "common.h"
+#include <type_traits>
+
+typedef _Float16 s2_h8 __attribute__((ext_vector_type(8)));
+typedef float s2_f4 __attribute__((ext_vector_type(4)));
+typedef float s2_f16 __attribute__((ext_vector_type(16)));
+typedef int s2_i4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* s2_gptr_t;
+typedef __attribute__((address_space(3))) void* s2_lptr_t;
+
+#define S2_HDR 8                       // floats before the packed weights: {1/scale, scale, max|w|, 0, 0,0,0,0}
+#define S2_CC 4                        // input channels per chunk
+#define S2_TH 8
+#define S2_TW 32
+#define S2_IH 18                       // (TH-1)*2 + 4
+#define S2_IW 66                       // (TW-1)*2 + 4
+#define S2_RP 9                        // row pairs
+#define S2_NI 19                       // ceil(IH*IW / 64) staged elements per lane and channel
+
+struct S2Args {
+    const float* src[FLDR_CONV_MAX_SRC];
+    int64_t src_bstride[FLDR_CONV_MAX_SRC];
+    int32_t src_cbegin[FLDR_CONV_MAX_SRC + 1];
+    int32_t n_src;
+    const float* wpack;
+    const float* bias;
+    float* out;                // fp32 NCHW or null
+    unsigned char* out_spk;    // split-packed or null
+    int32_t cin, cout, cout_store;
+    int32_t Hin, Win, Hout, Wout;
+    int32_t relu;
+    int32_t tiles_x;
+};
+
+// kernel tap (dy, dx) of k slot j (0..7) within row pair rp (0..1): dword d = j / 2 -> (parity, index offset); half j % 2 -> row
+__host__ __device__ __forceinline__ void s2_tap(int rp, int j, int& dy, int& dx) {
+    const int d = j >> 1;                      // 0: even plane, x; 1: even plane, x+1; 2: odd plane, x; 3: odd plane, x+1
+    const int parity = d >> 1, off = d & 1;
+    // tile-local column = 2*xl + dx with parity dx & 1 and index xl + (dx >> 1)
+    dx = parity + 2 * off;
+    dy = 2 * rp + (j & 1);
+}
+
+template <int MT, int NMT>
+struct S2Cfg {
+    static constexpr int KL = 64 / MT;                         // lane groups (k octets) per MFMA: 4 (16x16x32) or 2 (32x32x16)
+    static constexpr int CPS = KL / 2;                         // channels per MFMA step
+    static constexpr int STEPS = S2_CC / CPS;                  // 2 or 4
+    static constexpr int IWHP = 40;                            // dwords per (row pair, parity) line (33 used): the lane groups of a
+                                                               // 16x16x32 operand read land 16 banks apart (32x32x16: half overlap)
+    static constexpr int KIND = S2_RP * 2 * IWHP;              // dwords per channel and half
+    static constexpr int CHS = 2 * KIND;                       // dwords per channel (hi, lo): 1440 = 32 mod 64, so the four lane groups
+                                                               // of a 16x16x32 operand read ((channel, row pair) = +32, +16 banks) never collide
+    static constexpr int X_DW = S2_CC * CHS;                   // input dwords per stage
+    static constexpr int W_BYTES = STEPS * NMT * 2 * 1024;     // weights per chunk: [step][m][kind][lane][16 B]
+    static constexpr int STAGE_BYTES = W_BYTES + X_DW * 4;
+    static constexpr int LDS_BYTES = 2 * STAGE_BYTES;          // 54,272 B for cout <= 16: three workgroups per CU
+    static constexpr int NWI = (W_BYTES / 16 + 255) / 256;     // 16-B DMA pieces per thread per chunk
+};
+
+template <int MT, int NMT, int PT>
+__global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
+    using Cfg = S2Cfg<MT, NMT>;
+    constexpr int KL = Cfg::KL, STEPS = Cfg::STEPS, IWHP = Cfg::IWHP, KIND = Cfg::KIND, CHS = Cfg::CHS;
+    constexpr int TPR = S2_TW / MT, RPW = PT / TPR;            // pixel tiles per tile row, output rows per wave
+    static_assert(4 * RPW == S2_TH, "tile height");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n = blockIdx.y;
+    const int tile_y = blockIdx.x / a.tiles_x, tile_x = blockIdx.x % a.tiles_x;
+    const int oy0 = tile_y * S2_TH, ox0 = tile_x * S2_TW;
+    const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;            // pad = 1
+    const int lj = lane & (MT - 1), lg = lane / MT;
+
+    // ---- staging geometry (identical for every channel and chunk) ----
+    int g_off[S2_NI], l_half[S2_NI];
+    unsigned vmask = 0;
+#pragma unroll
+    for (int i = 0; i < S2_NI; ++i) {
+        const int e = lane + 64 * i;
+        const int y = e / S2_IW, x = e % S2_IW;
+        const int gy = iy0 + y, gx = ix0 + x;
+        const bool ok = e < S2_IH * S2_IW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+        vmask |= ok ? (1u << i) : 0u;
+        g_off[i] = ok ? gy * a.Win + gx : 0;
+        // half index inside a (channel, half) plane: dword ((y/2)*2 + (x&1)) * IWHP + x/2, half y&1
+        l_half[i] = e < S2_IH * S2_IW ? (((y >> 1) * 2 + (x & 1)) * IWHP + (x >> 1)) * 2 + (y & 1) : -1;
+    }
+
+    // ---- operand geometry ----
+    const int cps = KL / 2;
+    const int b_ch = cps == 2 ? (lg >> 1) : 0;                 // channel of the step's pair held by this lane group
+    const int b_rp = cps == 2 ? (lg & 1) : lg;                 // row pair
+    int boff[PT];                                             // dword offset of (row pair r + b_rp, even plane, xl) in a channel's hi plane
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int r = wave * RPW + p / TPR, xl = (p % TPR) * MT + lj;
+        boff[p] = b_ch * CHS + ((r + b_rp) * 2) * IWHP + xl;
+    }
+
+    typedef typename std::conditional<MT == 32, s2_f16, s2_f4>::type acc_t;
+    acc_t acc[NMT][PT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < (MT == 32 ? 16 : 4); ++r) acc[m][p][r] = 0.0f;
+
+    const int cin_pad = (a.cin + S2_CC - 1) / S2_CC * S2_CC;
+    const int n_chunks = cin_pad / S2_CC;
+
+    // per-channel plane pointers in VGPR lanes (lane l = channel l and l + 64), read back with v_readlane: no LDS table, no
+    // dynamically indexed kernel-argument reads in the loop
+    unsigned long long ctab_lo = 0, ctab_hi = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = lane + 64 * h;
+        unsigned long long e = 0;
+        if (c < a.cin) {
+            int s = 0;
+            while (s + 1 < a.n_src && c >= a.src_cbegin[s + 1]) ++s;
+            const float* base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(c - a.src_cbegin[s]) * a.Hin * a.Win;
+            e = (unsigned long long)reinterpret_cast<uintptr_t>(base);
+        }
+        if (h == 0) ctab_lo = e; else ctab_hi = e;
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    float pre[S2_NI];
+    auto issue_weights = [&](int chunk, unsigned char* stage) {
+        const unsigned char* g = reinterpret_cast<const unsigned char*>(a.wpack + S2_HDR) + (int64_t)chunk * Cfg::W_BYTES;
+#pragma unroll
+        for (int i = 0; i < Cfg::NWI; ++i) {
+            const int piece = i * 256 + wave * 64;                    // wave-uniform, x16 bytes
+            if ((piece + lane) * 16 < Cfg::W_BYTES)
+                __builtin_amdgcn_global_load_lds((s2_gptr_t)(g + (piece + lane) * 16), (s2_lptr_t)(stage + piece * 16), 16, 0, 0);
+        }
+    };
+    auto load_inputs = [&](int chunk, float (&dst)[S2_NI]) {      // wave w stages channel w of the chunk
+        const int c = chunk * S2_CC + wave_u;                     // wave-uniform
+        const unsigned long long t = c < 64 ? ctab_lo : ctab_hi;
+        const unsigned long long e = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(t >> 32), c & 63) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)t, c & 63);
+        const bool live = e != 0ull;
+        const float* base = reinterpret_cast<const float*>(static_cast<uintptr_t>(e));
+#pragma unroll
+        for (int i = 0; i < S2_NI; ++i) {
+            const bool ok = live && ((vmask >> i) & 1u);
+            float v = 0.0f;
+            if (ok) v = base[g_off[i]];
+            dst[i] = v;
+        }
+    };
+    auto store_inputs = [&](unsigned char* stage, const float (&src)[S2_NI]) {
+        _Float16* hi = reinterpret_cast<_Float16*>(stage + Cfg::W_BYTES) + wave * CHS * 2;
+        _Float16* lo = hi + KIND * 2;
+#pragma unroll
+        for (int i = 0; i < S2_NI; ++i) {
+            if (l_half[i] < 0) continue;
+            const float x = src[i];
+            const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);      // the split of conv_split_kernels.hip
+            hi[l_half[i]] = (_Float16)t;
+            lo[l_half[i]] = (_Float16)(x - t);
+        }
+    };
+
+    issue_weights(0, smem);
+    load_inputs(0, pre);
+    store_inputs(smem, pre);
+    __syncthreads();
+
+    // iteration ch: MFMAs on stage ch&1 while the weights of chunk ch+1 stream into the other stage by LDS-DMA and its inputs
+    // are prefetched into registers; after the MFMAs the registers are split and written; one barrier per chunk.
+    // (A two-chunk-deep register prefetch with counted waits was built and measured equal: the layer is bound by its plane
+    // traffic at ~2.5 TB/s, not by the exposed load latency.)
+    for (int ch = 0; ch < n_chunks; ++ch) {
+        unsigned char* cur = smem + (ch & 1) * Cfg::STAGE_BYTES;
+        unsigned char* nxt = smem + ((ch & 1) ^ 1) * Cfg::STAGE_BYTES;
+        const bool more = ch + 1 < n_chunks;
+        if (more) {                                               // stage nxt was last read in iteration ch-1 (barrier since)
+            issue_weights(ch + 1, nxt);
+            load_inputs(ch + 1, pre);
+        }
+        const int* xin = reinterpret_cast<const int*>(cur + Cfg::W_BYTES);
+        const unsigned char* win = cur + lane * 16;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            s2_h8 ah[NMT], al[NMT];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                ah[m] = *reinterpret_cast<const s2_h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+                al[m] = *reinterpret_cast<const s2_h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            }
+            const int cbase = s * cps * CHS;                        // first channel of this step
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int* q = xin + cbase + boff[p];
+                s2_i4 bhi, blo;
+                bhi[0] = q[0]; bhi[1] = q[1]; bhi[2] = q[IWHP]; bhi[3] = q[IWHP + 1];
+                blo[0] = q[KIND]; blo[1] = q[KIND + 1]; blo[2] = q[KIND + IWHP]; blo[3] = q[KIND + IWHP + 1];
+                const s2_h8 bh = __builtin_bit_cast(s2_h8, bhi), bl = __builtin_bit_cast(s2_h8, blo);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    if constexpr (MT == 32) {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m][p], 0, 0, 0);
+                    } else {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][p], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (more) store_inputs(nxt, pre);                         // split + LDS write of the registers prefetched above
+        __syncthreads();
+    }
+
+    // ---- epilogue: undo the weight scale, bias, ReLU, store (lane = pixel column, registers = output channels) ----
+    constexpr int NR = MT == 32 ? 16 : 4;
+    const float inv_scale = a.wpack[0];
+    const int64_t HWo = (int64_t)a.Hout * a.Wout;
+    float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
+    unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
+    const int lk = lg;
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int oy = oy0 + wave * RPW + p / TPR;
+        const int ox = ox0 + (p % TPR) * MT + lj;
+        const bool pix_ok = oy < a.Hout && ox < a.Wout;
+        const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m) {
+            float vv[NR];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                const int cb = co < a.cout ? co : a.cout - 1;
+                float v = acc[m][p][r] * inv_scale + (a.bias ? a.bias[cb] : 0.0f);
+                if (a.relu) v = fmaxf(v, 0.0f);
+                vv[r] = v;
+                if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+            }
+            if (spkn) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int r0 = 0; r0 < NR; r0 += 4) {
+                    const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                        const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+                        hi[r] = (_Float16)t;
+                        lo[r] = (_Float16)(x - t);
+                    }
+                    if (co0 < a.cout_store && pix_ok) {
+                        unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
+                        *reinterpret_cast<h4*>(q) = hi;
+                        *reinterpret_cast<h4*>(q + HWo * 16) = lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// prepack: max|w| -> power-of-two scale -> hi/lo halves in A-operand order [chunk][step][m][kind][lane][8 halves]
+// ------------------------------------------------------------------------------------------------
+static inline void s2_geometry(int cout, int& mt, int& nmt) {
+    if (cout <= 16) { mt = 16; nmt = 1; }
+    else if (cout <= 32) { mt = 32; nmt = 1; }
+    else { mt = 32; nmt = 2; }
+}
+
+__global__ void s2_absmax_kernel(const float* __restrict__ w, int64_t n, float* __restrict__ hdr) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x < S2_HDR) {
+        const float mx = red[0];
+        float scale = 1.0f;
+        if (mx > 0.0f) scale = exp2f(floorf(log2f(8192.0f / mx)));
+        const float v[S2_HDR] = {1.0f / scale, scale, mx, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        hdr[threadIdx.x] = v[threadIdx.x];
+    }
+}
+
+__global__ void s2_prepack_kernel(const float* __restrict__ w, float* __restrict__ wp, int cout, int cin, int mt, int nmt,
+                                  int64_t total_h8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-half element per thread
+    if (i >= total_h8) return;
+    const float scale = wp[1];
+    const int kl = 64 / mt, cps = kl / 2, steps = S2_CC / cps;
+    const int lane = (int)(i % 64);
+    const int kind = (int)((i / 64) % 2);
+    const int m = (int)((i / 128) % nmt);
+    const int s = (int)((i / (128 * nmt)) % steps);
+    const int chunk = (int)(i / ((int64_t)128 * nmt * steps));
+    const int li = lane % mt, lg = lane / mt;
+    const int co = m * mt + li;
+    const int c = chunk * S2_CC + s * cps + (cps == 2 ? (lg >> 1) : 0);
+    const int rp = cps == 2 ? (lg & 1) : lg;
+    s2_h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        int dy, dx;
+        s2_tap(rp, j, dy, dx);
+        const float x = (co < cout && c < cin) ? w[(((int64_t)co * cin + c) * 4 + dy) * 4 + dx] * scale : 0.0f;
+        const _Float16 h = (_Float16)x;
+        v[j] = kind == 0 ? h : (_Float16)(x - (float)h);
+    }
+    reinterpret_cast<s2_h8*>(wp + S2_HDR)[i] = v;
+}
+
+extern "C" int64_t fldr_conv_s2_prepack_size(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cout > 64 || cin > 112) return FLDR_E_ARG;
+    int mt, nmt;
+    s2_geometry(cout, mt, nmt);
+    const int n_chunks = (cin + S2_CC - 1) / S2_CC, steps = S2_CC / ((64 / mt) / 2);
+    return S2_HDR + (int64_t)n_chunks * steps * nmt * 2 * 64 * 4;        // floats
+}
+
+extern "C" int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(weight && wpack);
+    const int64_t total = fldr_conv_s2_prepack_size(cout, cin);
+    if (total < 0) return (int)total;
+    int mt, nmt;
+    s2_geometry(cout, mt, nmt);
+    const int64_t total_h8 = (total - S2_HDR) / 4;
+    hipLaunchKernelGGL(s2_absmax_kernel, dim3(1), dim3(256), 0, fldr_s(stream), weight, (int64_t)cout * cin * 16, wpack);
+    hipLaunchKernelGGL(s2_prepack_kernel, dim3(fldr_cdiv(total_h8, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin, mt, nmt,
+                       total_h8);
+    FLDR_LAUNCH_RET();
+}
+
+template <int MT, int NMT, int PT>
+static int s2_launch(S2Args& a, int N, hipStream_t s) {
+    using Cfg = S2Cfg<MT, NMT>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4x4s2_split_kernel<MT, NMT, PT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
+    const int tiles_y = fldr_cdiv(a.Hout, S2_TH);
+    hipLaunchKernelGGL((conv4x4s2_split_kernel<MT, NMT, PT>), dim3(a.tiles_x * tiles_y, N), dim3(256), Cfg::LDS_BYTES, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+// Same descriptor as fldr_conv2d (ksize 4, stride 2; no up2 sources, no residual); d->wpack from fldr_conv_s2_prepack.
+extern "C" int fldr_conv2d_s2_split(const fldr_conv_desc* d, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d && d->wpack && (d->out || d->out_spk) && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
+    FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= 112 && d->cout > 0 && d->cout <= 64 && !d->residual);
+    FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->ksize == 4 && d->stride == 2);
+    if (d->Hout != (d->Hin + 2 - 4) / 2 + 1 || d->Wout != (d->Win + 2 - 4) / 2 + 1) return FLDR_E_SHAPE;
+    S2Args a;
+    int csum = 0;
+    for (int s = 0; s < FLDR_CONV_MAX_SRC; ++s) {
+        const bool live = s < d->n_src;
+        if (live) { FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0 && !d->src_up2[s]); }
+        a.src[s] = live ? d->src[s] : nullptr;
+        a.src_bstride[s] = live ? d->src_bstride[s] : 0;
+        a.src_cbegin[s] = csum;
+        if (live) csum += d->src_c[s];
+    }
+    a.src_cbegin[FLDR_CONV_MAX_SRC] = csum;
+    if (csum != d->cin) return FLDR_E_SHAPE;
+    a.n_src = d->n_src;
+    a.wpack = d->wpack; a.bias = d->bias; a.out = d->out; a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
+    a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
+    a.Hin = d->Hin; a.Win = d->Win; a.Hout = d->Hout; a.Wout = d->Wout; a.relu = d->relu; a.tiles_x = 0;
+    int mt, nmt;
+    s2_geometry(d->cout, mt, nmt);
+    hipStream_t s = fldr_s(stream);
+    if (mt == 16) return s2_launch<16, 1, 4>(a, d->N, s);
+    if (nmt == 1) return s2_launch<32, 1, 2>(a, d->N, s);
+    return s2_launch<32, 2, 2>(a, d->N, s);
+}

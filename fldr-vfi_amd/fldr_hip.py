@@ -90,6 +90,9 @@ _SIGNATURES = {
     "fldr_conv_split_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
     "fldr_conv_split_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_conv_s2_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
+    "fldr_conv_s2_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
+    "fldr_conv2d_s2_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -416,6 +419,21 @@ def conv_split_prepack(weight):
     return wp
 
 
+def conv_s2_prepack(weight):
+    hit = getattr(weight, "_fldr_pack_s2", None)
+    if hit is not None and hit[0] == (weight._version, weight.data_ptr()):
+        return hit[1]
+    cout, cin, k, _ = weight.shape
+    n = lib().fldr_conv_s2_prepack_size(cout, cin)
+    if n < 0:
+        raise FldrError("unsupported convolution shape %s" % (tuple(weight.shape),))
+    w = weight.detach().contiguous()
+    wp = torch.empty(n, device=weight.device, dtype=torch.float32)
+    _check(lib().fldr_conv_s2_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, _stream()), "fldr_conv_s2_prepack")
+    weight._fldr_pack_s2 = ((weight._version, weight.data_ptr()), wp)
+    return wp
+
+
 def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=None, up2=None, out=None, precision=None,
            want_f32=True, want_spk=False):
     """conv(cat(srcs, 1)) with optional fused nearest-x2 read per source, ReLU and post-activation residual.
@@ -459,13 +477,15 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     if prec not in ("split", "fp32", "fp16"):
         raise ValueError("precision must be split, fp32 or fp16")
     split = prec in ("split", "fp16") and k == 3 and stride == 1
+    # stride-2 4x4 encoders: 3 x fp16 split as well unless exact fp32 is asked for ("fp16" has no hi-only variant here)
+    s2 = prec in ("split", "fp16") and k == 4 and stride == 2 and cout <= 64 and residual is None and not any(up2)
     if want_spk and split:
         raise FldrError("a split-packed output of a 3x3 stride-1 convolution comes from conv2d_spk")
     want_f32 = want_f32 or not want_spk or residual is not None
     outp = _spk_alloc(N, cs, Hout, Wout, srcs[0].device) if want_spk else None
     if out is None and want_f32:
         out = torch.empty(N, cs, Hout, Wout, device=srcs[0].device, dtype=torch.float32)
-    wp = conv_split_prepack(weight) if split else conv_prepack(weight)
+    wp = conv_split_prepack(weight) if split else (conv_s2_prepack(weight) if s2 else conv_prepack(weight))
     d.wpack = wp.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
     if residual is not None:
@@ -479,6 +499,8 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     d.ksize, d.stride, d.relu, d.precision = k, stride, int(bool(relu)), (1 if (split and prec == "fp16") else 0)
     if split:
         _check(lib().fldr_conv2d_split(ctypes.byref(d), _stream()), "fldr_conv2d_split")
+    elif s2:
+        _check(lib().fldr_conv2d_s2_split(ctypes.byref(d), _stream()), "fldr_conv2d_s2_split")
     else:
         _check(lib().fldr_conv2d(ctypes.byref(d), _stream()), "fldr_conv2d")
     if want_spk:

@@ -206,6 +206,12 @@ int64_t fldr_conv_split_prepack_size(int cout, int cin);
 int fldr_conv_split_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 
+/* The stride-2 4x4 convolutions (UNet encoders, fLDRnet.py:611-613) with the same 3 x fp16 split: fldr_conv_desc with ksize 4,
+ * stride 2, no x2 sources, no residual, cout <= 64; wpack from fldr_conv_s2_prepack; `out` and / or `out_spk`. */
+int64_t fldr_conv_s2_prepack_size(int cout, int cin);
+int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
+
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.
  * A logical [N,C,H,W] fp32 tensor is stored as [N][G=ceil(C/8)][hi,lo][H*W][8 x fp16] (x = hi + lo, 22 significant
  * bits; 4 B per element like fp32): the producer splits each value once and the consumer's staging becomes pure

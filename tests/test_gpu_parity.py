@@ -143,6 +143,26 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape):
             assert torch.equal(hip.conv2d([ref[:, half:]], w3, None, precision="split"), hip.conv2d_spk([gp.narrow(half, half)], w3, None))
 
 
+@pytest.mark.parametrize("shape", [([3, 3, 2, 5], 16, 40, 72, 1), ([16], 32, 34, 70, 2), ([32], 64, 48, 64, 1), ([26], 16, 50, 38, 1)])
+def test_stride2_split_conv_is_fp32_equivalent(hip, dev, shape):
+    """The 3 x fp16-split stride-2 4x4 convolution (UNet encoders) against an fp64 reference: error at the level of the exact
+    fp32-MFMA kernel; its split-packed twin equals fldr_spk_pack of its fp32 output."""
+    parts, cout, H, W, N = shape
+    g = _gen(51)
+    srcs = [torch.randn(N, c, H, W, generator=g) for c in parts]
+    cin = sum(parts)
+    wt = torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5
+    bs = torch.randn(cout, generator=g)
+    ref = F.relu(F.conv2d(torch.cat(srcs, 1).double(), wt.double(), bs.double(), stride=2, padding=1))
+    dsrc = [s.to(dev) for s in srcs]
+    a32 = hip.conv2d(dsrc, wt.to(dev), bs.to(dev), stride=2, relu=True, precision="fp32").double().cpu()
+    sp, spk = hip.conv2d(dsrc, wt.to(dev), bs.to(dev), stride=2, relu=True, precision="split", want_spk=True)
+    assert torch.equal(hip.spk_pack(sp).buf, spk.buf)
+    e32, esp = (a32 - ref).abs(), (sp.double().cpu() - ref).abs()
+    print("cin %3d cout %2d: mean|err| fp32-MFMA %.2e split %.2e ; max %.2e / %.2e" % (cin, cout, e32.mean(), esp.mean(), e32.max(), esp.max()))
+    assert esp.mean() <= 1.5 * e32.mean() + 1e-8 and esp.max() <= 2.0 * e32.max() + 1e-7
+
+
 def test_splat_and_correlation_backward(hip, oracle, dev):
     """fldr_softsplat_bwd / fldr_correlation_bwd against the oracle's restatement of the reference's backward kernels, and
     autograd through FunctionSoftsplat / FunctionCorrelation (the training-side use of the operators)."""
