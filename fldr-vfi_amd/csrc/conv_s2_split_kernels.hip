@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) void* s2_lptr_t;
 #define S2_IH 18                       // (TH-1)*2 + 4
 #define S2_IW 66                       // (TW-1)*2 + 4
 #define S2_RP 9                        // row pairs
-#define S2_NI 19                       // ceil(IH*IW / 64) staged elements per lane and channel
+#define S2_NI 10                       // ceil(RP*IW / 64) staged (row pair, column) items per lane and channel: 2 loads, 2 dword LDS writes each
 
 struct S2Args {
     const float* src[FLDR_CONV_MAX_SRC];
@@ -89,19 +89,23 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
     const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;            // pad = 1
     const int lj = lane & (MT - 1), lg = lane / MT;
 
-    // ---- staging geometry (identical for every channel and chunk) ----
-    int g_off[S2_NI], l_half[S2_NI];
-    unsigned vmask = 0;
+    // ---- staging geometry (identical for every channel and chunk): an item = one column of one row pair, i.e. exactly one
+    //      dword of the hi plane and one of the lo plane (the staging was the bottleneck of this kernel when every element was
+    //      converted and written on its own: 2 ds_write_b16 + 2 cvt per element against a 384-cycle MFMA phase per chunk) ----
+    int g_off0[S2_NI], g_off1[S2_NI], l_dw[S2_NI];
+    unsigned vmask0 = 0, vmask1 = 0;
 #pragma unroll
     for (int i = 0; i < S2_NI; ++i) {
         const int e = lane + 64 * i;
-        const int y = e / S2_IW, x = e % S2_IW;
-        const int gy = iy0 + y, gx = ix0 + x;
-        const bool ok = e < S2_IH * S2_IW && gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
-        vmask |= ok ? (1u << i) : 0u;
-        g_off[i] = ok ? gy * a.Win + gx : 0;
-        // half index inside a (channel, half) plane: dword ((y/2)*2 + (x&1)) * IWHP + x/2, half y&1
-        l_half[i] = e < S2_IH * S2_IW ? (((y >> 1) * 2 + (x & 1)) * IWHP + (x >> 1)) * 2 + (y & 1) : -1;
+        const int pr = e / S2_IW, x = e % S2_IW;
+        const int gy0 = iy0 + 2 * pr, gy1 = gy0 + 1, gx = ix0 + x;
+        const bool okx = e < S2_RP * S2_IW && gx >= 0 && gx < a.Win;
+        const bool ok0 = okx && gy0 >= 0 && gy0 < a.Hin, ok1 = okx && gy1 >= 0 && gy1 < a.Hin;
+        vmask0 |= ok0 ? (1u << i) : 0u;
+        vmask1 |= ok1 ? (1u << i) : 0u;
+        g_off0[i] = ok0 ? gy0 * a.Win + gx : 0;
+        g_off1[i] = ok1 ? gy1 * a.Win + gx : 0;
+        l_dw[i] = e < S2_RP * S2_IW ? (pr * 2 + (x & 1)) * IWHP + (x >> 1) : -1;      // dword inside a (channel, half) plane
     }
 
     // ---- operand geometry ----
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
     }
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-    float pre[S2_NI];
+    float pre[2 * S2_NI];
     auto issue_weights = [&](int chunk, unsigned char* stage) {
         const unsigned char* g = reinterpret_cast<const unsigned char*>(a.wpack + S2_HDR) + (int64_t)chunk * Cfg::W_BYTES;
 #pragma unroll
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
                 __builtin_amdgcn_global_load_lds((s2_gptr_t)(g + (piece + lane) * 16), (s2_lptr_t)(stage + piece * 16), 16, 0, 0);
         }
     };
-    auto load_inputs = [&](int chunk, float (&dst)[S2_NI]) {      // wave w stages channel w of the chunk
+    auto load_inputs = [&](int chunk, float (&dst)[2 * S2_NI]) {  // wave w stages channel w of the chunk
         const int c = chunk * S2_CC + wave_u;                     // wave-uniform
         const unsigned long long t = c < 64 ? ctab_lo : ctab_hi;
         const unsigned long long e = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(t >> 32), c & 63) << 32) |
@@ -163,22 +167,27 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
         const float* base = reinterpret_cast<const float*>(static_cast<uintptr_t>(e));
 #pragma unroll
         for (int i = 0; i < S2_NI; ++i) {
-            const bool ok = live && ((vmask >> i) & 1u);
-            float v = 0.0f;
-            if (ok) v = base[g_off[i]];
-            dst[i] = v;
+            float v0 = 0.0f, v1 = 0.0f;
+            if (live && ((vmask0 >> i) & 1u)) v0 = base[g_off0[i]];
+            if (live && ((vmask1 >> i) & 1u)) v1 = base[g_off1[i]];
+            dst[2 * i] = v0; dst[2 * i + 1] = v1;
         }
     };
-    auto store_inputs = [&](unsigned char* stage, const float (&src)[S2_NI]) {
-        _Float16* hi = reinterpret_cast<_Float16*>(stage + Cfg::W_BYTES) + wave * CHS * 2;
-        _Float16* lo = hi + KIND * 2;
+    auto store_inputs = [&](unsigned char* stage, const float (&src)[2 * S2_NI]) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2* hi = reinterpret_cast<h2*>(stage + Cfg::W_BYTES) + wave * CHS;
+        h2* lo = hi + KIND;
 #pragma unroll
         for (int i = 0; i < S2_NI; ++i) {
-            if (l_half[i] < 0) continue;
-            const float x = src[i];
-            const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);      // the split of conv_split_kernels.hip
-            hi[l_half[i]] = (_Float16)t;
-            lo[l_half[i]] = (_Float16)(x - t);
+            if (l_dw[i] < 0) continue;
+            const float x0 = src[2 * i], x1 = src[2 * i + 1];
+            const float t0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u);    // the split of conv_split_kernels.hip
+            const float t1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
+            h2 h, l;
+            h[0] = (_Float16)t0; h[1] = (_Float16)t1;
+            l[0] = (_Float16)(x0 - t0); l[1] = (_Float16)(x1 - t1);
+            hi[l_dw[i]] = h;                                                       // half 0 = the even row of the pair
+            lo[l_dw[i]] = l;
         }
     };
 
