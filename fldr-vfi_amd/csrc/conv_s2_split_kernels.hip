@@ -46,7 +46,7 @@ struct S2Args {
     int32_t cin, cout, cout_store;
     int32_t Hin, Win, Hout, Wout;
     int32_t relu;
-    int32_t tiles_x;
+    int32_t tiles_x, n_tiles, tiles_per_xcd;
 };
 
 // kernel tap (dy, dx) of k slot j (0..7) within row pair rp (0..1): dword d = j / 2 -> (parity, index offset); half j % 2 -> row
@@ -84,7 +84,11 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n = blockIdx.y;
-    const int tile_y = blockIdx.x / a.tiles_x, tile_x = blockIdx.x % a.tiles_x;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (b and b+8 share an L2), so XCD x gets the contiguous
+    // tile range [x*tpx, (x+1)*tpx): neighbouring tiles share their halo rows / columns (18 x 66 inputs per 16 x 64 core) in ONE L2.
+    const int tile = (blockIdx.x & 7) * a.tiles_per_xcd + (blockIdx.x >> 3);
+    if (tile >= a.n_tiles) return;                              // workgroup-uniform
+    const int tile_y = tile / a.tiles_x, tile_x = tile % a.tiles_x;
     const int oy0 = tile_y * S2_TH, ox0 = tile_x * S2_TW;
     const int iy0 = oy0 * 2 - 1, ix0 = ox0 * 2 - 1;            // pad = 1
     const int lj = lane & (MT - 1), lg = lane / MT;
@@ -198,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
 
     // iteration ch: MFMAs on stage ch&1 while the weights of chunk ch+1 stream into the other stage by LDS-DMA and its inputs
     // are prefetched into registers; after the MFMAs the registers are split and written; one barrier per chunk.
-    // (A two-chunk-deep register prefetch with counted waits was built and measured equal: the layer is bound by its plane
-    // traffic at ~2.5 TB/s, not by the exposed load latency.)
+    // (Built and measured equal or slower: a two-chunk-deep register prefetch with counted waits, 16-byte staging loads,
+    // unconditional clamped loads.  enc1 moves 1.06 GB in ~400 us.)
     for (int ch = 0; ch < n_chunks; ++ch) {
         unsigned char* cur = smem + (ch & 1) * Cfg::STAGE_BYTES;
         unsigned char* nxt = smem + ((ch & 1) ^ 1) * Cfg::STAGE_BYTES;
@@ -381,7 +385,9 @@ static int s2_launch(S2Args& a, int N, hipStream_t s) {
     }
     a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
     const int tiles_y = fldr_cdiv(a.Hout, S2_TH);
-    hipLaunchKernelGGL((conv4x4s2_split_kernel<MT, NMT, PT>), dim3(a.tiles_x * tiles_y, N), dim3(256), Cfg::LDS_BYTES, s, a);
+    a.n_tiles = a.tiles_x * tiles_y;
+    a.tiles_per_xcd = (a.n_tiles + 7) / 8;
+    hipLaunchKernelGGL((conv4x4s2_split_kernel<MT, NMT, PT>), dim3(8 * a.tiles_per_xcd, N), dim3(256), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }
 
