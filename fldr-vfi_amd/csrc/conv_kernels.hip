@@ -436,6 +436,7 @@ extern "C" int fldr_conv2d(const fldr_conv_desc* d, fldr_stream_t stream) {
     const int Ho = d->ksize == 3 ? d->Hin : (d->Hin + 2 - 4) / 2 + 1;
     const int Wo = d->ksize == 3 ? d->Win : (d->Win + 2 - 4) / 2 + 1;
     if (Ho != d->Hout || Wo != d->Wout) return FLDR_E_SHAPE;
+    for (int k = 0; k < d->n_src; ++k) if (d->src_cstride[k] != 0) return FLDR_E_ARG;      // channel-strided sources: fldr_conv2d_s2_split only
     ConvArgs a;
     int csum = 0;
     for (int s = 0; s < FLDR_CONV_MAX_SRC; ++s) {

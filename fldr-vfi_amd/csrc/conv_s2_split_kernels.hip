@@ -37,6 +37,7 @@ typedef __attribute__((address_space(3))) void* s2_lptr_t;
 struct S2Args {
     const float* src[FLDR_CONV_MAX_SRC];
     int64_t src_bstride[FLDR_CONV_MAX_SRC];
+    int64_t src_cstride[FLDR_CONV_MAX_SRC];            // floats between channel planes
     int32_t src_cbegin[FLDR_CONV_MAX_SRC + 1];
     int32_t n_src;
     const float* wpack;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
         if (c < a.cin) {
             int s = 0;
             while (s + 1 < a.n_src && c >= a.src_cbegin[s + 1]) ++s;
-            const float* base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(c - a.src_cbegin[s]) * a.Hin * a.Win;
+            const float* base = a.src[s] + (int64_t)n * a.src_bstride[s] + (int64_t)(c - a.src_cbegin[s]) * a.src_cstride[s];
             e = (unsigned long long)reinterpret_cast<uintptr_t>(base);
         }
         if (h == 0) ctab_lo = e; else ctab_hi = e;
@@ -404,6 +405,7 @@ extern "C" int fldr_conv2d_s2_split(const fldr_conv_desc* d, fldr_stream_t strea
         if (live) { FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0 && !d->src_up2[s]); }
         a.src[s] = live ? d->src[s] : nullptr;
         a.src_bstride[s] = live ? d->src_bstride[s] : 0;
+        a.src_cstride[s] = live ? (d->src_cstride[s] ? d->src_cstride[s] : (int64_t)d->Hin * d->Win) : 0;
         a.src_cbegin[s] = csum;
         if (live) csum += d->src_c[s];
     }

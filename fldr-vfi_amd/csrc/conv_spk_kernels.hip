@@ -546,7 +546,9 @@ __global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t
 }
 
 // sizeof of the descriptor structs as this library was compiled (binding self-check: tests/test_host_cpu.py)
-extern "C" int fldr_sizeof_desc(int which) { return which == 0 ? (int)sizeof(fldr_conv_desc) : which == 1 ? (int)sizeof(fldr_spk_conv_desc) : FLDR_E_ARG; }
+extern "C" int fldr_sizeof_desc(int which) {
+    return which == 0 ? (int)sizeof(fldr_conv_desc) : which == 1 ? (int)sizeof(fldr_spk_conv_desc) : which == 2 ? (int)sizeof(fldr_prep_desc) : FLDR_E_ARG;
+}
 
 extern "C" int64_t fldr_spk_bytes(int C, int H, int W) {
     if (C <= 0 || H <= 0 || W <= 0) return FLDR_E_ARG;

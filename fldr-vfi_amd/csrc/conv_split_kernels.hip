@@ -445,6 +445,7 @@ extern "C" int fldr_conv2d_split(const fldr_conv_desc* d, fldr_stream_t stream) 
     FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= SP_MAX_CIN && d->cout > 0 && d->cout <= 96);
     FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->ksize == 3 && d->stride == 1);
     if (d->Hout != d->Hin || d->Wout != d->Win) return FLDR_E_SHAPE;
+    for (int k = 0; k < d->n_src; ++k) if (d->src_cstride[k] != 0) return FLDR_E_ARG;      // channel-strided sources: fldr_conv2d_s2_split only
     SplitArgs a;
     int csum = 0;
     for (int s = 0; s < d->n_src; ++s) {

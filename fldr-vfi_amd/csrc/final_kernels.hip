@@ -36,6 +36,7 @@ __global__ void dec3_prepack_kernel(const float* __restrict__ w, float* __restri
 struct FinalArgs {
     const float* cand[6];
     int64_t bstride[6];
+    int64_t cstride[6];          // floats between the 3 channel planes of a candidate
 };
 
 template <typename OUT>
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
         for (int k = 0; k < 6; ++k)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
-                cv[k][ch] = *reinterpret_cast<const float2*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * HW + po);
+                cv[k][ch] = *reinterpret_cast<const float2*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k] + po);
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma clang fp contract(off)
@@ -151,19 +152,28 @@ extern "C" int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t
     FLDR_LAUNCH_RET();
 }
 
-extern "C" int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
-                               const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
-                               float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream) {
-    FLDR_CHECK_ARG(d2 && weff && bias && cand && cand_bstride && t && N > 0 && H > 0 && W > 0);
+extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+                                       const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t,
+                                       double T_param, double* out_f64, float* out_f32, float* refine_out_or_null, int N,
+                                       int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d2 && weff && bias && cand && cand_bstride && cand_cstride && t && N > 0 && H > 0 && W > 0);
     FLDR_CHECK_ARG((out_f64 != nullptr) != (out_f32 != nullptr));
     if ((H | W) & 1) return FLDR_E_SHAPE;
     FinalArgs a;
     for (int k = 0; k < 6; ++k) {
-        FLDR_CHECK_ARG(cand[k] && (((uintptr_t)cand[k]) & 7) == 0 && (cand_bstride[k] & 1) == 0);
-        a.cand[k] = cand[k]; a.bstride[k] = cand_bstride[k];
+        FLDR_CHECK_ARG(cand[k] && (((uintptr_t)cand[k]) & 7) == 0 && (cand_bstride[k] & 1) == 0 && (cand_cstride[k] & 1) == 0);
+        a.cand[k] = cand[k]; a.bstride[k] = cand_bstride[k]; a.cstride[k] = cand_cstride[k];
     }
     dim3 grid(fldr_cdiv(W / 2, D3_TW), fldr_cdiv(H / 2, D3_TH), N);
     if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W);
     else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W);
     FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+                               const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
+                               float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream) {
+    const int64_t HW = (int64_t)H * W;
+    const int64_t cs[6] = {HW, HW, HW, HW, HW, HW};
+    return fldr_dec3_synth_strided(d2, weff, bias, cand, cand_bstride, cs, t, T_param, out_f64, out_f32, refine_out_or_null, N, H, W, stream);
 }

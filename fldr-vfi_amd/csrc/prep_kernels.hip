@@ -13,7 +13,8 @@
 struct PrepArgs {
     const float4* flow_lo4;        // [N,h,w] x (flow_10.x, flow_10.y, flow_01.x, flow_01.y): one 16-B load per low-resolution pixel
     const float* I0; const float* I1;
-    int64_t i0_bstride, i1_bstride;   // floats between samples ([3,H,W] blocks are contiguous)
+    int64_t i0_bstride, i1_bstride;   // floats between samples
+    int64_t i0_cstride, i1_cstride;   // floats between channel planes
     const float* t;                // [N]
     float* z0; float* z1;          // [N,1,H,W] or null (both or neither)
     float* flow_t0; float* flow_t1; float* flowback_0; float* flowback_1;   // [N,2,H,W]
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     // the frames at this pixel (direct reads, issued first)
     float c0[3], c1[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { c0[c] = i0[(int64_t)c * HW + pix]; c1[c] = i1[(int64_t)c * HW + pix]; }
+    for (int c = 0; c < 3; ++c) { c0[c] = i0[(int64_t)c * a.i0_cstride + pix]; c1[c] = i1[(int64_t)c * a.i1_cstride + pix]; }
 
     // upsampled flows at this pixel (fLDRnet.py:419-422)
     const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float w0 = fldr_tap_sample(t0, i1 + (int64_t)c * HW, a.W, a.H) * m0;
-            const float w1 = fldr_tap_sample(t1, i0 + (int64_t)c * HW, a.W, a.H) * m1;
+            const float w0 = fldr_tap_sample(t0, i1 + (int64_t)c * a.i1_cstride, a.W, a.H) * m0;
+            const float w1 = fldr_tap_sample(t1, i0 + (int64_t)c * a.i0_cstride, a.W, a.H) * m1;
             acc0 += a.za0 * fabsf(c0[c] - w0);
             acc1 += a.za1 * fabsf(c1[c] - w1);
         }
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     const int64_t o3 = (int64_t)n * 3 * HW + pix;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        a.im0_tot[o3 + (int64_t)c * HW] = fldr_tap_sample(ti0, i0 + (int64_t)c * HW, a.W, a.H) * mi0;
-        a.im1_tot[o3 + (int64_t)c * HW] = fldr_tap_sample(ti1, i1 + (int64_t)c * HW, a.W, a.H) * mi1;
+        a.im0_tot[o3 + (int64_t)c * HW] = fldr_tap_sample(ti0, i0 + (int64_t)c * a.i0_cstride, a.W, a.H) * mi0;
+        a.im1_tot[o3 + (int64_t)c * HW] = fldr_tap_sample(ti1, i1 + (int64_t)c * a.i1_cstride, a.W, a.H) * mi1;
     }
 }
 
@@ -166,6 +167,7 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d->im0_tot && d->im1_tot && (!d->z0 == !d->z1) && d->N > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0);
     PrepArgs a;
     a.flow_lo4 = reinterpret_cast<const float4*>(d->ws); a.I0 = d->I0; a.I1 = d->I1; a.i0_bstride = d->i0_bstride; a.i1_bstride = d->i1_bstride;
+    a.i0_cstride = d->i0_cstride ? d->i0_cstride : (int64_t)d->H * d->W; a.i1_cstride = d->i1_cstride ? d->i1_cstride : (int64_t)d->H * d->W;
     a.t = d->t; a.z0 = d->z0; a.z1 = d->z1; a.flow_t0 = d->flow_t0; a.flow_t1 = d->flow_t1;
     a.flowback_0 = d->flowback_0; a.flowback_1 = d->flowback_1; a.im0_tot = d->im0_tot; a.im1_tot = d->im1_tot;
     a.h = d->h; a.w = d->w; a.H = d->H; a.W = d->W;

@@ -124,7 +124,8 @@ __device__ __forceinline__ bool st_match(const float4 b, float rx0, float rx1, f
 // mode: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ 1 normalisation accumulator
 // when MODE >= 1); channel group = blockIdx.z % groups.
 template <int MODE, int CB, int TW, int TH>
-__global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+__global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict__ in, int64_t in_bstride, int64_t in_cstride,
+                                                         const float* __restrict__ flow,
                                                          const float* __restrict__ metric, const float* __restrict__ blk,
                                                          const float* __restrict__ sbt, float* __restrict__ out,
                                                          int C, int H, int W, int groups, int nsb_x, int nsb) {
@@ -180,7 +181,7 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
 
     const float* fl = flow + (int64_t)n * 2 * HW;
     const float* mt = metric ? metric + (int64_t)n * HW : nullptr;
-    const float* inn = in + (int64_t)n * C * HW;
+    const float* inn = in + (int64_t)n * in_bstride;              // channel planes in_cstride floats apart (views of [B,3,2,H,W])
 
     // ---- accumulate: thread = one source pixel of a block (wave = one 64-pixel row), ST_U blocks in flight ----
     for (int q0 = 0; q0 < n_blk; q0 += ST_U) {
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
                 const int cc = cbase + c < C ? cbase + c : C - 1;
-                val[u][c] = inn[(int64_t)cc * HW + pix];
+                val[u][c] = inn[(int64_t)cc * in_cstride + pix];
             }
         }
 #pragma unroll
@@ -296,7 +297,8 @@ __device__ __forceinline__ int st_shl1(int v) { return __builtin_amdgcn_update_d
 __device__ __forceinline__ float st_shr1(float v) { return __int_as_float(st_shr1(__float_as_int(v))); }
 
 template <int MODE, int CB, int TW, int TH>
-__global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict__ in, const float* __restrict__ flow,
+__global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict__ in, int64_t in_bstride, int64_t in_cstride,
+                                                         const float* __restrict__ flow,
                                                          const float* __restrict__ metric, const float* __restrict__ blk,
                                                          const float* __restrict__ sbt, float* __restrict__ out,
                                                          int C, int H, int W, int groups, int nsb_x, int nsb) {
@@ -330,7 +332,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 
     const float* fl = flow + (int64_t)n * 2 * HW;
     const float* mt = metric ? metric + (int64_t)n * HW : nullptr;
-    const float* inn = in + (int64_t)n * C * HW;
+    const float* inn = in + (int64_t)n * in_bstride;              // channel planes in_cstride floats apart (views of [B,3,2,H,W])
 
     // one corner of one source row: claim, then read-modify-write by the owners; repeat for the lanes that lost
     auto scatter = [&](bool active, int cell, float w, const float (&v)[CA]) __attribute__((always_inline)) {
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
                 const int cc = cbase + c < C ? cbase + c : C - 1;
-                val[buf][r][c] = inn[(int64_t)cc * HW + pix];
+                val[buf][r][c] = inn[(int64_t)cc * in_cstride + pix];
             }
         }
     };
@@ -612,15 +614,15 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 }
 
 template <int MODE>
-static void splat_band_launch(const float* img, const float* flow, const float* metric, const float* blk, const float* sbt,
+static void splat_band_launch(const float* img, int64_t ibs, int64_t ics, const float* flow, const float* metric, const float* blk, const float* sbt,
                               float* out, int N, int C, int H, int W, int nsb_x, int nsb, hipStream_t s) {
     if (C <= 3) {                  // images: 3 channels + normalisation, 128 x 6 band per wave (12.75 KB of LDS per wave: 3 workgroups per CU)
         dim3 grid(fldr_cdiv(W, 128), fldr_cdiv(H, 4 * 6), N);
-        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, 128, 6>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
+        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, 128, 6>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
     } else {                       // feature maps: groups of 12 channels, 64 x 4 band per wave (13.5 KB)
         const int groups = fldr_cdiv(C, 12);
         dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 4), N * groups);
-        hipLaunchKernelGGL((splat_band_kernel<MODE, 12, 64, 4>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
+        hipLaunchKernelGGL((splat_band_kernel<MODE, 12, 64, 4>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
     }
 }
 
@@ -631,15 +633,15 @@ extern "C" int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W) {
 }
 
 template <int MODE>
-static void splat_tile_launch(const float* img, const float* flow, const float* metric, const float* blk, const float* sbt,
+static void splat_tile_launch(const float* img, int64_t ibs, int64_t ics, const float* flow, const float* metric, const float* blk, const float* sbt,
                               float* out, int N, int C, int H, int W, int nsb_x, int nsb, hipStream_t s) {
     if (C <= 3) {                  // images: every channel + the normalisation accumulator in one 128 x 32 tile (64 KB of LDS)
         dim3 grid(fldr_cdiv(W, 128), fldr_cdiv(H, 32), N);
-        hipLaunchKernelGGL((splat_tile_kernel<MODE, 3, 128, 32>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
+        hipLaunchKernelGGL((splat_tile_kernel<MODE, 3, 128, 32>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
     } else {                       // feature maps: groups of 12 channels, 64 x 16 tiles (52 KB)
         const int groups = fldr_cdiv(C, 12);
         dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 16), N * groups);
-        hipLaunchKernelGGL((splat_tile_kernel<MODE, 12, 64, 16>), grid, dim3(256), 0, s, img, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
+        hipLaunchKernelGGL((splat_tile_kernel<MODE, 12, 64, 16>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
     }
 }
 
@@ -647,8 +649,19 @@ static void splat_tile_launch(const float* img, const float* flow, const float* 
 static int g_splat_tile_variant = 1;     // 0: LDS-atomic tiles, 1: claim-and-add bands
 extern "C" int fldr_debug_splat_tile_variant(int v) { if (v == 0 || v == 1) g_splat_tile_variant = v; return g_splat_tile_variant; }
 
+extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                           const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                           fldr_stream_t stream);
+
 extern "C" int fldr_softsplat_tile(const float* img, const float* flow, const float* metric, float* out, float* ws,
                                    int N, int C, int H, int W, int mode, fldr_stream_t stream) {
+    return fldr_softsplat_tile_strided(img, (int64_t)C * H * W, (int64_t)H * W, flow, metric, out, ws, N, C, H, W, mode, stream);
+}
+
+// img: sample n, channel c at img + n*img_bstride + c*img_cstride (floats), each [H,W] plane contiguous.
+extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                           const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                           fldr_stream_t stream) {
     FLDR_CHECK_ARG(img && flow && out && ws && N > 0 && C > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 3);
     FLDR_CHECK_ARG(mode != 2 || metric != nullptr);
     if (W > 65535 * ST_BW || H > 32767 * ST_BH) return FLDR_E_SHAPE;
@@ -660,18 +673,18 @@ extern "C" int fldr_softsplat_tile(const float* img, const float* flow, const fl
     hipLaunchKernelGGL(splat_bounds_kernel, dim3(nsb, N), dim3(256), 0, s, flow, blk, sbt, H, W, nsb_x, nsb);
     if (g_splat_tile_variant == 1) {
         switch (mode) {
-            case 0: splat_band_launch<0>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
-            case 1: splat_band_launch<1>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
-            case 2: splat_band_launch<2>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
-            default: splat_band_launch<3>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            case 0: splat_band_launch<0>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            case 1: splat_band_launch<1>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            case 2: splat_band_launch<2>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+            default: splat_band_launch<3>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
         }
         FLDR_LAUNCH_RET();
     }
     switch (mode) {
-        case 0: splat_tile_launch<0>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
-        case 1: splat_tile_launch<1>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
-        case 2: splat_tile_launch<2>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
-        default: splat_tile_launch<3>(img, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+        case 0: splat_tile_launch<0>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+        case 1: splat_tile_launch<1>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+        case 2: splat_tile_launch<2>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
+        default: splat_tile_launch<3>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
     }
     FLDR_LAUNCH_RET();
 }

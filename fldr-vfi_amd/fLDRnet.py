@@ -271,8 +271,8 @@ class DCTVFInet(nn.Module):
         # come out of the same pass.  t-scaling happens on the low-resolution flows as in the reference (:404-422).
         inv = cache.get("level0") if cache is not None else None
         if inv is None:
-            I0 = x_l[:, :, 0].contiguous()
-            I1 = x_l[:, :, 1].contiguous()
+            I0 = x_l[:, :, 0]          # views of [B,3,2,H,W]: every consumer below takes batch / channel strides, no copies
+            I1 = x_l[:, :, 1]
         else:
             I0, I1, z0, z1 = inv
         r = fldr_hip.level0_prep(flow_l, I0, I1, t4, H, W, za0, za1, withmask=mask,

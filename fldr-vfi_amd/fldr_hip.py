@@ -33,6 +33,7 @@ class ConvDesc(ctypes.Structure):
         ("Hin", ctypes.c_int32), ("Win", ctypes.c_int32), ("Hout", ctypes.c_int32), ("Wout", ctypes.c_int32),
         ("ksize", ctypes.c_int32), ("stride", ctypes.c_int32), ("relu", ctypes.c_int32), ("precision", ctypes.c_int32),
         ("out_spk", ctypes.c_void_p),
+        ("src_cstride", ctypes.c_int64 * MAX_SRC),
     ]
 
 
@@ -46,6 +47,7 @@ class PrepDesc(ctypes.Structure):
         ("N", ctypes.c_int32), ("h", ctypes.c_int32), ("w", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
         ("mul", ctypes.c_float), ("z_alpha0", ctypes.c_float), ("z_alpha1", ctypes.c_float), ("withmask", ctypes.c_int32),
         ("ws", ctypes.c_void_p),
+        ("i0_cstride", ctypes.c_int64), ("i1_cstride", ctypes.c_int64),
     ]
 
 
@@ -74,6 +76,8 @@ _SIGNATURES = {
     "fldr_softsplat_fused_spk": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_softsplat_tile_strided": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64] + [_c_float_p] * 4 + [ctypes.c_int] * 5
+                                    + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_softsplat_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -106,6 +110,9 @@ _SIGNATURES = {
     "fldr_dec3_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
     "fldr_dec3_synth": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fldr_dec3_synth_strided": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                               ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p,
+                                               _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_frame_metrics": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -154,6 +161,20 @@ def _dev(t, name, dtype=torch.float32):
     if not t.is_contiguous():
         raise ValueError("%s must be contiguous" % name)
     return ctypes.c_void_p(t.data_ptr())
+
+
+def _planes(t, name):
+    """A [N,C,H,W] fp32 device tensor as (tensor, batch stride, channel stride) in floats for the entry points that take
+    channel-strided images: views whose [H,W] planes are contiguous (x_l[0][:, :, 0] of the [B,3,2,H,W] frames,
+    fLDRnet.py:130-131) pass through, anything else is copied."""
+    if not t.is_cuda:
+        raise NotImplementedError("%s: fldr_hip has no CPU path (the reference has none either, softSplat.py:251-252)" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    N, C, H, W = t.shape
+    if not ((W == 1 or t.stride(3) == 1) and (H == 1 or t.stride(2) == W)):
+        t = t.contiguous()
+    return t, (t.stride(0) if N > 1 else 0), (t.stride(1) if C > 1 else H * W)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -216,9 +237,23 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
     """FunctionSoftsplat (softSplat.py:320-352).  want_spk: return the result split-packed (Spk) instead of fp32 NCHW."""
     N, C, H, W = img.shape
     assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W
-    img, flow = img.contiguous(), flow.contiguous()
+    flow = flow.contiguous()
     if metric is not None:
         metric = metric.contiguous()
+    kern = kernel or SPLAT_KERNEL
+    if kern == "auto":
+        kern = "tile" if C <= 3 else "strip"
+    if kern == "tile" and not want_spk:
+        img, ibs, ics = _planes(img, "img")
+        ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
+        if out is None:
+            out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
+        _check(lib().fldr_softsplat_tile_strided(ctypes.c_void_p(img.data_ptr()), ibs, ics, _dev(flow, "flow"),
+                                                 _dev(metric, "metric") if metric is not None else None,
+                                                 _dev(out, "out"), _dev(ws, "ws"), N, C, H, W, _MODES[mode], _stream()),
+               "fldr_softsplat_tile_strided")
+        return out
+    img = img.contiguous()
     if want_spk:
         ca = C + (0 if mode == "summation" else 1)
         scratch = torch.empty(N * ca * H * W, device=img.device, dtype=torch.float32)
@@ -228,18 +263,6 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
                                               ctypes.c_void_p(outp.buf.data_ptr()), _dev(scratch, "scratch"), N, C, H, W,
                                               _MODES[mode], _stream()), "fldr_softsplat_fused_spk")
         return outp
-    kern = kernel or SPLAT_KERNEL
-    if kern == "auto":
-        kern = "tile" if C <= 3 else "strip"
-    if kern == "tile":
-        ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
-        if out is None:
-            out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
-        _check(lib().fldr_softsplat_tile(_dev(img, "img"), _dev(flow, "flow"),
-                                         _dev(metric, "metric") if metric is not None else None,
-                                         _dev(out, "out"), _dev(ws, "ws"), N, C, H, W, _MODES[mode], _stream()),
-               "fldr_softsplat_tile")
-        return out
     ca = C + (0 if mode == "summation" else 1)
     if scratch is None:
         scratch = torch.empty(N * ca * H * W, device=img.device, dtype=torch.float32)
@@ -335,15 +358,13 @@ def resize_bilinear(x, H, W, mul=1.0):
 
 def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True):
     """fLDRnet.py:400-479 minus the splats in one kernel.  flow_lo [N,4,h,w]; I0 / I1 [N,3,H,W] (batch-strided views of
-    the [N,3,2,H,W] level-0 tensor are fine when each sample's [3,H,W] block is contiguous).
+    the [N,3,2,H,W] level-0 tensor, e.g. x[:, :, 0], are read in place: batch and channel strides are passed down).
     -> dict(z0, z1 (None unless want_z), flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot)."""
     N, four, h, w = flow_lo.shape
     assert four == 4 and I0.shape == (N, 3, H, W) and I1.shape == (N, 3, H, W)
     flow_lo = flow_lo.contiguous()
-    if not I0[0].is_contiguous():
-        I0 = I0.contiguous()
-    if not I1[0].is_contiguous():
-        I1 = I1.contiguous()
+    I0, i0b, i0c = _planes(I0, "I0")
+    I1, i1b, i1c = _planes(I1, "I1")
     dev = flow_lo.device
     e = lambda c: torch.empty(N, c, H, W, device=dev, dtype=torch.float32)
     out = {"z0": e(1) if want_z else None, "z1": e(1) if want_z else None, "flow_t0": e(2), "flow_t1": e(2),
@@ -352,8 +373,7 @@ def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True):
     d = PrepDesc()
     d.flow_lo = _dev(flow_lo, "flow_lo").value
     d.I0, d.I1 = I0.data_ptr(), I1.data_ptr()
-    d.i0_bstride = I0.stride(0) if N > 1 else 0
-    d.i1_bstride = I1.stride(0) if N > 1 else 0
+    d.i0_bstride, d.i1_bstride, d.i0_cstride, d.i1_cstride = i0b, i1b, i0c, i1c
     d.t = _dev(t, "t").value
     for k, v in out.items():
         setattr(d, k, v.data_ptr() if v is not None else None)
@@ -450,12 +470,20 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     d = ConvDesc()
     keep = []
     csum = 0
+    prec = precision or CONV_PRECISION
+    if prec not in ("split", "fp32", "fp16"):
+        raise ValueError("precision must be split, fp32 or fp16")
+    split = prec in ("split", "fp16") and k == 3 and stride == 1
+    # stride-2 4x4 encoders: 3 x fp16 split as well unless exact fp32 is asked for ("fp16" has no hi-only variant here)
+    s2 = prec in ("split", "fp16") and k == 4 and stride == 2 and cout <= 64 and residual is None and not any(up2)
     for i, (s, u) in enumerate(zip(srcs, up2)):
         if not s.is_cuda:
             raise NotImplementedError("fldr conv2d has no CPU path")
         if s.dtype != torch.float32:
             raise TypeError("conv source must be float32")
-        if s[0].is_contiguous() is False:
+        if s2:
+            s, _, d.src_cstride[i] = _planes(s, "conv source")          # channel-strided views (I0 / I1) are read in place
+        elif s[0].is_contiguous() is False:
             s = s.contiguous()
         keep.append(s)
         assert s.shape[0] == N and s.shape[2] * (2 if u else 1) == Hin and s.shape[3] * (2 if u else 1) == Win
@@ -473,12 +501,6 @@ def conv2d(srcs, weight, bias, stride=1, relu=False, residual=None, cout_store=N
     else:
         raise FldrError("unsupported convolution k=%d stride=%d" % (k, stride))
     cs = cout if cout_store is None else cout_store
-    prec = precision or CONV_PRECISION
-    if prec not in ("split", "fp32", "fp16"):
-        raise ValueError("precision must be split, fp32 or fp16")
-    split = prec in ("split", "fp16") and k == 3 and stride == 1
-    # stride-2 4x4 encoders: 3 x fp16 split as well unless exact fp32 is asked for ("fp16" has no hi-only variant here)
-    s2 = prec in ("split", "fp16") and k == 4 and stride == 2 and cout <= 64 and residual is None and not any(up2)
     if want_spk and split:
         raise FldrError("a split-packed output of a 3x3 stride-1 convolution comes from conv2d_spk")
     want_f32 = want_f32 or not want_spk or residual is not None
@@ -666,22 +688,21 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
     d2 = d2.contiguous()
     ptrs = (ctypes.c_void_p * 6)()
     strides = (ctypes.c_int64 * 6)()
+    cstrides = (ctypes.c_int64 * 6)()
     keep = []
     for k, c in enumerate(cands):
         assert c.shape == (N, 3, H, W)
-        if not c[0].is_contiguous():
-            c = c.contiguous()
+        c, strides[k], cstrides[k] = _planes(c, "candidate")
         keep.append(c)
-        ptrs[k] = _dev(c[0], "candidate").value
-        strides[k] = c.stride(0) if N > 1 else 0
+        ptrs[k] = c.data_ptr()
     t = t.reshape(N).contiguous().float()
     out = torch.empty(N, 3, H, W, device=d2.device, dtype=out_dtype)
     refine = torch.empty(N, 6, H, W, device=d2.device, dtype=torch.float32) if want_refine else None
     o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
     o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
-    _check(lib().fldr_dec3_synth(_dev(d2, "d2"), _dev(weff, "weff"), _dev(bias.detach(), "bias"), ptrs, strides, _dev(t, "t"),
-                                 float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None, N, H, W, _stream()),
-           "fldr_dec3_synth")
+    _check(lib().fldr_dec3_synth_strided(_dev(d2, "d2"), _dev(weff, "weff"), _dev(bias.detach(), "bias"), ptrs, strides, cstrides,
+                                         _dev(t, "t"), float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None,
+                                         N, H, W, _stream()), "fldr_dec3_synth_strided")
     return (out, refine) if want_refine else out
 
 

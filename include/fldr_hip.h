@@ -66,6 +66,12 @@ int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* m
 int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W);
 int fldr_softsplat_tile(const float* img, const float* flow, const float* metric_or_null, float* out, float* ws,
                         int N, int C, int H, int W, int mode, fldr_stream_t stream);
+/* The same with a strided image: sample n, channel c at img + n*img_bstride + c*img_cstride (floats), each [H,W] plane
+ * contiguous — the frames I0 / I1 are the views x_l[0][:, :, 0] / [:, :, 1] of the [B,3,2,H,W] input (fLDRnet.py:130-131)
+ * and need no copy. */
+int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * PWC cost volume — replaces OpticalFlow/correlation.py (forward only).
@@ -156,6 +162,7 @@ typedef struct fldr_prep_desc {
     float z_alpha0, z_alpha1;
     int32_t withmask;                /* not args.outMaskLess */
     float* ws;                       /* workspace: N*h*w*4 floats (the low-resolution flow, channel-interleaved), 16-B aligned */
+    int64_t i0_cstride, i1_cstride;  /* floats between the channel planes of I0 / I1; 0 = H*W (contiguous [3,H,W]) */
 } fldr_prep_desc;
 int fldr_level0_prep(const fldr_prep_desc* desc, fldr_stream_t stream);
 
@@ -190,6 +197,8 @@ typedef struct fldr_conv_desc {
     int32_t precision;         /* 0: fp32 MFMA (exact fp32 products, default); 1: fp16 inputs, fp32 accumulate */
     void*   out_spk;           /* fldr_conv2d only: optional split-packed twin of the output (fldr_spk_* below; the layout
                                   the 3x3 convolutions consume); `out` may then be NULL.  NULL for fldr_conv2d_split. */
+    int64_t src_cstride[FLDR_CONV_MAX_SRC];    /* fldr_conv2d_s2_split only: floats between the channel planes of source s;
+                                                  0 = Hin*Win (contiguous).  Must be 0 for the other entry points. */
 } fldr_conv_desc;
 
 /* Number of floats fldr_conv_prepack writes for a [cout,cin,k,k] weight. */
@@ -241,7 +250,7 @@ int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fld
 int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
 int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
-int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: sizeof(fldr_spk_conv_desc) — binding self-check */
+int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc — binding self-check */
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 
 /* ------------------------------------------------------------------------------------------
@@ -265,6 +274,12 @@ int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream);
 int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
                     const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
                     float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream);
+/* The same with channel-strided candidates: channel ch of candidate k, sample n at cand[k] + n*cand_bstride[k] +
+ * ch*cand_cstride[k] (floats; even). */
+int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+                            const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
+                            double* out_f64, float* out_f32, float* refine_out_or_null, int N, int H, int W,
+                            fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Callers either side of the path, on the device (the reference does these on the CPU).

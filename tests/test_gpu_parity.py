@@ -103,6 +103,40 @@ def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
     assert torch.equal(r["im0_tot"], hip.bwarp(I0, fb0, True)) and torch.equal(r["im1_tot"], hip.bwarp(I1, fb1, True))
 
 
+def test_channel_strided_frames_read_in_place(hip, dev):
+    """I0 / I1 are the views x[:, :, 0] / x[:, :, 1] of the [B,3,2,H,W] input (fLDRnet.py:130-131): level0_prep, the tile
+    splat, the stride-2 encoder and dec3_synth read them through batch + channel strides and must give exactly what
+    they give on contiguous copies."""
+    N, h, w, up = 2, 12, 20, 8
+    H, W = h * up, w * up
+    g = _gen(77)
+    x = (torch.rand(N, 3, 2, H, W, generator=g) * 2 - 1).to(dev)
+    flow_lo = ((torch.rand(N, 4, h, w, generator=g) - 0.5) * 6).to(dev)
+    t4 = torch.tensor([0.25, 0.75]).view(N, 1, 1, 1).to(dev)
+    views = (x[:, :, 0], x[:, :, 1])
+    copies = (views[0].contiguous(), views[1].contiguous())
+    assert not views[0][0].is_contiguous()
+    res = []
+    r = hip.level0_prep(flow_lo, copies[0], copies[1], t4, H, W, -1.9, -1.8, withmask=True, want_z=True)
+    w0 = hip.softsplat_fused(copies[0], r["flow_t0"], r["z0"], "softmax", kernel="tile")
+    w1 = hip.softsplat_fused(copies[1], r["flow_t1"], r["z1"], "softmax", kernel="tile")
+    for I0, I1 in (views, copies):
+        r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.9, -1.8, withmask=True, want_z=True)
+        wt = (torch.rand(16, 10, 4, 4, generator=_gen(3)) - 0.5).to(dev)
+        b = (torch.rand(16, generator=_gen(4)) - 0.5).to(dev)
+        e = hip.conv2d([I0, I1, r["flow_t0"], r["flow_t1"]], wt, b, stride=2, relu=True, precision="split")
+        d2 = torch.rand(N, 16, H // 2, W // 2, generator=_gen(5)).to(dev)
+        w3 = (torch.rand(6, 16, 3, 3, generator=_gen(6)) - 0.5).to(dev)
+        b3 = (torch.rand(6, generator=_gen(7)) - 0.5).to(dev)
+        o = hip.dec3_synth(d2, w3, b3, [w0, w1, r["im0_tot"], r["im1_tot"], I0, I1], t4, 1.56)
+        res.append([r[k] for k in ("z0", "z1", "flowback_0", "im0_tot", "im1_tot")] + [e, o])
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # the splat's summation order does not depend on the image layout, but only closeness is promised
+    _cmp(hip.softsplat_fused(views[0], r["flow_t0"], r["z0"], "softmax", kernel="tile"), w0, 1e-5, what="tile splat, strided image")
+    _cmp(hip.softsplat_fused(views[1], r["flow_t1"], r["z1"], "softmax", kernel="tile"), w1, 1e-5, what="tile splat, strided image")
+
+
 def test_pca_stream_equals_two_pass(hip, dev, model):
     """One-pass projection (raw fp64 parked, streaming rescale) == two-pass kernel bit for bit; its split-packed twin ==
     fldr_spk_pack of the fp32 output."""

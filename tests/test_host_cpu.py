@@ -28,11 +28,12 @@ def test_library_exports_every_declared_symbol():
 
 def test_conv_desc_layout_matches_header():
     import fldr_hip
-    # 12 ptr + 12 i64 + 12 i32 + 12 i32 + i32 (+pad) + 4 ptr + 12 i32 + 1 ptr
-    assert ctypes.sizeof(fldr_hip.ConvDesc) == 12 * 8 + 12 * 8 + 12 * 4 + 12 * 4 + 8 + 4 * 8 + 12 * 4 + 8
+    # 12 ptr + 12 i64 + 12 i32 + 12 i32 + i32 (+pad) + 4 ptr + 12 i32 + 1 ptr + 12 i64
+    assert ctypes.sizeof(fldr_hip.ConvDesc) == 12 * 8 + 12 * 8 + 12 * 4 + 12 * 4 + 8 + 4 * 8 + 12 * 4 + 8 + 12 * 8
     # the ctypes mirrors against the structs the library was compiled with
     assert ctypes.sizeof(fldr_hip.ConvDesc) == fldr_hip.lib().fldr_sizeof_desc(0)
     assert ctypes.sizeof(fldr_hip.SpkConvDesc) == fldr_hip.lib().fldr_sizeof_desc(1)
+    assert ctypes.sizeof(fldr_hip.PrepDesc) == fldr_hip.lib().fldr_sizeof_desc(2)
     assert fldr_hip.lib().fldr_conv_prepack_size(96, 100, 3) == 104 * 9 * 96
     assert fldr_hip.lib().fldr_conv_prepack_size(6, 16, 3) == 16 * 9 * 16
     assert fldr_hip.lib().fldr_conv_prepack_size(16, 26, 4) == 28 * 272      # channel rows padded to 16 mod 32 floats
