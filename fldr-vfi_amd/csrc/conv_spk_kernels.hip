@@ -64,7 +64,9 @@ struct SpkArgs {
     int32_t n_chunks, cout, cout_store;
     int32_t H, W;
     int32_t relu;
-    int32_t tiles_x, n_tiles, groups;
+    int32_t tiles_x, n_tiles, groups;             // groups: output-channel groups of 16*NMT channels the launch is split into
+    int32_t pack_nmt;                             // 16-channel blocks per weight-pack group (>= NMT, a multiple of it: small
+                                                  // launches run the NMT=1 kernel on sub-groups of an NMT=3 pack)
     int32_t n_units, units_per_xcd, wgs_per_xcd;
     uint32_t m_groups, m_tiles, m_tiles_x;        // floor(2^32 / d) + 1: u / d == umulhi(u, m) for u * d < 2^32 (d > 1)
 };
@@ -180,10 +182,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
     int w_piece[Cfg::NWI], x_piece[3];
     uint32_t w_voff[Cfg::NWI];
+    // Weight source: the pack holds [pack group][chunk][step][pack_nmt blocks][kind] 1-KB blocks; this workgroup's
+    // output group (constant over its units, see cbase below) is blocks [msel, msel + NMT) of pack group pgrp.
+    const int grp0 = u_first % a.groups, sub = a.pack_nmt / NMT;
+    const int pgrp = grp0 / sub, msel = (grp0 - pgrp * sub) * NMT;
+    const int pack_w_bytes = SPK_STEPS * a.pack_nmt * 2 * 1024;
 #pragma unroll
     for (int i = 0; i < Cfg::NWI; ++i) {
         w_piece[i] = min(i * 512 + wave * 64, Cfg::PIECES - 64);
-        w_voff[i] = (uint32_t)(w_piece[i] + lane) * 16u;
+        const int b = w_piece[i] >> 6, step = b / (2 * NMT), mk = b - step * 2 * NMT;          // LDS block (step, m, kind)
+        w_voff[i] = (uint32_t)((step * a.pack_nmt + msel) * 2 + mk) * 1024u + (uint32_t)lane * 16u;
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) x_piece[i] = min(((wave & 1) * 3 + i) * 64, SPK_PLANE / 16 - 64);
@@ -205,9 +213,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     int iss_u = u_first, iss_c = 0;
     uint32_t g_full[3], g_half[3];                                       // byte offsets in a plane; ~0u = outside the image
     int iss_n = 0;
-    const char* iss_w = nullptr;
+    const char* const iss_w = reinterpret_cast<const char*>(a.wpack + SPK_HDR) + (int64_t)pgrp * n_chunks * pack_w_bytes;
     auto issue_geometry = [&]() {
-        const int t = spk_div(iss_u, a.m_groups, a.groups), grp = iss_u - t * a.groups;
+        const int t = spk_div(iss_u, a.m_groups, a.groups);
         iss_n = spk_div(t, a.m_tiles, a.n_tiles);
         const int tile = t - iss_n * a.n_tiles;
         const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
@@ -221,7 +229,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
             g_full[i] = ok ? (uint32_t)(gy * a.W + gx) * 16u : ~0u;
             g_half[i] = ok ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : ~0u;
         }
-        iss_w = reinterpret_cast<const char*>(a.wpack + SPK_HDR) + (int64_t)grp * n_chunks * Cfg::W_BYTES;
     };
     const char* wbase = nullptr;                                         // workgroup-uniform source of the next weight slab
     const char* dptr[3];                                                 // per-lane source addresses of the next input pieces
@@ -232,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
 #if defined(SPK_ABLATE) && (SPK_ABLATE == 4 || SPK_ABLATE == 5)
         wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR);        // diagnostic: always the same (cached) slab
 #else
-        wbase = live ? iss_w + (int64_t)iss_c * Cfg::W_BYTES : reinterpret_cast<const char*>(a.wpack + SPK_HDR);
+        wbase = live ? iss_w + (int64_t)iss_c * pack_w_bytes : reinterpret_cast<const char*>(a.wpack + SPK_HDR);
 #endif
         const int gi = live ? iss_c * 2 + igrp : 0;
         const uint32_t e_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_ptr, gi), e_hi = __builtin_amdgcn_readlane((int)(uint32_t)(tab_ptr >> 32), gi);
@@ -278,7 +285,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     const int gout = (a.cout_store + 7) >> 3;
     // The output-channel group is the same for every unit of a workgroup (the host keeps wgs_per_xcd a multiple of
     // `groups`), so the bias is fetched once.
-    const int cbase = (u_first % a.groups) * MTOT;
+    const int cbase = grp0 * MTOT;
     float bias_r[NMT][4];
 #pragma unroll
     for (int m = 0; m < NMT; ++m)
@@ -651,6 +658,8 @@ extern "C" int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout
 
 // Persistent workgroups per XCD (32 = one per CU); fldr_debug_spk_wgs_per_xcd changes it for occupancy experiments.
 static int g_spk_wgs_per_xcd = 32;
+static int g_spk_small_units = 96;                 // launches with at most this many units use 16-channel sub-groups (-1: never)
+extern "C" int fldr_debug_spk_small_units(int v) { if (v != 0) g_spk_small_units = v; return g_spk_small_units; }
 extern "C" int fldr_debug_spk_wgs_per_xcd(int v) { if (v > 0) g_spk_wgs_per_xcd = v; return g_spk_wgs_per_xcd; }
 
 template <int NMT, int TERMS, bool HAS_RES>
@@ -715,7 +724,15 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     a.H = d->H; a.W = d->W; a.relu = d->relu;
     int nmt, groups;
     spk_geometry(d->cout, nmt, groups);
-    a.groups = groups;
+    a.groups = groups; a.pack_nmt = nmt;
+    // Small launches (the coarse pyramid levels): fewer units than CUs, and every workgroup would stream the weights
+    // of 48 output channels on its own (166 KB for 96 inputs, ~8 us at one CU's DMA rate).  Run the 16-channel kernel
+    // on sub-groups of the same weight pack instead: 3x the workgroups, a third of the weight stream each; the
+    // results are the same bits (each 16-channel block accumulates independently in the same order).
+    if (nmt > 1) {
+        const int64_t units = (int64_t)d->N * fldr_cdiv(d->W, SPK_TW) * fldr_cdiv(d->H, SPK_TH) * groups;
+        if (units <= g_spk_small_units) { a.groups = (d->cout + 15) / 16; nmt = 1; }
+    }
     hipStream_t s = fldr_s(stream);
     if (d->precision == 1) {
         if (nmt == 1) return spk_launch<1, 1>(a, d->N, s);

@@ -8,14 +8,18 @@
 // That is 4 taps instead of 9 (2.25x fewer MACs) and no redundant reads.  With 16 -> 6 channels this layer
 // is far too thin for the matrix cores (6 of 16 MFMA rows would be useful), so it runs on the vector ALUs with
 // the phase weights as scalar (SGPR) operands: one thread = one low-res pixel = 2x2 output pixels x 6 logits,
-// the 8x32 low-res tile (+halo) of all 16 input channels staged once in LDS.  HBM-bound by the 18 candidate
-// planes + the fp64 frame it writes.
+// the 8x32 low-res tile (+halo) of all 16 input channels staged once in LDS.  Measured at 2304x3840 (cold HBM): 311 us,
+// 222 us without the convolution, 235 us without the candidate loads — co-limited by the vector ALUs (768 packed fp32
+// FMAs + ~670 fp64 operations per thread, ~600 of them the six fp64 exponentials of each pixel) and the 991 MB it
+// moves (18 candidate planes in, the fp64 frame out).
 #include "common.h"
 
 #define D3_CIN 16
 #define D3_COUT 6
+#ifndef D3_TH
 #define D3_TH 8
 #define D3_TW 32
+#endif
 
 // weff[c][phase][co][tap], tap = dy2*2+dx2  (1536 floats)
 __global__ void dec3_prepack_kernel(const float* __restrict__ w, float* __restrict__ weff) {
@@ -46,7 +50,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
                                                          float* __restrict__ refine_dbg, int H, int W) {
     const int h = H >> 1, w = W >> 1;
     __shared__ float tile[D3_CIN][D3_TH + 2][D3_TW + 2];
-    const int tid = threadIdx.x, tx = tid & 31, ty = tid >> 5;
+    const int tid = threadIdx.x, tx = tid % D3_TW, ty = tid / D3_TW;
     const int i0 = blockIdx.y * D3_TH, j0 = blockIdx.x * D3_TW, n = blockIdx.z;
     const float* src = d2 + (int64_t)n * D3_CIN * h * w;
     constexpr int TILE_E = (D3_TH + 2) * (D3_TW + 2);
@@ -69,6 +73,23 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
         if (e < D3_CIN * TILE_E) (&tile[0][0][0])[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? st[q] : 0.0f;
     }
     __syncthreads();
+
+    // Candidate pixels of this thread's 2x2 output quad: row a = 0 is requested BEFORE the convolution below and row 1
+    // before row 0's fp64 tail, so that HBM keeps streaming under the ALU phases (clamped addresses for the threads of
+    // a partial tile; they return before using them).
+    const int li = i0 + ty, lj = j0 + tx;
+    const int64_t HW = (int64_t)H * W;
+    const int lic = min(li, h - 1), ljc = min(lj, w - 1);
+    float2 cv[2][6][3];
+    auto load_cands = [&](int a) __attribute__((always_inline)) {
+        const int64_t po = (int64_t)(2 * lic + a) * W + 2 * ljc;
+#pragma unroll
+        for (int k = 0; k < 6; ++k)
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch)
+                cv[a][k][ch] = *reinterpret_cast<const float2*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k] + po);
+    };
+    load_cands(0);
 
     float acc[4][D3_COUT];
 #pragma unroll
@@ -99,20 +120,21 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
         }
     }
 
-    const int li = i0 + ty, lj = j0 + tx;
-    if (li >= h || lj >= w) return;
-    const int64_t HW = (int64_t)H * W;
-    const float t = tv[n];
-    const double w1 = (double)t, w0 = (double)(1.0f - t);
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        const int64_t po = (int64_t)(2 * li + a) * W + 2 * lj;           // two horizontally adjacent output pixels
-        float2 cv[6][3];
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int k = 0; k < 6; ++k)
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch)
-                cv[k][ch] = *reinterpret_cast<const float2*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k] + po);
+            for (int ch = 0; ch < 3; ++ch) { if (a == 0) { fldr_pin(cv[0][k][ch].x); fldr_pin(cv[0][k][ch].y); } }
+    load_cands(1);
+    if (li >= h || lj >= w) return;
+    const float t = tv[n];
+    const double w1 = (double)t, w0 = (double)(1.0f - t);
+    const double inv_T = 1.0 / T;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int64_t po = (int64_t)(2 * li + a) * W + 2 * lj;           // two horizontally adjacent output pixels
+        double res[2][3];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
 #pragma clang fp contract(off)
@@ -121,27 +143,39 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
 #pragma unroll
                 for (int co = 0; co < D3_COUT; ++co) refine_dbg[((int64_t)n * D3_COUT + co) * HW + po + b] = acc[ph][co];
             }
+            // The vector ALUs' fp64 rate co-limits this kernel with HBM: the 15 fp64 divisions per pixel of the literal
+            // formula (logit / T, exp / sum, blend / div) are 2 reciprocals and multiplications here (<= 1 ulp of fp64 per
+            // factor, ten orders of magnitude below the fp32 inputs' own precision).
             double s[6], mx = -1.0e300;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { s[k] = (double)acc[ph][k] / T; mx = s[k] > mx ? s[k] : mx; }
+            for (int k = 0; k < 6; ++k) { s[k] = (double)acc[ph][k] * inv_T; mx = s[k] > mx ? s[k] : mx; }
             double sum = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { s[k] = exp(s[k] - mx); sum += s[k]; }
+                        for (int k = 0; k < 6; ++k) { s[k] = exp(s[k] - mx); sum += s[k]; }
+            const double inv_sum = 1.0 / sum;
             double wo[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) wo[k] = ((k & 1) ? w1 : w0) * (s[k] / sum);
+            for (int k = 0; k < 6; ++k) wo[k] = ((k & 1) ? w1 : w0) * (s[k] * inv_sum);
             double div = ((wo[0] + wo[1]) + wo[2]) + wo[3];               // fLDRnet.py:517
             div = div + (wo[4] + wo[5]);                                   // :522
+            const double inv_div = 1.0 / div;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 double v[6];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) v[k] = wo[k] * (double)(b ? cv[k][ch].y : cv[k][ch].x);
+                for (int k = 0; k < 6; ++k) v[k] = wo[k] * (double)(b ? cv[a][k][ch].y : cv[a][k][ch].x);
                 double o = v[0] + v[1];                                    // :518
                 o = o + (v[2] + v[3]);                                     // :520
                 o = o + (v[4] + v[5]);                                     // :521
-                out[((int64_t)n * 3 + ch) * HW + po + b] = (OUT)(o / div); // :524
+                res[b][ch] = o * inv_div;                                  // :524
             }
+        }
+        // both pixels of the pair in one 16-B (fp64) / 8-B (fp32) store per channel
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            OUT* o = out + ((int64_t)n * 3 + ch) * HW + po;
+            if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0][ch], res[1][ch]);
+            else *reinterpret_cast<float2*>(o) = make_float2((float)res[0][ch], (float)res[1][ch]);
         }
     }
 }
@@ -159,6 +193,7 @@ extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const
     FLDR_CHECK_ARG(d2 && weff && bias && cand && cand_bstride && cand_cstride && t && N > 0 && H > 0 && W > 0);
     FLDR_CHECK_ARG((out_f64 != nullptr) != (out_f32 != nullptr));
     if ((H | W) & 1) return FLDR_E_SHAPE;
+    FLDR_CHECK_ARG(((reinterpret_cast<uintptr_t>(out_f64) & 15) | (reinterpret_cast<uintptr_t>(out_f32) & 7)) == 0);     // pixel pairs are stored whole
     FinalArgs a;
     for (int k = 0; k < 6; ++k) {
         FLDR_CHECK_ARG(cand[k] && (((uintptr_t)cand[k]) & 7) == 0 && (cand_bstride[k] & 1) == 0 && (cand_cstride[k] & 1) == 0);

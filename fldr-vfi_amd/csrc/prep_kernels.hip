@@ -11,7 +11,9 @@
 #include "common.h"
 
 struct PrepArgs {
-    const float4* flow_lo4;        // [N,h,w] x (flow_10.x, flow_10.y, flow_01.x, flow_01.y): one 16-B load per low-resolution pixel
+    const float2* flow_lo2;        // [2][N,h,w] x float2: flow_10 (x,y) of every sample, then flow_01 (x,y): one 8-B load per
+                                   // low-resolution pixel and flow
+    int N;
     const float* I0; const float* I1;
     int64_t i0_bstride, i1_bstride;   // floats between samples
     int64_t i0_cstride, i1_cstride;   // floats between channel planes
@@ -33,12 +35,17 @@ __device__ __forceinline__ PrepLin prep_lin(int o, float scale, int in_size) {
     return r;
 }
 
-// The four low-resolution neighbours of one full-resolution coordinate, all 4 flow channels each (4 loads of 16 B).
+// The four low-resolution neighbours of one full-resolution coordinate, all 4 flow channels each (8 loads of 8 B).
 struct PrepQuad { float4 a00, a01, a10, a11; };
-__device__ __forceinline__ PrepQuad prep_quad(const float4* __restrict__ p, int w, const PrepLin& ix, const PrepLin& iy) {
+__device__ __forceinline__ PrepQuad prep_quad(const float2* __restrict__ p10, const float2* __restrict__ p01, int w, const PrepLin& ix,
+                                              const PrepLin& iy) {
     PrepQuad q;
-    q.a00 = p[(int64_t)iy.i0 * w + ix.i0]; q.a01 = p[(int64_t)iy.i0 * w + ix.i1];
-    q.a10 = p[(int64_t)iy.i1 * w + ix.i0]; q.a11 = p[(int64_t)iy.i1 * w + ix.i1];
+    const int64_t o00 = (int64_t)iy.i0 * w + ix.i0, o01 = (int64_t)iy.i0 * w + ix.i1;
+    const int64_t o10 = (int64_t)iy.i1 * w + ix.i0, o11 = (int64_t)iy.i1 * w + ix.i1;
+    const float2 b00 = p10[o00], b01 = p10[o01], b10 = p10[o10], b11 = p10[o11];
+    const float2 c00 = p01[o00], c01 = p01[o01], c10 = p01[o10], c11 = p01[o11];
+    q.a00 = make_float4(b00.x, b00.y, c00.x, c00.y); q.a01 = make_float4(b01.x, b01.y, c01.x, c01.y);
+    q.a10 = make_float4(b10.x, b10.y, c10.x, c10.y); q.a11 = make_float4(b11.x, b11.y, c11.x, c11.y);
     return q;
 }
 __device__ __forceinline__ float prep_ch(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
@@ -55,22 +62,53 @@ __device__ __forceinline__ float prep_up(const PrepQuad& q, int c, const PrepLin
     return (wy0 * top + iy.l * bot) * mul;
 }
 
-// bwarp_tscaled of a full-resolution 2-channel flow field (channels c0, c0+1 of the low-resolution flow) that only exists
-// as its low-resolution source: sample (xs * up(channel)) at the tap `tp` with the arithmetic of bwarp_kernel's scaled branch.
-__device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const float4* __restrict__ lo4, int c0, const PrepArgs& a, float xs,
+// prep_up of one channel from four already selected neighbours (pre == 0 arithmetic of prep_up).
+__device__ __forceinline__ float prep_up4(float a00, float a01, float a10, float a11, const PrepLin& ix, const PrepLin& iy, float mul) {
+#pragma clang fp contract(off)
+    const float wx0 = 1.0f - ix.l, wy0 = 1.0f - iy.l;
+    const float top = wx0 * a00 + ix.l * a01;
+    const float bot = wx0 * a10 + ix.l * a11;
+    return (wy0 * top + iy.l * bot) * mul;
+}
+
+// bwarp_tscaled of a full-resolution 2-channel flow field that only exists as its low-resolution source `lo2` (x, y per
+// low-resolution pixel): sample (xs * up(channel)) at the tap `tp` with the arithmetic of bwarp_kernel's scaled branch.
+// The tap's four corners are adjacent full-resolution pixels, and when upsampling (scale <= 1) adjacent pixels start
+// their low-resolution neighbourhoods at most one cell apart: the four 2x2 neighbourhoods lie in ONE 3x3 block, loaded
+// once (9 loads of 8 B instead of 16 of 16 B — the kernel is bound by L1 bandwidth) and picked apart with selects.
+__device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const float2* __restrict__ lo2, const PrepArgs& a, float xs,
                                                 float& ox, float& oy) {
 #pragma clang fp contract(off)
     const int xa = min(max(tp.x0, 0), a.W - 1), xb = min(max(tp.x0 + 1, 0), a.W - 1);
     const int ya = min(max(tp.y0, 0), a.H - 1), yb = min(max(tp.y0 + 1, 0), a.H - 1);
     const PrepLin lxa = prep_lin(xa, a.sx, a.w), lxb = prep_lin(xb, a.sx, a.w);
     const PrepLin lya = prep_lin(ya, a.sy, a.h), lyb = prep_lin(yb, a.sy, a.h);
-    const PrepQuad qnw = prep_quad(lo4, a.w, lxa, lya), qne = prep_quad(lo4, a.w, lxb, lya);
-    const PrepQuad qsw = prep_quad(lo4, a.w, lxa, lyb), qse = prep_quad(lo4, a.w, lxb, lyb);
+    // columns lxa.i0 + {0,1,2} and rows lya.i0 + {0,1,2}, clamped like fldr_lin_src's i1: (i0, i1) of xa is columns (0,1),
+    // of xb columns (dx, dx+1) with dx = lxb.i0 - lxa.i0 in {0,1}
+    const int c0 = lxa.i0, c1 = min(c0 + 1, a.w - 1), c2 = min(c0 + 2, a.w - 1);
+    const int r0 = lya.i0, r1 = min(r0 + 1, a.h - 1), r2 = min(r0 + 2, a.h - 1);
+    const float2* q0 = lo2 + (int64_t)r0 * a.w;
+    const float2* q1 = lo2 + (int64_t)r1 * a.w;
+    const float2* q2 = lo2 + (int64_t)r2 * a.w;
+    const float2 m00 = q0[c0], m01 = q0[c1], m02 = q0[c2];
+    const float2 m10 = q1[c0], m11 = q1[c1], m12 = q1[c2];
+    const float2 m20 = q2[c0], m21 = q2[c1], m22 = q2[c2];
+    const bool dx = lxb.i0 != lxa.i0, dy = lyb.i0 != lya.i0;
+    auto sel = [](bool c, const float2& t, const float2& f) { return make_float2(c ? t.x : f.x, c ? t.y : f.y); };
+    // east pair of columns per row, then south pair of rows
+    const float2 e00 = sel(dx, m01, m00), e01 = sel(dx, m02, m01);
+    const float2 e10 = sel(dx, m11, m10), e11 = sel(dx, m12, m11);
+    const float2 e20 = sel(dx, m21, m20), e21 = sel(dx, m22, m21);
+    const float2 sw00 = sel(dy, m10, m00), sw01 = sel(dy, m11, m01), sw10 = sel(dy, m20, m10), sw11 = sel(dy, m21, m11);
+    const float2 se00 = sel(dy, e10, e00), se01 = sel(dy, e11, e01), se10 = sel(dy, e20, e10), se11 = sel(dy, e21, e11);
     float o[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        const float pnw = prep_up(qnw, c0 + k, lxa, lya, a.mul, 0, 1.0f), pne = prep_up(qne, c0 + k, lxb, lya, a.mul, 0, 1.0f);
-        const float psw = prep_up(qsw, c0 + k, lxa, lyb, a.mul, 0, 1.0f), pse = prep_up(qse, c0 + k, lxb, lyb, a.mul, 0, 1.0f);
+        auto ch = [k](const float2& v) { return k == 0 ? v.x : v.y; };
+        const float pnw = prep_up4(ch(m00), ch(m01), ch(m10), ch(m11), lxa, lya, a.mul);
+        const float pne = prep_up4(ch(e00), ch(e01), ch(e10), ch(e11), lxb, lya, a.mul);
+        const float psw = prep_up4(ch(sw00), ch(sw01), ch(sw10), ch(sw11), lxa, lyb, a.mul);
+        const float pse = prep_up4(ch(se00), ch(se01), ch(se10), ch(se11), lxb, lyb, a.mul);
         float v = 0.0f;
         v += tp.vnw ? (pnw * xs) * tp.wnw : 0.0f;
         v += tp.vne ? (pne * xs) * tp.wne : 0.0f;
@@ -81,13 +119,14 @@ __device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const float4*
     ox = o[0]; oy = o[1];
 }
 
-// [N,4,h,w] -> [N,h,w] x float4
-__global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __restrict__ lo, float4* __restrict__ lo4, int64_t hw) {
+// [N,4,h,w] -> [2][N,h,w] x float2
+__global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __restrict__ lo, float2* __restrict__ lo2, int64_t hw) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int n = blockIdx.y;
+    const int n = blockIdx.y, N = gridDim.y;
     if (i >= hw) return;
     const float* p = lo + (int64_t)n * 4 * hw + i;
-    lo4[(int64_t)n * hw + i] = make_float4(p[0], p[hw], p[2 * hw], p[3 * hw]);
+    lo2[(int64_t)n * hw + i] = make_float2(p[0], p[hw]);
+    lo2[(int64_t)(N + n) * hw + i] = make_float2(p[2 * hw], p[3 * hw]);
 }
 
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
@@ -98,7 +137,8 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     if (px >= a.W || py >= a.H) return;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
     const int64_t pix = (int64_t)py * a.W + px;
-    const float4* lo4 = a.flow_lo4 + (int64_t)n * hw;        // channels: 0,1 = flow_10 (x,y); 2,3 = flow_01 (x,y)
+    const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;       // flow_10 (x,y)
+    const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;   // flow_01 (x,y); quad channels: 0,1 = flow_10, 2,3 = flow_01
     const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
     const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
     const float tv = a.t[n], omt = 1.0f - tv;
@@ -110,7 +150,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 
     // upsampled flows at this pixel (fLDRnet.py:419-422)
     const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
-    const PrepQuad q = prep_quad(lo4, a.w, lx, ly);
+    const PrepQuad q = prep_quad(lo10, lo01, a.w, lx, ly);
     const float f10x = prep_up(q, 0, lx, ly, a.mul, 0, 1.0f), f10y = prep_up(q, 1, lx, ly, a.mul, 0, 1.0f);
     const float f01x = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f), f01y = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
 
@@ -144,8 +184,8 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1);
     const float mb0 = a.withmask ? fldr_tap_mask(tb0) : 1.0f, mb1 = a.withmask ? fldr_tap_mask(tb1) : 1.0f;
     float fb0x, fb0y, fb1x, fb1y;
-    prep_sample_up2(tb0, lo4, 0, a, tv, fb0x, fb0y);
-    prep_sample_up2(tb1, lo4, 2, a, omt, fb1x, fb1y);
+    prep_sample_up2(tb0, lo10, a, tv, fb0x, fb0y);
+    prep_sample_up2(tb1, lo01, a, omt, fb1x, fb1y);
     fb0x = fb0x * mb0; fb0y = fb0y * mb0; fb1x = fb1x * mb1; fb1y = fb1y * mb1;
     a.flowback_0[o2] = fb0x; a.flowback_0[o2 + HW] = fb0y;
     a.flowback_1[o2] = fb1x; a.flowback_1[o2 + HW] = fb1y;
@@ -165,8 +205,9 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->ws && d->flow_lo && d->I0 && d->I1 && d->t && d->flow_t0 && d->flow_t1 && d->flowback_0 && d->flowback_1);
     FLDR_CHECK_ARG(d->im0_tot && d->im1_tot && (!d->z0 == !d->z1) && d->N > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0);
+    if (d->H < d->h || d->W < d->w) return FLDR_E_SHAPE;          // upsampling only (prep_sample_up2's 3x3 neighbourhood)
     PrepArgs a;
-    a.flow_lo4 = reinterpret_cast<const float4*>(d->ws); a.I0 = d->I0; a.I1 = d->I1; a.i0_bstride = d->i0_bstride; a.i1_bstride = d->i1_bstride;
+    a.flow_lo2 = reinterpret_cast<const float2*>(d->ws); a.N = d->N; a.I0 = d->I0; a.I1 = d->I1; a.i0_bstride = d->i0_bstride; a.i1_bstride = d->i1_bstride;
     a.i0_cstride = d->i0_cstride ? d->i0_cstride : (int64_t)d->H * d->W; a.i1_cstride = d->i1_cstride ? d->i1_cstride : (int64_t)d->H * d->W;
     a.t = d->t; a.z0 = d->z0; a.z1 = d->z1; a.flow_t0 = d->flow_t0; a.flow_t1 = d->flow_t1;
     a.flowback_0 = d->flowback_0; a.flowback_1 = d->flowback_1; a.im0_tot = d->im0_tot; a.im1_tot = d->im1_tot;
@@ -176,7 +217,7 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     a.za0 = d->z_alpha0; a.za1 = d->z_alpha1; a.withmask = d->withmask;
     const int64_t hw = (int64_t)d->h * d->w;
     hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
-                       reinterpret_cast<float4*>(d->ws), hw);
+                       reinterpret_cast<float2*>(d->ws), hw);
     dim3 grid(fldr_cdiv(d->W, 64), fldr_cdiv(d->H, 4), d->N);
     hipLaunchKernelGGL(level0_prep_kernel, grid, dim3(256), 0, fldr_s(stream), a);
     FLDR_LAUNCH_RET();

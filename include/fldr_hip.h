@@ -251,6 +251,7 @@ int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
 int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
 int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc — binding self-check */
+int fldr_debug_spk_small_units(int v);                              /* tuning hook: launches of <= v units run as 16-channel sub-groups (default 96; -1: never; 0: query) */
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 
 /* ------------------------------------------------------------------------------------------
