@@ -97,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
     // ---- staging geometry (identical for every channel and chunk): an item = one column of one row pair, i.e. exactly one
     //      dword of the hi plane and one of the lo plane (the staging was the bottleneck of this kernel when every element was
     //      converted and written on its own: 2 ds_write_b16 + 2 cvt per element against a 384-cycle MFMA phase per chunk) ----
-    int g_off0[S2_NI], g_off1[S2_NI], l_dw[S2_NI];
+    uint32_t g_off0[S2_NI], g_off1[S2_NI];                    // element offsets inside a channel plane (host-checked < 2^30)
+    int l_dw[S2_NI];
     unsigned vmask0 = 0, vmask1 = 0;
 #pragma unroll
     for (int i = 0; i < S2_NI; ++i) {
@@ -108,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
         const bool ok0 = okx && gy0 >= 0 && gy0 < a.Hin, ok1 = okx && gy1 >= 0 && gy1 < a.Hin;
         vmask0 |= ok0 ? (1u << i) : 0u;
         vmask1 |= ok1 ? (1u << i) : 0u;
-        g_off0[i] = ok0 ? gy0 * a.Win + gx : 0;
-        g_off1[i] = ok1 ? gy1 * a.Win + gx : 0;
+        g_off0[i] = ok0 ? (uint32_t)(gy0 * a.Win + gx) : 0u;
+        g_off1[i] = ok1 ? (uint32_t)(gy1 * a.Win + gx) : 0u;
         l_dw[i] = e < S2_RP * S2_IW ? (pr * 2 + (x & 1)) * IWHP + (x >> 1) : -1;      // dword inside a (channel, half) plane
     }
 
@@ -169,12 +170,14 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
         const unsigned long long e = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(t >> 32), c & 63) << 32) |
                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)t, c & 63);
         const bool live = e != 0ull;
-        const float* base = reinterpret_cast<const float*>(static_cast<uintptr_t>(e));
+        // a GLOBAL pointer (address space 1), wave-uniform: global_load_dword with an SGPR base and a 32-bit lane offset
+        // instead of flat_load (a flat load also occupies the LDS counter the operand reads below wait on)
+        const auto* base = (const __attribute__((address_space(1))) float*)e;
 #pragma unroll
         for (int i = 0; i < S2_NI; ++i) {
             float v0 = 0.0f, v1 = 0.0f;
-            if (live && ((vmask0 >> i) & 1u)) v0 = base[g_off0[i]];
-            if (live && ((vmask1 >> i) & 1u)) v1 = base[g_off1[i]];
+            if (live && ((vmask0 >> i) & 1u)) v0 = base[(uint64_t)g_off0[i]];
+            if (live && ((vmask1 >> i) & 1u)) v1 = base[(uint64_t)g_off1[i]];
             dst[2 * i] = v0; dst[2 * i + 1] = v1;
         }
     };

@@ -62,58 +62,51 @@ __device__ __forceinline__ float prep_up(const PrepQuad& q, int c, const PrepLin
     return (wy0 * top + iy.l * bot) * mul;
 }
 
-// prep_up of one channel from four already selected neighbours (pre == 0 arithmetic of prep_up).
-__device__ __forceinline__ float prep_up4(float a00, float a01, float a10, float a11, const PrepLin& ix, const PrepLin& iy, float mul) {
-#pragma clang fp contract(off)
-    const float wx0 = 1.0f - ix.l, wy0 = 1.0f - iy.l;
-    const float top = wx0 * a00 + ix.l * a01;
-    const float bot = wx0 * a10 + ix.l * a11;
-    return (wy0 * top + iy.l * bot) * mul;
-}
-
 // bwarp_tscaled of a full-resolution 2-channel flow field that only exists as its low-resolution source `lo2` (x, y per
 // low-resolution pixel): sample (xs * up(channel)) at the tap `tp` with the arithmetic of bwarp_kernel's scaled branch.
 // The tap's four corners are adjacent full-resolution pixels, and when upsampling (scale <= 1) adjacent pixels start
 // their low-resolution neighbourhoods at most one cell apart: the four 2x2 neighbourhoods lie in ONE 3x3 block, loaded
-// once (9 loads of 8 B instead of 16 of 16 B — the kernel is bound by L1 bandwidth) and picked apart with selects.
-__device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const float2* __restrict__ lo2, const PrepArgs& a, float xs,
-                                                float& ox, float& oy) {
+// once (9 loads of 8 B instead of 16 of 16 B) and picked apart with selects.  (The kernel is bound by its VALU
+// instruction count: ~1,100 per pixel after this and the prepared taps of common.h, 1,411 before.)
+__device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const FldrTapP& tpp, const float2* __restrict__ lo2, const PrepArgs& a,
+                                                float xs, float& ox, float& oy) {
 #pragma clang fp contract(off)
     const int xa = min(max(tp.x0, 0), a.W - 1), xb = min(max(tp.x0 + 1, 0), a.W - 1);
     const int ya = min(max(tp.y0, 0), a.H - 1), yb = min(max(tp.y0 + 1, 0), a.H - 1);
     const PrepLin lxa = prep_lin(xa, a.sx, a.w), lxb = prep_lin(xb, a.sx, a.w);
     const PrepLin lya = prep_lin(ya, a.sy, a.h), lyb = prep_lin(yb, a.sy, a.h);
     // columns lxa.i0 + {0,1,2} and rows lya.i0 + {0,1,2}, clamped like fldr_lin_src's i1: (i0, i1) of xa is columns (0,1),
-    // of xb columns (dx, dx+1) with dx = lxb.i0 - lxa.i0 in {0,1}
+    // of xb columns (dx, dx+1) with dx = lxb.i0 - lxa.i0 in {0,1}; rows alike
     const int c0 = lxa.i0, c1 = min(c0 + 1, a.w - 1), c2 = min(c0 + 2, a.w - 1);
     const int r0 = lya.i0, r1 = min(r0 + 1, a.h - 1), r2 = min(r0 + 2, a.h - 1);
     const float2* q0 = lo2 + (int64_t)r0 * a.w;
     const float2* q1 = lo2 + (int64_t)r1 * a.w;
     const float2* q2 = lo2 + (int64_t)r2 * a.w;
-    const float2 m00 = q0[c0], m01 = q0[c1], m02 = q0[c2];
-    const float2 m10 = q1[c0], m11 = q1[c1], m12 = q1[c2];
-    const float2 m20 = q2[c0], m21 = q2[c1], m22 = q2[c2];
+    const float2 m[3][3] = {{q0[c0], q0[c1], q0[c2]}, {q1[c0], q1[c1], q1[c2]}, {q2[c0], q2[c1], q2[c2]}};
     const bool dx = lxb.i0 != lxa.i0, dy = lyb.i0 != lya.i0;
-    auto sel = [](bool c, const float2& t, const float2& f) { return make_float2(c ? t.x : f.x, c ? t.y : f.y); };
-    // east pair of columns per row, then south pair of rows
-    const float2 e00 = sel(dx, m01, m00), e01 = sel(dx, m02, m01);
-    const float2 e10 = sel(dx, m11, m10), e11 = sel(dx, m12, m11);
-    const float2 e20 = sel(dx, m21, m20), e21 = sel(dx, m22, m21);
-    const float2 sw00 = sel(dy, m10, m00), sw01 = sel(dy, m11, m01), sw10 = sel(dy, m20, m10), sw11 = sel(dy, m21, m11);
-    const float2 se00 = sel(dy, e10, e00), se01 = sel(dy, e11, e01), se10 = sel(dy, e20, e10), se11 = sel(dy, e21, e11);
+    const float wxa = 1.0f - lxa.l, wxb = 1.0f - lxb.l, wya = 1.0f - lya.l, wyb = 1.0f - lyb.l;
     float o[2];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-        auto ch = [k](const float2& v) { return k == 0 ? v.x : v.y; };
-        const float pnw = prep_up4(ch(m00), ch(m01), ch(m10), ch(m11), lxa, lya, a.mul);
-        const float pne = prep_up4(ch(e00), ch(e01), ch(e10), ch(e11), lxb, lya, a.mul);
-        const float psw = prep_up4(ch(sw00), ch(sw01), ch(sw10), ch(sw11), lxa, lyb, a.mul);
-        const float pse = prep_up4(ch(se00), ch(se01), ch(se10), ch(se11), lxb, lyb, a.mul);
+        // prep_up's arithmetic per corner — top = wx0 * a00 + lx * a01, bot likewise, (wy0 * top + ly * bot) * mul — with the
+        // horizontal interpolations done once per neighbourhood row (west pair of columns for xa, east pair for xb) and the
+        // vertical pairs of rows picked afterwards: same operands, same operations, 20 selects instead of 56
+        float tw[3], te[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const float v0 = k == 0 ? m[r][0].x : m[r][0].y, v1 = k == 0 ? m[r][1].x : m[r][1].y, v2 = k == 0 ? m[r][2].x : m[r][2].y;
+            tw[r] = wxa * v0 + lxa.l * v1;
+            te[r] = wxb * (dx ? v1 : v0) + lxb.l * (dx ? v2 : v1);
+        }
+        const float pnw = (wya * tw[0] + lya.l * tw[1]) * a.mul;
+        const float pne = (wya * te[0] + lya.l * te[1]) * a.mul;
+        const float psw = (wyb * (dy ? tw[1] : tw[0]) + lyb.l * (dy ? tw[2] : tw[1])) * a.mul;
+        const float pse = (wyb * (dy ? te[1] : te[0]) + lyb.l * (dy ? te[2] : te[1])) * a.mul;
         float v = 0.0f;
-        v += tp.vnw ? (pnw * xs) * tp.wnw : 0.0f;
-        v += tp.vne ? (pne * xs) * tp.wne : 0.0f;
-        v += tp.vsw ? (psw * xs) * tp.wsw : 0.0f;
-        v += tp.vse ? (pse * xs) * tp.wse : 0.0f;
+        v += (pnw * xs) * tpp.wnw;
+        v += (pne * xs) * tpp.wne;
+        v += (psw * xs) * tpp.wsw;
+        v += (pse * xs) * tpp.wse;
         o[k] = v;
     }
     ox = o[0]; oy = o[1];
@@ -156,14 +149,14 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 
     // splat metrics (fLDRnet.py:442-446 = zmetric_kernel): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10)
     if (a.z0) {
-        const FldrTap t0 = fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1);
-        const FldrTap t1 = fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1);
-        const float m0 = fldr_tap_mask(t0), m1 = fldr_tap_mask(t1);
+        const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
+        const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
+        const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float w0 = fldr_tap_sample(t0, i1 + (int64_t)c * a.i1_cstride, a.W, a.H) * m0;
-            const float w1 = fldr_tap_sample(t1, i0 + (int64_t)c * a.i0_cstride, a.W, a.H) * m1;
+            const float w0 = fldr_tap_sample_p(t0, i1 + (int64_t)c * a.i1_cstride) * m0;
+            const float w1 = fldr_tap_sample_p(t1, i0 + (int64_t)c * a.i0_cstride) * m1;
             acc0 += a.za0 * fabsf(c0[c] - w0);
             acc1 += a.za1 * fabsf(c1[c] - w1);
         }
@@ -182,30 +175,31 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     // flowback_1 = bwarp((1-t) * flow_01, t * flow_10)
     const FldrTap tb0 = fldr_grid_tap((float)px, (float)py, omt * f01x, omt * f01y, a.W, a.H, a.inv_wm1, a.inv_hm1);
     const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1);
-    const float mb0 = a.withmask ? fldr_tap_mask(tb0) : 1.0f, mb1 = a.withmask ? fldr_tap_mask(tb1) : 1.0f;
+    const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
+    const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
     float fb0x, fb0y, fb1x, fb1y;
-    prep_sample_up2(tb0, lo10, a, tv, fb0x, fb0y);
-    prep_sample_up2(tb1, lo01, a, omt, fb1x, fb1y);
+    prep_sample_up2(tb0, tb0p, lo10, a, tv, fb0x, fb0y);
+    prep_sample_up2(tb1, tb1p, lo01, a, omt, fb1x, fb1y);
     fb0x = fb0x * mb0; fb0y = fb0y * mb0; fb1x = fb1x * mb1; fb1y = fb1y * mb1;
     a.flowback_0[o2] = fb0x; a.flowback_0[o2 + HW] = fb0y;
     a.flowback_1[o2] = fb1x; a.flowback_1[o2 + HW] = fb1y;
 
     // backward-warped frames (fLDRnet.py:478-479 = bwarp_kernel)
-    const FldrTap ti0 = fldr_grid_tap((float)px, (float)py, fb0x, fb0y, a.W, a.H, a.inv_wm1, a.inv_hm1);
-    const FldrTap ti1 = fldr_grid_tap((float)px, (float)py, fb1x, fb1y, a.W, a.H, a.inv_wm1, a.inv_hm1);
-    const float mi0 = a.withmask ? fldr_tap_mask(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask(ti1) : 1.0f;
+    const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb0x, fb0y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
+    const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb1x, fb1y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
+    const float mi0 = a.withmask ? fldr_tap_mask_p(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1) : 1.0f;
     const int64_t o3 = (int64_t)n * 3 * HW + pix;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        a.im0_tot[o3 + (int64_t)c * HW] = fldr_tap_sample(ti0, i0 + (int64_t)c * a.i0_cstride, a.W, a.H) * mi0;
-        a.im1_tot[o3 + (int64_t)c * HW] = fldr_tap_sample(ti1, i1 + (int64_t)c * a.i1_cstride, a.W, a.H) * mi1;
+        a.im0_tot[o3 + (int64_t)c * HW] = fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0;
+        a.im1_tot[o3 + (int64_t)c * HW] = fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1;
     }
 }
 
 extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->ws && d->flow_lo && d->I0 && d->I1 && d->t && d->flow_t0 && d->flow_t1 && d->flowback_0 && d->flowback_1);
     FLDR_CHECK_ARG(d->im0_tot && d->im1_tot && (!d->z0 == !d->z1) && d->N > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0);
-    if (d->H < d->h || d->W < d->w) return FLDR_E_SHAPE;          // upsampling only (prep_sample_up2's 3x3 neighbourhood)
+    if (d->H < d->h || d->W < d->w || (int64_t)d->H * d->W * 4 >= (1ll << 32)) return FLDR_E_SHAPE;          // upsampling only (prep_sample_up2's 3x3 neighbourhood)
     PrepArgs a;
     a.flow_lo2 = reinterpret_cast<const float2*>(d->ws); a.N = d->N; a.I0 = d->I0; a.I1 = d->I1; a.i0_bstride = d->i0_bstride; a.i1_bstride = d->i1_bstride;
     a.i0_cstride = d->i0_cstride ? d->i0_cstride : (int64_t)d->H * d->W; a.i1_cstride = d->i1_cstride ? d->i1_cstride : (int64_t)d->H * d->W;
