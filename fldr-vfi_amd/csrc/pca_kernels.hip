@@ -63,14 +63,16 @@ template <int K, int PASS>
 __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ planes, const double* __restrict__ ev,
                                                   const double* __restrict__ mean, const double* __restrict__ mv,
                                                   double* __restrict__ mm, float* __restrict__ out32,
-                                                  double* __restrict__ out64, int H, int W) {
+                                                  double* __restrict__ out64, int H, int W, int Ktot, int nq) {
+    // K components per thread; a plane's Ktot = K * nq components are spread over nq threads (blockIdx.z = p * nq + q):
+    // on the coarse pyramid levels one thread per block is a single wave's chain of 1,024 dependent fp64 FMAs
     const int BW = W >> 3, BH = H >> 3;
     int bx = blockIdx.x * 64 + (threadIdx.x & 63);
     int by = blockIdx.y * 4 + (threadIdx.x >> 6);
-    int p = blockIdx.z;
+    const int p = blockIdx.z / nq, k0 = (blockIdx.z - p * nq) * K;
     bool live = bx < BW && by < BH;
     double y[K];
-    if (live) pca_block<K>(planes + (int64_t)p * H * W, W, bx, by, ev, mean, mv, y);
+    if (live) pca_block<K>(planes + (int64_t)p * H * W, W, bx, by, ev + k0 * 64, mean, mv + k0, y);
     if (PASS == 0 || PASS == 2) {
         double lo = 1.0e300, hi = -1.0e300;
         if (live) {
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ plan
         }
         if (PASS == 2 && live) {                                        // raw projections for pca_rescale_kernel
             const int64_t BHW = (int64_t)BH * BW;
-            const int64_t o = ((int64_t)p * K) * BHW + (int64_t)by * BW + bx;
+            const int64_t o = ((int64_t)p * Ktot + k0) * BHW + (int64_t)by * BW + bx;
 #pragma unroll
             for (int k = 0; k < K; ++k) out64[o + (int64_t)k * BHW] = y[k];
         }
@@ -101,7 +103,7 @@ __global__ __launch_bounds__(256) void pca_kernel(const float* __restrict__ plan
         if (!live) return;
         const double mi = mm[0], range = mm[1] - mm[0];
         const int64_t BHW = (int64_t)BH * BW;
-        const int64_t o = ((int64_t)p * K) * BHW + (int64_t)by * BW + bx;
+        const int64_t o = ((int64_t)p * Ktot + k0) * BHW + (int64_t)by * BW + bx;
 #pragma unroll
         for (int k = 0; k < K; ++k) {
             double v = ((y[k] - mi) / range) * 2.0 - 1.0;               // pca_comp.py:523-526
@@ -157,7 +159,12 @@ static void pca_launch_stream(const float* planes, const double* ev, const doubl
                               double* o64, void* spk, double* mm, int P, int H, int W, hipStream_t s) {
     dim3 grid(fldr_cdiv(W / 8, 64), fldr_cdiv(H / 8, 4), P);
     hipLaunchKernelGGL(pca_init_minmax, dim3(1), dim3(1), 0, s, mm);
-    hipLaunchKernelGGL((pca_kernel<K, 2>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, (float*)nullptr, o64, H, W);
+    if ((int64_t)grid.x * grid.y * P < 64 && K % 4 == 0 && K > 4) {        // coarse levels (<= 36 x 60 blocks): 4 components per thread
+        grid.z = P * (K / 4);                                               // (measured 19/17/16 -> 11/11/10 us; 2 per thread is slower again)
+        hipLaunchKernelGGL((pca_kernel<4, 2>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, (float*)nullptr, o64, H, W, K, K / 4);
+    } else {
+        hipLaunchKernelGGL((pca_kernel<K, 2>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, (float*)nullptr, o64, H, W, K, 1);
+    }
     const int64_t BHW = (int64_t)(H / 8) * (W / 8);
     const int C = P * K;
     hipLaunchKernelGGL(pca_rescale_kernel, dim3(fldr_cdiv(BHW, 256), (C + 7) / 8), dim3(256), 0, s, o64, mm, o32,
@@ -169,8 +176,8 @@ static void pca_launch(const float* planes, const double* ev, const double* mean
                        double* mm, int P, int H, int W, hipStream_t s) {
     dim3 grid(fldr_cdiv(W / 8, 64), fldr_cdiv(H / 8, 4), P);
     hipLaunchKernelGGL(pca_init_minmax, dim3(1), dim3(1), 0, s, mm);
-    hipLaunchKernelGGL((pca_kernel<K, 0>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W);
-    hipLaunchKernelGGL((pca_kernel<K, 1>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W);
+    hipLaunchKernelGGL((pca_kernel<K, 0>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W, K, 1);
+    hipLaunchKernelGGL((pca_kernel<K, 1>), grid, dim3(256), 0, s, planes, ev, mean, mv, mm, o32, o64, H, W, K, 1);
 }
 
 // fldr_pca_project with the fp64 output buffer as the intermediate (one projection instead of two) and an optional

@@ -183,8 +183,16 @@ static void splat_launch(const float* in, const float* flow, const float* metric
         hipLaunchKernelGGL((splat_strip_kernel<MODE, 4, 8>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, 1);
     } else {              // feature maps: channel groups of 7 (49 = 7 x 7) for parallelism, 8 rows per wave
         const int groups = fldr_cdiv(CA, 7);
-        dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 8), N * groups);
-        hipLaunchKernelGGL((splat_strip_kernel<MODE, 7, 8>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, groups);
+        if ((int64_t)H * W > 40000) {
+            dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 8), N * groups);
+            hipLaunchKernelGGL((splat_strip_kernel<MODE, 7, 8>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, groups);
+        } else {
+            // coarse pyramid levels (<= 144 x 240): a wave's rows are a chain of dependent L2 atomics (measured: 16 us per
+            // launch whatever the size with 8 rows per wave; 5.5 us with 2 rows per wave and 4x the waves; at 288 x 480 the
+            // extra atomics of the shorter vertical merge chains cost more than the parallelism gives, 47 vs 41 us)
+            dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 2), N * groups);
+            hipLaunchKernelGGL((splat_strip_kernel<MODE, 7, 2>), grid, dim3(256), 0, s, in, flow, metric, acc, C, H, W, groups);
+        }
     }
 }
 
