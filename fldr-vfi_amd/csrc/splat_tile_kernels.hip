@@ -281,6 +281,10 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
 // ------------------------------------------------------------------------------------------------
 
 #define SB_LIST 128
+#ifndef ST_IMG_TW
+#define ST_IMG_TW 56            // band of the image instance: 56 + 3 + (flow spread <= 5) columns of candidates = ONE 64-pixel chunk per
+#define ST_IMG_TH 12            // row in the trimmed walk; measured in the 4K forward: 128x6 366 us, 120x6 336 us, 56x12 317 us
+#endif
 
 #ifdef ST_STAMPS
 __device__ unsigned long long st_stamp_buf[16];
@@ -355,12 +359,12 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     // ---- accumulate: lane = one source pixel of a 64-pixel row; the next block's 4 rows are loaded ahead ----
     float fx[2][ST_BH], fy[2][ST_BH], mv[2][ST_BH], val[2][ST_BH][CB];
     int bxy[2] = {0, 0};
-    auto load_block = [&](int buf, int e) __attribute__((always_inline)) {   // e = (block row << 16) | block column
+    auto load_block = [&](int buf, int e) __attribute__((always_inline)) {   // e = (first row << 16) | first column: 4 rows x 64 pixels
         bxy[buf] = e;
-        const int px = (e & 0xFFFF) * ST_BW + lane;
+        const int px = (e & 0xFFFF) + lane;
 #pragma unroll
         for (int r = 0; r < ST_BH; ++r) {
-            const int py = (e >> 16) * ST_BH + r;
+            const int py = (e >> 16) + r;
             const bool ok = px < W && py < H;
             const int64_t pix = ok ? (int64_t)py * W + px : 0;
             fx[buf][r] = fl[pix]; fy[buf][r] = fl[HW + pix];
@@ -397,14 +401,14 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     // them), so no claim round is needed.  Any other row takes the claim path above (exact for every flow).
     auto process_block = [&](int buf) __attribute__((always_inline)) {
         const int e = bxy[buf];
-        const int px = (e & 0xFFFF) * ST_BW + lane;
+        const int px = (e & 0xFFFF) + lane;
         float pend[CA];
         int pend_cell = -1;
 #pragma unroll
         for (int c = 0; c < CA; ++c) pend[c] = 0.0f;
 #pragma unroll
         for (int r = 0; r < ST_BH; ++r) {
-            const int py = (e >> 16) * ST_BH + r;
+            const int py = (e >> 16) + r;
             const bool ok = px < W && py < H;
             const StGeom g = st_geom(px, py, fx[buf][r], fy[buf][r], W, H);
             const int lx = g.x0 - tx0, ly = g.y0 - ty0;          // band-local north-west corner
@@ -504,34 +508,6 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     //      them in LDS, then walk their blocks (the next super-block's block bounds and the next block's rows are loaded
     //      ahead).  Any number of candidates is handled: when the list is full the scan stops, the list is walked, and
     //      the scan resumes where it stopped. ----
-    auto walk_sb = [&](int sbi, unsigned long long mk) __attribute__((always_inline)) {
-        const int bx0 = (sbi % nsb_x) * ST_SBX, by0 = (sbi / nsb_x) * ST_SBY;
-        auto pop = [&]() __attribute__((always_inline)) -> int {  // next matching block of this super-block
-            const int bit = __builtin_ctzll(mk);
-            mk &= mk - 1;
-            return ((by0 + bit / ST_SBX) << 16) | (bx0 + bit % ST_SBX);
-        };
-        if (!mk) return;
-        load_block(0, pop());
-        for (;;) {
-            const bool more1 = mk != 0;
-            if (more1) load_block(1, pop());
-            { TSTAMP(p0) process_block(0); TSTAMP(p1)
-#ifdef ST_STAMPS
-              c_proc += p1 - p0; ++c_blocks;
-#endif
-            }
-            if (!more1) break;
-            const bool more0 = mk != 0;
-            if (more0) load_block(0, pop());
-            { TSTAMP(p0) process_block(1); TSTAMP(p1)
-#ifdef ST_STAMPS
-              c_proc += p1 - p0; ++c_blocks;
-#endif
-            }
-            if (!more0) break;
-        }
-    };
     auto sb_blocks = [&](int sbi, const float4 bb) __attribute__((always_inline)) -> unsigned long long {
         const int sx = ((sbi % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, sy = ((sbi / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
         return __ballot(st_match(bb, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fty0, fty1));
@@ -570,14 +546,92 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 #ifdef ST_STAMPS
         c_walk -= t_w0;
 #endif
-        if (n_list > 0) {
-            int sbi = sbl[0];
-            float4 bb = *reinterpret_cast<const float4*>(bkn + ((int64_t)sbi * ST_SB_BLOCKS + lane) * 4);
+        // Trimmed walk (the common case: one scan pass found every candidate).  Aligned 64 x 4 source blocks overhang a band
+        // on both sides — a 128-wide band shifted by the flow is hit by three of them, and every row of a hit block costs
+        // ~450 VALU instructions — so the candidates are re-cut to the band: the bounding box of the matching blocks,
+        // intersected with the pixel range their joint flow bounds allow (the st_match test for a single pixel), walked in
+        // 64-pixel chunks that start at its left edge.  Exact: a source outside the range cannot touch the band, and
+        // the chunks / row groups are disjoint.  Taken when it needs no more 64 x 4 pieces than there are matching blocks.
+        bool trimmed = false;
+        int it_k = 0, it_nb = 0, it_nx = 1, it_X0 = 0, it_Y0 = 0;
+        if (s_start == 0 && s_resume == nsb && n_list > 0) {
+            const float INF = __builtin_inff();
+            float rxmin = INF, rxmax = -INF, rymin = INF, rymax = -INF;     // flow bounds of the matching blocks
+            int cx0 = 0x7fffffff, cx1 = -1, cy0 = 0x7fffffff, cy1 = -1;     // their bounding box (pixels, inclusive)
+            int n_match = 0;
             for (int i = 0; i < n_list; ++i) {
-                const int nsbi = sbl[i + 1 < n_list ? i + 1 : i];
-                const float4 nbb = *reinterpret_cast<const float4*>(bkn + ((int64_t)nsbi * ST_SB_BLOCKS + lane) * 4);
-                walk_sb(sbi, sb_blocks(sbi, bb));
-                sbi = nsbi; bb = nbb;
+                const int sbi = sbl[i];
+                const float4 bb = *reinterpret_cast<const float4*>(bkn + ((int64_t)sbi * ST_SB_BLOCKS + lane) * 4);
+                const int sx = ((sbi % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, sy = ((sbi / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
+                const bool hit = st_match(bb, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fty0, fty1);
+                n_match += __popcll(__ballot(hit));
+                if (hit) {
+                    rxmin = fminf(rxmin, bb.x); rxmax = fmaxf(rxmax, bb.y); rymin = fminf(rymin, bb.z); rymax = fmaxf(rymax, bb.w);
+                    cx0 = min(cx0, sx); cx1 = max(cx1, sx + ST_BW - 1); cy0 = min(cy0, sy); cy1 = max(cy1, sy + ST_BH - 1);
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                rxmin = fminf(rxmin, __shfl_xor(rxmin, o)); rxmax = fmaxf(rxmax, __shfl_xor(rxmax, o));
+                rymin = fminf(rymin, __shfl_xor(rymin, o)); rymax = fmaxf(rymax, __shfl_xor(rymax, o));
+                cx0 = min(cx0, __shfl_xor(cx0, o)); cx1 = max(cx1, __shfl_xor(cx1, o));
+                cy0 = min(cy0, __shfl_xor(cy0, o)); cy1 = max(cy1, __shfl_xor(cy1, o));
+            }
+            if (cx1 >= 0 && rxmax - rxmin < 1.0e6f && rymax - rymin < 1.0e6f) {       // (finite, sane bounds; wave-uniform)
+                // x + fx >= tx0 - 2 and x + fx <= tx1 + 1 for some fx in [rxmin, rxmax]  (st_match with rx0 = rx1 = x)
+                const int X0 = max(cx0, (int)floorf(ftx0 - 2.0f - rxmax)), X1 = min(min(cx1, W - 1), (int)ceilf(ftx1 + 1.0f - rxmin));
+                const int Y0 = max(cy0, (int)floorf(fty0 - 2.0f - rymax)), Y1 = min(min(cy1, H - 1), (int)ceilf(fty1 + 1.0f - rymin));
+                const int nx = X1 >= X0 ? (X1 - X0) / ST_BW + 1 : 0, ny = Y1 >= Y0 ? (Y1 - Y0) / ST_BH + 1 : 0;
+                if (nx * ny <= n_match) {                 // never more blocks than the walk below would process
+                    trimmed = true;
+                    it_nx = nx > 0 ? nx : 1; it_nb = nx * ny; it_X0 = X0; it_Y0 = Y0;
+                }
+            }
+        }
+        // One generator for both walks (a single pair of load / process sites keeps the kernel inside the instruction
+        // cache): the chunks of the trimmed rectangle, or the matching blocks of the listed super-blocks.
+        int li = 0, wbx0 = 0, wby0 = 0;
+        unsigned long long mk = 0ull;
+        auto next_block = [&](int& e) __attribute__((always_inline)) -> bool {
+            if (trimmed) {
+                if (it_k >= it_nb) return false;
+                const int gy = it_k / it_nx;
+                e = ((it_Y0 + gy * ST_BH) << 16) | (it_X0 + (it_k - gy * it_nx) * ST_BW);
+                ++it_k;
+                return true;
+            }
+            while (!mk) {
+                if (li >= n_list) return false;
+                const int sbi = sbl[li++];
+                const float4 bb = *reinterpret_cast<const float4*>(bkn + ((int64_t)sbi * ST_SB_BLOCKS + lane) * 4);
+                mk = sb_blocks(sbi, bb);
+                wbx0 = (sbi % nsb_x) * ST_SBX; wby0 = (sbi / nsb_x) * ST_SBY;
+            }
+            const int bit = __builtin_ctzll(mk);
+            mk &= mk - 1;
+            e = (((wby0 + bit / ST_SBX) * ST_BH) << 16) | ((wbx0 + bit % ST_SBX) * ST_BW);
+            return true;
+        };
+        {
+            int e0 = 0, e1 = 0;
+            bool have = next_block(e0);
+            if (have) load_block(0, e0);
+            while (have) {
+                const bool more = next_block(e1);
+                if (more) load_block(1, e1);
+                { TSTAMP(p0) process_block(0); TSTAMP(p1)
+#ifdef ST_STAMPS
+                  c_proc += p1 - p0; ++c_blocks;
+#endif
+                }
+                if (!more) break;
+                have = next_block(e0);
+                if (have) load_block(0, e0);
+                { TSTAMP(p0) process_block(1); TSTAMP(p1)
+#ifdef ST_STAMPS
+                  c_proc += p1 - p0; ++c_blocks;
+#endif
+                }
             }
         }
         TSTAMP(t_w1)
@@ -616,9 +670,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 template <int MODE>
 static void splat_band_launch(const float* img, int64_t ibs, int64_t ics, const float* flow, const float* metric, const float* blk, const float* sbt,
                               float* out, int N, int C, int H, int W, int nsb_x, int nsb, hipStream_t s) {
-    if (C <= 3) {                  // images: 3 channels + normalisation, 128 x 6 band per wave (12.75 KB of LDS per wave: 3 workgroups per CU)
-        dim3 grid(fldr_cdiv(W, 128), fldr_cdiv(H, 4 * 6), N);
-        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, 128, 6>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
+    if (C <= 3) {                  // images: 3 channels + normalisation, 56 x 12 band per wave (11.4 KB of LDS per wave: 3 workgroups per CU)
+        dim3 grid(fldr_cdiv(W, ST_IMG_TW), fldr_cdiv(H, 4 * ST_IMG_TH), N);
+        hipLaunchKernelGGL((splat_band_kernel<MODE, 3, ST_IMG_TW, ST_IMG_TH>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, 1, nsb_x, nsb);
     } else {                       // feature maps: groups of 12 channels, 64 x 4 band per wave (13.5 KB)
         const int groups = fldr_cdiv(C, 12);
         dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4 * 4), N * groups);

@@ -1,7 +1,8 @@
 """NF single-stream 4K forwards (pyramid prebuilt) for a rocprofv3 kernel trace; tools/trace_timeline.py reads the CSV."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
-import fldr_harness as Hn
+import fldr_harness as Hn, fldr_hip
+if os.environ.get("LIB"): fldr_hip.LIB_PATH = os.environ["LIB"]      # experimental build (tools/stamps/build_variant.sh)
 dev = torch.device("cuda:0")
 model, _, args = Hn.prepare_model(dev)
 frames = Hn.frames_from_uint8(Hn.synthetic_pair(2160, 3840, seed=0)).to(dev)
