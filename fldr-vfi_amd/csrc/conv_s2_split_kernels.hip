@@ -48,6 +48,7 @@ struct S2Args {
     int32_t Hin, Win, Hout, Wout;
     int32_t relu;
     int32_t tiles_x, n_tiles, tiles_per_xcd;
+    int32_t N, wgs_per_xcd;    // persistent kernel: samples (tiles are numbered over all samples), workgroups per XCD
 };
 
 // kernel tap (dy, dx) of k slot j (0..7) within row pair rp (0..1): dword d = j / 2 -> (parity, index offset); half j % 2 -> row
@@ -302,6 +303,279 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent variant (enc1 / enc2: the weights of ALL chunks fit in LDS next to the two input stages).
+//
+// The kernel above is latency-bound, not HBM-bound: its 8 x 32 tiles are 7 short iterations (enc1) that each expose one
+// global-load round trip (the next chunk is requested at the top of an iteration and needed at its end) and one weight
+// DMA round trip before the barrier, plus a per-tile prologue (geometry, first chunk) and epilogue; measured on enc1:
+// 405 us, 232 us with the input loads compiled out, unchanged without the MFMAs.  Here
+//   * workgroups are persistent (2 per CU) and walk an XCD-contiguous list of tiles: the weights are fetched once per
+//     workgroup and the (tile, chunk) iterations of all its tiles form ONE pipeline;
+//   * the inputs of iteration j are requested during iteration j-2 (two register sets), split and written to LDS at the
+//     end of iteration j-1 and consumed in iteration j: every load has a whole iteration to land;
+//   * loads are unconditional from clamped offsets (one SGPR plane base + a 32-bit lane offset each) and masked afterwards.
+// Same operand layout, same MFMA order as the kernel above: bit-identical results.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NMT, int PT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv4x4s2_pers_kernel(S2Args a) {
+    // (two workgroups per CU by LDS = 2 waves per SIMD: the full 256-VGPR budget, no spills — a scratch reload would sit in
+    // the same in-order counter as the prefetched inputs and drain them)
+    using Cfg = S2Cfg<MT, NMT>;
+    constexpr int KL = Cfg::KL, STEPS = Cfg::STEPS, IWHP = Cfg::IWHP, KIND = Cfg::KIND, CHS = Cfg::CHS;
+    constexpr int TPR = S2_TW / MT, RPW = PT / TPR;
+    static_assert(4 * RPW == S2_TH, "tile height");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int lj = lane & (MT - 1), lg = lane / MT;
+    const int cin_pad = (a.cin + S2_CC - 1) / S2_CC * S2_CC;
+    const int n_chunks = cin_pad / S2_CC;
+    unsigned char* const wall = smem;                                         // [chunk][W_BYTES]
+    unsigned char* const xst = smem + n_chunks * Cfg::W_BYTES;                // two input stages of X_DW dwords
+
+    // tiles of this workgroup: XCD x owns tiles [x*tpx, (x+1)*tpx) of the N * n_tiles (sample-major) list
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int total_tiles = a.N * a.n_tiles;
+    const int t_end = min((xcd + 1) * a.tiles_per_xcd, total_tiles);
+    const int t_first = xcd * a.tiles_per_xcd + slot;
+    if (t_first >= t_end) return;                                             // workgroup-uniform
+    const int my_tiles = (t_end - t_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_tiles * n_chunks;
+
+    // ---- weights: everything, once ----
+    {
+        const unsigned char* g = reinterpret_cast<const unsigned char*>(a.wpack + S2_HDR);
+        const int wbytes = n_chunks * Cfg::W_BYTES;                           // multiple of 1 KB
+        for (int piece = wave * 64; piece * 16 < wbytes; piece += 256)        // wave-uniform
+            __builtin_amdgcn_global_load_lds((s2_gptr_t)(g + (piece + lane) * 16), (s2_lptr_t)(wall + piece * 16), 16, 0, 0);
+    }
+
+    // ---- per-channel plane pointers (sample 0) and batch strides in VGPR lanes (lane l = channel l; cin <= 64) ----
+    unsigned long long ctab = 0ull;
+    long long btab = 0;
+    if (lane < a.cin) {
+        int s = 0;
+        while (s + 1 < a.n_src && lane >= a.src_cbegin[s + 1]) ++s;
+        ctab = (unsigned long long)reinterpret_cast<uintptr_t>(a.src[s] + (int64_t)(lane - a.src_cbegin[s]) * a.src_cstride[s]);
+        btab = a.src_bstride[s];
+    }
+
+    // ---- staging geometry ----
+    // tile-independent: the LDS dword of item i; per tile: clamped byte offsets of its two rows and their validity bits
+    int l_dw[S2_NI], it_pr2[S2_NI], it_x[S2_NI];
+#pragma unroll
+    for (int i = 0; i < S2_NI; ++i) {
+        const int e = lane + 64 * i;
+        const int pr = e / S2_IW, x = e % S2_IW;
+        it_pr2[i] = 2 * pr; it_x[i] = x;
+        l_dw[i] = e < S2_RP * S2_IW ? (pr * 2 + (x & 1)) * IWHP + (x >> 1) : -1;
+    }
+    uint32_t voff0[S2_NI], voff1[S2_NI];
+    unsigned iss_m0 = 0, iss_m1 = 0;
+    int iss_k = 0, iss_c = 0, iss_n = 0;
+    auto issue_geometry = [&]() __attribute__((always_inline)) {
+        const int t = t_first + iss_k * a.wgs_per_xcd;
+        iss_n = t / a.n_tiles;
+        const int tile = t - iss_n * a.n_tiles;
+        const int ty = tile / a.tiles_x;
+        const int iy0 = ty * S2_TH * 2 - 1, ix0 = (tile - ty * a.tiles_x) * S2_TW * 2 - 1;
+        iss_m0 = 0; iss_m1 = 0;
+#pragma unroll
+        for (int i = 0; i < S2_NI; ++i) {
+            const int gy0 = iy0 + it_pr2[i], gy1 = gy0 + 1, gx = ix0 + it_x[i];
+            const bool okx = l_dw[i] >= 0 && gx >= 0 && gx < a.Win;
+            const bool ok0 = okx && gy0 >= 0 && gy0 < a.Hin, ok1 = okx && gy1 >= 0 && gy1 < a.Hin;
+            iss_m0 |= ok0 ? (1u << i) : 0u;
+            iss_m1 |= ok1 ? (1u << i) : 0u;
+            const int cx = min(max(gx, 0), a.Win - 1);
+            voff0[i] = (uint32_t)(min(max(gy0, 0), a.Hin - 1) * a.Win + cx) * 4u;
+            voff1[i] = (uint32_t)(min(max(gy1, 0), a.Hin - 1) * a.Win + cx) * 4u;
+        }
+    };
+    // request the inputs of the issue side's (tile, chunk) into `dst` and step the issue side; wave w stages channel w
+    // (the two validity words travel in dst[2*S2_NI], dst[2*S2_NI+1])
+    auto issue_loads = [&](float (&dst)[2 * S2_NI + 2]) __attribute__((always_inline)) {
+        const int c = iss_c * S2_CC + wave_u;                                 // wave-uniform
+        const unsigned long long e = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(ctab >> 32), c & 63) << 32) |
+                                     (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ctab, c & 63);
+        const long long bs = (long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)btab >> 32), c & 63) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(unsigned long long)btab, c & 63));
+        const bool live = c < a.cin;                                          // padding channels of the last chunk read plane 0 and are masked
+        const auto* base = (const __attribute__((address_space(1))) char*)(live ? e + (unsigned long long)(iss_n * bs) * 4ull : (unsigned long long)reinterpret_cast<uintptr_t>(a.src[0]));
+#pragma unroll
+        for (int i = 0; i < S2_NI; ++i) {
+            dst[2 * i] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]);
+            dst[2 * i + 1] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]);
+        }
+        dst[2 * S2_NI] = __uint_as_float(live ? iss_m0 : 0u); dst[2 * S2_NI + 1] = __uint_as_float(live ? iss_m1 : 0u);
+        if (++iss_c == n_chunks) { iss_c = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }      // (past the end: the last tile again)
+    };
+    auto store_inputs = [&](unsigned char* stage, const float (&src)[2 * S2_NI + 2]) __attribute__((always_inline)) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const unsigned m0 = __float_as_uint(src[2 * S2_NI]), m1 = __float_as_uint(src[2 * S2_NI + 1]);
+        h2* hi = reinterpret_cast<h2*>(stage) + wave * CHS;
+        h2* lo = hi + KIND;
+#pragma unroll
+        for (int i = 0; i < S2_NI; ++i) {
+            if (l_dw[i] < 0) continue;
+            const float x0 = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
+            const float t0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u);
+            const float t1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
+            h2 h, l;
+            h[0] = (_Float16)t0; h[1] = (_Float16)t1;
+            l[0] = (_Float16)(x0 - t0); l[1] = (_Float16)(x1 - t1);
+            hi[l_dw[i]] = h;
+            lo[l_dw[i]] = l;
+        }
+    };
+
+    // ---- operand geometry (as above) ----
+    const int cps = KL / 2;
+    const int b_ch = cps == 2 ? (lg >> 1) : 0;
+    const int b_rp = cps == 2 ? (lg & 1) : lg;
+    int boff[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int r = wave * RPW + p / TPR, xl = (p % TPR) * MT + lj;
+        boff[p] = b_ch * CHS + ((r + b_rp) * 2) * IWHP + xl;
+    }
+    typedef typename std::conditional<MT == 32, s2_f16, s2_f4>::type acc_t;
+    constexpr int NR = MT == 32 ? 16 : 4;
+    acc_t acc[NMT][PT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[m][p][r] = 0.0f;
+
+    const float inv_scale = a.wpack[0];
+    const int64_t HWo = (int64_t)a.Hout * a.Wout;
+    int cur_k = 0, cur_c = 0;
+    float bias_r[NMT][NR];                                                    // this lane's output channels, fetched once
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg : m * 16 + lg * 4 + r;
+            bias_r[m][r] = a.bias ? a.bias[co < a.cout ? co : a.cout - 1] : 0.0f;
+        }
+
+    auto mfma_phase = [&](const unsigned char* xs, int ch) __attribute__((always_inline)) {
+        const int* xin = reinterpret_cast<const int*>(xs);
+        const unsigned char* win = wall + ch * Cfg::W_BYTES + lane * 16;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            s2_h8 ah[NMT], al[NMT];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                ah[m] = *reinterpret_cast<const s2_h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+                al[m] = *reinterpret_cast<const s2_h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            }
+            const int cbase = s * cps * CHS;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int* q = xin + cbase + boff[p];
+                s2_i4 bhi, blo;
+                bhi[0] = q[0]; bhi[1] = q[1]; bhi[2] = q[IWHP]; bhi[3] = q[IWHP + 1];
+                blo[0] = q[KIND]; blo[1] = q[KIND + 1]; blo[2] = q[KIND + IWHP]; blo[3] = q[KIND + IWHP + 1];
+                const s2_h8 bh = __builtin_bit_cast(s2_h8, bhi), bl = __builtin_bit_cast(s2_h8, blo);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    if constexpr (MT == 32) {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m][p], 0, 0, 0);
+                    } else {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][p], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    // undo the weight scale, bias, ReLU, store (lane = pixel column, registers = output channels); clears the accumulators
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int t = t_first + cur_k * a.wgs_per_xcd;
+        const int n = t / a.n_tiles, tile = t - n * a.n_tiles;
+        const int ty = tile / a.tiles_x;
+        const int oy0 = ty * S2_TH, ox0 = (tile - ty * a.tiles_x) * S2_TW;
+        float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
+        unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
+        const int lk = lg;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int oy = oy0 + wave * RPW + p / TPR;
+            const int ox = ox0 + (p % TPR) * MT + lj;
+            const bool pix_ok = oy < a.Hout && ox < a.Wout;
+            const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                float vv[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                    float v = acc[m][p][r] * inv_scale + bias_r[m][r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    vv[r] = v;
+                    acc[m][p][r] = 0.0f;
+                    if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+                }
+                if (spkn) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int r0 = 0; r0 < NR; r0 += 4) {
+                        const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
+                        h4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                            const float t2 = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+                            hi[r] = (_Float16)t2;
+                            lo[r] = (_Float16)(x - t2);
+                        }
+                        if (co0 < a.cout_store && pix_ok) {
+                            unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
+                            *reinterpret_cast<h4*>(q) = hi;
+                            *reinterpret_cast<h4*>(q + HWo * 16) = lo;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- pipeline: iteration j computes on stage j & 1; its inputs were requested in iteration j-2 ----
+    // Every iteration issues its 20 loads UNCONDITIONALLY (past the end they re-read the last tile: harmless) and the
+    // epilogue's stores come after the LDS write, so that between the request of a register set and its use there is
+    // exactly one other request: the compiler's wait becomes a counted vmcnt(20) instead of a drain.
+    float preA[2 * S2_NI + 2], preB[2 * S2_NI + 2];
+    issue_geometry();
+    issue_loads(preA);                                                        // iteration 0
+    issue_loads(preB);                                                        // iteration 1
+    store_inputs(xst, preA);
+    __syncthreads();                                                          // (drains the weight DMA too)
+    unsigned char* const xs0 = xst;
+    unsigned char* const xs1 = xst + Cfg::X_DW * 4;
+    for (int j = 0; j < total; j += 2) {
+        // even iteration: stage 0; requests iteration j+2 into A (A held iteration j: consumed), writes iteration j+1 from B
+        issue_loads(preA);
+        mfma_phase(xs0, cur_c);
+        store_inputs(xs1, preB);
+        if (cur_c == n_chunks - 1) { epilogue(); cur_c = 0; ++cur_k; } else ++cur_c;
+        __syncthreads();
+        if (j + 1 >= total) break;
+        // odd iteration: stage 1; requests j+3 into B, writes j+2 from A
+        issue_loads(preB);
+        mfma_phase(xs1, cur_c);
+        store_inputs(xs0, preA);
+        if (cur_c == n_chunks - 1) { epilogue(); cur_c = 0; ++cur_k; } else ++cur_c;
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // prepack: max|w| -> power-of-two scale -> hi/lo halves in A-operand order [chunk][step][m][kind][lane][8 halves]
 // ------------------------------------------------------------------------------------------------
 static inline void s2_geometry(int cout, int& mt, int& nmt) {
@@ -395,6 +669,30 @@ static int s2_launch(S2Args& a, int N, hipStream_t s) {
     FLDR_LAUNCH_RET();
 }
 
+// Persistent kernel: 2 workgroups per CU (LDS: all weights + two input stages), XCD-contiguous tile ranges.
+static int g_s2_persistent = 1;
+extern "C" int fldr_debug_s2_persistent(int v) { if (v >= 0) g_s2_persistent = v; return g_s2_persistent; }
+
+template <int MT, int NMT, int PT>
+static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {
+    static int attr_bytes = 0;
+    if (attr_bytes < lds_bytes) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4x4s2_pers_kernel<MT, NMT, PT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_bytes = lds_bytes;
+    }
+    a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
+    a.n_tiles = a.tiles_x * fldr_cdiv(a.Hout, S2_TH);
+    a.N = N;
+    const int64_t total = (int64_t)N * a.n_tiles;
+    if (total >= (1ll << 30)) return FLDR_E_SHAPE;
+    a.tiles_per_xcd = (int)((total + 7) / 8);
+    a.wgs_per_xcd = a.tiles_per_xcd < 64 ? a.tiles_per_xcd : 64;
+    hipLaunchKernelGGL((conv4x4s2_pers_kernel<MT, NMT, PT>), dim3(8 * a.wgs_per_xcd), dim3(256), lds_bytes, s, a);
+    FLDR_LAUNCH_RET();
+}
+
 // Same descriptor as fldr_conv2d (ksize 4, stride 2; no up2 sources, no residual); d->wpack from fldr_conv_s2_prepack.
 extern "C" int fldr_conv2d_s2_split(const fldr_conv_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->wpack && (d->out || d->out_spk) && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
@@ -421,6 +719,13 @@ extern "C" int fldr_conv2d_s2_split(const fldr_conv_desc* d, fldr_stream_t strea
     int mt, nmt;
     s2_geometry(d->cout, mt, nmt);
     hipStream_t s = fldr_s(stream);
+    if ((int64_t)d->Hin * d->Win * 4 >= (1ll << 32)) return FLDR_E_SHAPE;
+    // persistent kernel when every chunk's weights fit in LDS next to the input stages with two workgroups per CU
+    const int n_chunks = (d->cin + S2_CC - 1) / S2_CC;
+    if (g_s2_persistent && d->cin <= 64) {
+        if (mt == 16) { const int lds = n_chunks * S2Cfg<16, 1>::W_BYTES + 2 * S2Cfg<16, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers<16, 1, 4>(a, d->N, s, lds); }
+        else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers<32, 1, 2>(a, d->N, s, lds); }
+    }
     if (mt == 16) return s2_launch<16, 1, 4>(a, d->N, s);
     if (nmt == 1) return s2_launch<32, 1, 2>(a, d->N, s);
     return s2_launch<32, 2, 2>(a, d->N, s);

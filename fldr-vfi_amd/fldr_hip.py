@@ -97,6 +97,7 @@ _SIGNATURES = {
     "fldr_conv_s2_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
     "fldr_conv_s2_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_s2_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_debug_s2_persistent": (ctypes.c_int, [ctypes.c_int]),
     "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

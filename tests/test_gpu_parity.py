@@ -197,6 +197,27 @@ def test_stride2_split_conv_is_fp32_equivalent(hip, dev, shape):
     assert esp.mean() <= 1.5 * e32.mean() + 1e-8 and esp.max() <= 2.0 * e32.max() + 1e-7
 
 
+@pytest.mark.parametrize("shape", [([3, 3, 2, 5], 16, 40, 72, 1), ([16], 32, 34, 70, 2), ([26], 16, 50, 38, 3), ([5], 16, 18, 66, 1)])
+def test_stride2_persistent_kernel_bit_identical_to_per_tile(hip, dev, shape):
+    """The persistent stride-2 kernel (weights resident in LDS, inputs requested two iterations ahead) against the per-tile
+    kernel it replaces for enc1 / enc2: same operand layout and MFMA order => identical fp32 and split-packed outputs;
+    partial tiles, several samples, multi-source concatenation."""
+    parts, cout, H, W, N = shape
+    g = _gen(23)
+    srcs = [(torch.rand(N, c, H, W, generator=g) * 2 - 1).to(dev) for c in parts]
+    wt = ((torch.rand(cout, sum(parts), 4, 4, generator=g) - 0.5) / 4).to(dev)
+    b = (torch.rand(cout, generator=g) - 0.5).to(dev)
+    outs = []
+    try:
+        for mode in (0, 1):
+            hip.lib().fldr_debug_s2_persistent(mode)
+            o, sp = hip.conv2d(srcs, wt, b, stride=2, relu=True, precision="split", want_spk=True)
+            outs.append((o.clone(), sp.buf.clone()))
+    finally:
+        hip.lib().fldr_debug_s2_persistent(1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_splat_and_correlation_backward(hip, oracle, dev):
     """fldr_softsplat_bwd / fldr_correlation_bwd against the oracle's restatement of the reference's backward kernels, and
     autograd through FunctionSoftsplat / FunctionCorrelation (the training-side use of the operators)."""
