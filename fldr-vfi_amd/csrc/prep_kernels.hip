@@ -22,9 +22,15 @@ struct PrepArgs {
     float* flow_t0; float* flow_t1; float* flowback_0; float* flowback_1;   // [N,2,H,W]
     float* im0_tot; float* im1_tot;                                         // [N,3,H,W]
     int h, w, H, W;
-    float sy, sx, mul, inv_wm1, inv_hm1, za0, za1;
+    float sy, sx, mul, inv_wm1, inv_hm1, r_wm1, r_hm1, za0, za1;     // inv_*: the grid normalisation divisors max(S-1,1); r_*: their reciprocals
     int withmask;
 };
+
+// Uniform base pointer + 32-bit byte offset: one global_load / global_store with an SGPR base and a VGPR offset, no 64-bit
+// address arithmetic per access (the kernel is bound by its VALU instruction count).  Planes are < 4 GB (host-checked).
+__device__ __forceinline__ float prep_ldf(const float* __restrict__ base, uint32_t boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff); }
+__device__ __forceinline__ float2 prep_ldf2(const float2* __restrict__ base, uint32_t boff) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + boff); }
+__device__ __forceinline__ void prep_stf(float* __restrict__ base, uint32_t boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
 
 // Source indices / weight of F.interpolate(bilinear, align_corners=False) along one axis (fldr_lin_src), computed once
 // and shared by every plane and tap that is evaluated at the same coordinate.
@@ -40,10 +46,11 @@ struct PrepQuad { float4 a00, a01, a10, a11; };
 __device__ __forceinline__ PrepQuad prep_quad(const float2* __restrict__ p10, const float2* __restrict__ p01, int w, const PrepLin& ix,
                                               const PrepLin& iy) {
     PrepQuad q;
-    const int64_t o00 = (int64_t)iy.i0 * w + ix.i0, o01 = (int64_t)iy.i0 * w + ix.i1;
-    const int64_t o10 = (int64_t)iy.i1 * w + ix.i0, o11 = (int64_t)iy.i1 * w + ix.i1;
-    const float2 b00 = p10[o00], b01 = p10[o01], b10 = p10[o10], b11 = p10[o11];
-    const float2 c00 = p01[o00], c01 = p01[o01], c10 = p01[o10], c11 = p01[o11];
+    const uint32_t y0 = __umul24((uint32_t)iy.i0, (uint32_t)w), y1 = __umul24((uint32_t)iy.i1, (uint32_t)w);   // full-rate 24-bit multiplies
+    const uint32_t o00 = (y0 + (uint32_t)ix.i0) * 8u, o01 = (y0 + (uint32_t)ix.i1) * 8u;
+    const uint32_t o10 = (y1 + (uint32_t)ix.i0) * 8u, o11 = (y1 + (uint32_t)ix.i1) * 8u;
+    const float2 b00 = prep_ldf2(p10, o00), b01 = prep_ldf2(p10, o01), b10 = prep_ldf2(p10, o10), b11 = prep_ldf2(p10, o11);
+    const float2 c00 = prep_ldf2(p01, o00), c01 = prep_ldf2(p01, o01), c10 = prep_ldf2(p01, o10), c11 = prep_ldf2(p01, o11);
     q.a00 = make_float4(b00.x, b00.y, c00.x, c00.y); q.a01 = make_float4(b01.x, b01.y, c01.x, c01.y);
     q.a10 = make_float4(b10.x, b10.y, c10.x, c10.y); q.a11 = make_float4(b11.x, b11.y, c11.x, c11.y);
     return q;
@@ -79,10 +86,11 @@ __device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const FldrTap
     // of xb columns (dx, dx+1) with dx = lxb.i0 - lxa.i0 in {0,1}; rows alike
     const int c0 = lxa.i0, c1 = min(c0 + 1, a.w - 1), c2 = min(c0 + 2, a.w - 1);
     const int r0 = lya.i0, r1 = min(r0 + 1, a.h - 1), r2 = min(r0 + 2, a.h - 1);
-    const float2* q0 = lo2 + (int64_t)r0 * a.w;
-    const float2* q1 = lo2 + (int64_t)r1 * a.w;
-    const float2* q2 = lo2 + (int64_t)r2 * a.w;
-    const float2 m[3][3] = {{q0[c0], q0[c1], q0[c2]}, {q1[c0], q1[c1], q1[c2]}, {q2[c0], q2[c1], q2[c2]}};
+    const uint32_t q0 = __umul24((uint32_t)r0, (uint32_t)a.w) * 8u, q1 = __umul24((uint32_t)r1, (uint32_t)a.w) * 8u, q2 = __umul24((uint32_t)r2, (uint32_t)a.w) * 8u;
+    const uint32_t k0 = (uint32_t)c0 * 8u, k1 = (uint32_t)c1 * 8u, k2 = (uint32_t)c2 * 8u;
+    const float2 m[3][3] = {{prep_ldf2(lo2, q0 + k0), prep_ldf2(lo2, q0 + k1), prep_ldf2(lo2, q0 + k2)},
+                            {prep_ldf2(lo2, q1 + k0), prep_ldf2(lo2, q1 + k1), prep_ldf2(lo2, q1 + k2)},
+                            {prep_ldf2(lo2, q2 + k0), prep_ldf2(lo2, q2 + k1), prep_ldf2(lo2, q2 + k2)}};
     const bool dx = lxb.i0 != lxa.i0, dy = lyb.i0 != lya.i0;
     const float wxa = 1.0f - lxa.l, wxb = 1.0f - lxb.l, wya = 1.0f - lya.l, wyb = 1.0f - lyb.l;
     float o[2];
@@ -129,7 +137,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     const int n = blockIdx.z;
     if (px >= a.W || py >= a.H) return;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
-    const int64_t pix = (int64_t)py * a.W + px;
+    const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;      // byte offset of this pixel inside a plane
     const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;       // flow_10 (x,y)
     const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;   // flow_01 (x,y); quad channels: 0,1 = flow_10, 2,3 = flow_01
     const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
@@ -139,7 +147,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     // the frames at this pixel (direct reads, issued first)
     float c0[3], c1[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { c0[c] = i0[(int64_t)c * a.i0_cstride + pix]; c1[c] = i1[(int64_t)c * a.i1_cstride + pix]; }
+    for (int c = 0; c < 3; ++c) { c0[c] = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb); }
 
     // upsampled flows at this pixel (fLDRnet.py:419-422)
     const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
@@ -149,8 +157,8 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 
     // splat metrics (fLDRnet.py:442-446 = zmetric_kernel): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10)
     if (a.z0) {
-        const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
-        const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
+        const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+        const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
         const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
         float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
@@ -160,39 +168,39 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
             acc0 += a.za0 * fabsf(c0[c] - w0);
             acc1 += a.za1 * fabsf(c1[c] - w1);
         }
-        a.z0[(int64_t)n * HW + pix] = acc0 / 3.0f;
-        a.z1[(int64_t)n * HW + pix] = acc1 / 3.0f;
+        prep_stf(a.z0 + (int64_t)n * HW, pixb, fldr_div_by(acc0, 3.0f, 1.0f / 3.0f));      // == acc0 / 3.0f (the mean over the 3 channels)
+        prep_stf(a.z1 + (int64_t)n * HW, pixb, fldr_div_by(acc1, 3.0f, 1.0f / 3.0f));
     }
 
     // t-scaled forward flows (fLDRnet.py:404-405,419-422): upsampling of (t * flow_01_lo) and ((1-t) * flow_10_lo)
-    const int64_t o2 = (int64_t)n * 2 * HW + pix;
-    a.flow_t0[o2] = prep_up(q, 2, lx, ly, a.mul, 1, tv);
-    a.flow_t0[o2 + HW] = prep_up(q, 3, lx, ly, a.mul, 1, tv);
-    a.flow_t1[o2] = prep_up(q, 0, lx, ly, a.mul, 1, omt);
-    a.flow_t1[o2 + HW] = prep_up(q, 1, lx, ly, a.mul, 1, omt);
+    const int64_t o2 = (int64_t)n * 2 * HW;                     // (uniform: plane bases below are scalar)
+    prep_stf(a.flow_t0 + o2, pixb, prep_up(q, 2, lx, ly, a.mul, 1, tv));
+    prep_stf(a.flow_t0 + o2 + HW, pixb, prep_up(q, 3, lx, ly, a.mul, 1, tv));
+    prep_stf(a.flow_t1 + o2, pixb, prep_up(q, 0, lx, ly, a.mul, 1, omt));
+    prep_stf(a.flow_t1 + o2 + HW, pixb, prep_up(q, 1, lx, ly, a.mul, 1, omt));
 
     // backward flows (fLDRnet.py:474-475 = bwarp_kernel with scales): flowback_0 = bwarp(t * flow_10, (1-t) * flow_01),
     // flowback_1 = bwarp((1-t) * flow_01, t * flow_10)
-    const FldrTap tb0 = fldr_grid_tap((float)px, (float)py, omt * f01x, omt * f01y, a.W, a.H, a.inv_wm1, a.inv_hm1);
-    const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1);
+    const FldrTap tb0 = fldr_grid_tap((float)px, (float)py, omt * f01x, omt * f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+    const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
     const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
     const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
     float fb0x, fb0y, fb1x, fb1y;
     prep_sample_up2(tb0, tb0p, lo10, a, tv, fb0x, fb0y);
     prep_sample_up2(tb1, tb1p, lo01, a, omt, fb1x, fb1y);
     fb0x = fb0x * mb0; fb0y = fb0y * mb0; fb1x = fb1x * mb1; fb1y = fb1y * mb1;
-    a.flowback_0[o2] = fb0x; a.flowback_0[o2 + HW] = fb0y;
-    a.flowback_1[o2] = fb1x; a.flowback_1[o2 + HW] = fb1y;
+    prep_stf(a.flowback_0 + o2, pixb, fb0x); prep_stf(a.flowback_0 + o2 + HW, pixb, fb0y);
+    prep_stf(a.flowback_1 + o2, pixb, fb1x); prep_stf(a.flowback_1 + o2 + HW, pixb, fb1y);
 
     // backward-warped frames (fLDRnet.py:478-479 = bwarp_kernel)
-    const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb0x, fb0y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
-    const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb1x, fb1y, a.W, a.H, a.inv_wm1, a.inv_hm1), a.W, a.H);
+    const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb0x, fb0y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+    const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb1x, fb1y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
     const float mi0 = a.withmask ? fldr_tap_mask_p(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1) : 1.0f;
-    const int64_t o3 = (int64_t)n * 3 * HW + pix;
+    const int64_t o3 = (int64_t)n * 3 * HW;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        a.im0_tot[o3 + (int64_t)c * HW] = fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0;
-        a.im1_tot[o3 + (int64_t)c * HW] = fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1;
+        prep_stf(a.im0_tot + o3 + (int64_t)c * HW, pixb, fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0);
+        prep_stf(a.im1_tot + o3 + (int64_t)c * HW, pixb, fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1);
     }
 }
 
@@ -208,6 +216,7 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     a.h = d->h; a.w = d->w; a.H = d->H; a.W = d->W;
     a.sy = (float)d->h / (float)d->H; a.sx = (float)d->w / (float)d->W; a.mul = d->mul;
     a.inv_wm1 = (float)(d->W - 1 > 1 ? d->W - 1 : 1); a.inv_hm1 = (float)(d->H - 1 > 1 ? d->H - 1 : 1);
+    a.r_wm1 = 1.0f / a.inv_wm1; a.r_hm1 = 1.0f / a.inv_hm1;
     a.za0 = d->z_alpha0; a.za1 = d->z_alpha1; a.withmask = d->withmask;
     const int64_t hw = (int64_t)d->h * d->w;
     hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,

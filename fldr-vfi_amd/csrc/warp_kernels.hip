@@ -324,7 +324,7 @@ __global__ __launch_bounds__(256) void bwarp_kernel(const float* __restrict__ x,
     const float* fl = flo + (int64_t)n * 2 * HW;
     const float xs = tscale(xs_mode, t, n), fs = tscale(fs_mode, t, n);
     FldrTap tp = fldr_grid_tap((float)px, (float)py, fs_mode ? fs * fl[pix] : fl[pix], fs_mode ? fs * fl[HW + pix] : fl[HW + pix],
-                               W, H, inv_wm1, inv_hm1);
+                               W, H, inv_wm1, inv_hm1, 1.0f / inv_wm1, 1.0f / inv_hm1);
     float m = withmask ? fldr_tap_mask(tp) : 1.0f;
     const float* xp = x + (int64_t)n * C * HW;
     float* op = out + (int64_t)n * C * HW + pix;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void zmetric_kernel(const float* __restrict__ 
     const int64_t HW = (int64_t)H * W;
     const int64_t pix = (int64_t)py * W + px;
     const float* fl = flow + (int64_t)n * 2 * HW;
-    FldrTap t = fldr_grid_tap((float)px, (float)py, fl[pix], fl[HW + pix], W, H, inv_wm1, inv_hm1);
+    FldrTap t = fldr_grid_tap((float)px, (float)py, fl[pix], fl[HW + pix], W, H, inv_wm1, inv_hm1, 1.0f / inv_wm1, 1.0f / inv_hm1);
     float m = fldr_tap_mask(t);
     const float* sp = self_img + (int64_t)n * C * HW + pix;
     const float* op = other + (int64_t)n * C * HW;
