@@ -54,23 +54,38 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     const int i0 = blockIdx.y * D3_TH, j0 = blockIdx.x * D3_TW, n = blockIdx.z;
     const float* src = d2 + (int64_t)n * D3_CIN * h * w;
     constexpr int TILE_E = (D3_TH + 2) * (D3_TW + 2);
-    constexpr int NLD = (D3_CIN * TILE_E + 255) / 256;
-    float st[NLD];
+    // Staging: this thread's (up to two) slots of a channel's (TH+2) x (TW+2) tile are the same for all 16 channels, so the
+    // index arithmetic is done once and every load is a scalar channel base + a precomputed 32-bit lane offset (the kernel
+    // is bound by its vector-ALU instruction count: the flat element -> (channel, row, column) decode per load cost
+    // ~400 instructions per thread).  Unconditional clamped loads, then mask (see common.h).
+    static_assert(TILE_E <= 512, "two slots per thread");
+    uint32_t goff[2];
+    int lidx[2];
+    bool inb[2];
 #pragma unroll
-    for (int q = 0; q < NLD; ++q) {                      // unconditional clamped loads, then mask (see common.h)
-        const int e = tid + 256 * q;
-        const int c = min(e / TILE_E, D3_CIN - 1), r = e % TILE_E;
-        const int gy = i0 - 1 + r / (D3_TW + 2), gx = j0 - 1 + r % (D3_TW + 2);
+    for (int j = 0; j < 2; ++j) {
+        const int r = tid + 256 * j;
+        const int rr = r < TILE_E ? r : 0;
+        const int gy = i0 - 1 + rr / (D3_TW + 2), gx = j0 - 1 + rr % (D3_TW + 2);
         const int cy = min(max(gy, 0), h - 1), cx = min(max(gx, 0), w - 1);
-        st[q] = src[((int64_t)c * h + cy) * w + cx];
+        goff[j] = (__umul24((uint32_t)cy, (uint32_t)w) + (uint32_t)cx) * 4u;
+        lidx[j] = r < TILE_E ? r : -1;
+        inb[j] = gy >= 0 && gy < h && gx >= 0 && gx < w;
+    }
+    float st[D3_CIN][2];
+    const int64_t hw = (int64_t)h * w;
+#pragma unroll
+    for (int c = 0; c < D3_CIN; ++c) {
+        const char* base = reinterpret_cast<const char*>(src + c * hw);          // uniform
+        st[c][0] = *reinterpret_cast<const float*>(base + goff[0]);
+        st[c][1] = *reinterpret_cast<const float*>(base + goff[1]);
     }
 #pragma unroll
-    for (int q = 0; q < NLD; ++q) {
-        const int e = tid + 256 * q;
-        const int r = e % TILE_E;
-        const int gy = i0 - 1 + r / (D3_TW + 2), gx = j0 - 1 + r % (D3_TW + 2);
-        fldr_pin(st[q]);
-        if (e < D3_CIN * TILE_E) (&tile[0][0][0])[e] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? st[q] : 0.0f;
+    for (int c = 0; c < D3_CIN; ++c) {
+        fldr_pin(st[c][0]); fldr_pin(st[c][1]);
+        float* tc = &tile[c][0][0];
+        tc[lidx[0]] = inb[0] ? st[c][0] : 0.0f;                                   // (tid < 256 <= TILE_E: slot 0 always exists)
+        if (lidx[1] >= 0) tc[lidx[1]] = inb[1] ? st[c][1] : 0.0f;
     }
     __syncthreads();
 
@@ -82,12 +97,12 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     const int lic = min(li, h - 1), ljc = min(lj, w - 1);
     float2 cv[2][6][3];
     auto load_cands = [&](int a) __attribute__((always_inline)) {
-        const int64_t po = (int64_t)(2 * lic + a) * W + 2 * ljc;
+        const uint32_t pob = (__umul24((uint32_t)(2 * lic + a), (uint32_t)W) + (uint32_t)(2 * ljc)) * 4u;     // byte offset inside a plane (< 4 GB, host-checked)
 #pragma unroll
         for (int k = 0; k < 6; ++k)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
-                cv[a][k][ch] = *reinterpret_cast<const float2*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k] + po);
+                cv[a][k][ch] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k]) + pob);
     };
     load_cands(0);
 
@@ -173,7 +188,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
         // both pixels of the pair in one 16-B (fp64) / 8-B (fp32) store per channel
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
-            OUT* o = out + ((int64_t)n * 3 + ch) * HW + po;
+            char* o = reinterpret_cast<char*>(out + ((int64_t)n * 3 + ch) * HW) + (uint32_t)po * (uint32_t)sizeof(OUT);      // scalar plane base + 32-bit offset
             if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0][ch], res[1][ch]);
             else *reinterpret_cast<float2*>(o) = make_float2((float)res[0][ch], (float)res[1][ch]);
         }
@@ -193,6 +208,7 @@ extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const
     FLDR_CHECK_ARG(d2 && weff && bias && cand && cand_bstride && cand_cstride && t && N > 0 && H > 0 && W > 0);
     FLDR_CHECK_ARG((out_f64 != nullptr) != (out_f32 != nullptr));
     if ((H | W) & 1) return FLDR_E_SHAPE;
+    if ((int64_t)H * W * 8 >= (1ll << 32)) return FLDR_E_SHAPE;            // 32-bit byte offsets inside a plane
     FLDR_CHECK_ARG(((reinterpret_cast<uintptr_t>(out_f64) & 15) | (reinterpret_cast<uintptr_t>(out_f32) & 7)) == 0);     // pixel pairs are stored whole
     FinalArgs a;
     for (int k = 0; k < 6; ++k) {
