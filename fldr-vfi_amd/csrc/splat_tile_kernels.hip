@@ -577,7 +577,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
                 cx0 = min(cx0, __shfl_xor(cx0, o)); cx1 = max(cx1, __shfl_xor(cx1, o));
                 cy0 = min(cy0, __shfl_xor(cy0, o)); cy1 = max(cy1, __shfl_xor(cy1, o));
             }
-            if (cx1 >= 0 && rxmax - rxmin < 1.0e6f && rymax - rymin < 1.0e6f) {       // (finite, sane bounds; wave-uniform)
+            if (cx1 >= 0 && fabsf(rxmin) < 1.0e6f && fabsf(rxmax) < 1.0e6f && fabsf(rymin) < 1.0e6f && fabsf(rymax) < 1.0e6f) {   // (finite, int-safe bounds; wave-uniform)
                 // x + fx >= tx0 - 2 and x + fx <= tx1 + 1 for some fx in [rxmin, rxmax]  (st_match with rx0 = rx1 = x)
                 const int X0 = max(cx0, (int)floorf(ftx0 - 2.0f - rxmax)), X1 = min(min(cx1, W - 1), (int)ceilf(ftx1 + 1.0f - rxmin));
                 const int Y0 = max(cy0, (int)floorf(fty0 - 2.0f - rymax)), Y1 = min(min(cy1, H - 1), (int)ceilf(fty1 + 1.0f - rymin));

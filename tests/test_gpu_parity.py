@@ -272,6 +272,27 @@ def test_tile_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
     _cmp(out, oracle.function_softsplat(x, flow, z, mode), atol=3e-5, rtol=1e-5, what="tile " + mode)
 
 
+def test_tile_softsplat_extreme_and_smooth_flows(hip, oracle, dev):
+    """Band splat corner cases: a smooth flow field (trimmed candidate walk) with 1 % of the vectors thrown out to
+    +-3e9 px (bounds far beyond int range: the block walk takes over where they occur) and a pure sub-pixel shift."""
+    g = _gen(41)
+    N, C, H, W = 1, 3, 150, 400
+    x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+    lo = torch.randn(N, 2, 5, 9, generator=g) * 4
+    flow = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False) + 7.3
+    z = torch.randn(N, 1, H, W, generator=g)
+    out = hip.softsplat_fused(x.to(dev), flow.to(dev), z.to(dev), "softmax", kernel="tile")
+    _cmp(out, oracle.function_softsplat(x, flow, z, "softmax"), atol=3e-5, rtol=1e-5, what="smooth flow")
+    wild = flow.clone()
+    m = torch.rand(N, 1, H, W, generator=g) < 0.01
+    wild = torch.where(m, torch.where(torch.rand(N, 2, H, W, generator=g) < 0.5, torch.tensor(3.0e9), torch.tensor(-3.0e9)), wild)
+    out = hip.softsplat_fused(x.to(dev), wild.to(dev), z.to(dev), "softmax", kernel="tile")
+    _cmp(out, oracle.function_softsplat(x, wild, z, "softmax"), atol=3e-5, rtol=1e-5, what="smooth flow with outliers")
+    shift = torch.zeros(N, 2, H, W); shift[:, 0] = 0.25; shift[:, 1] = -0.5
+    out = hip.softsplat_fused(x.to(dev), shift.to(dev), None, "average", kernel="tile")
+    _cmp(out, oracle.function_softsplat(x, shift, None, "average"), atol=3e-5, rtol=1e-5, what="sub-pixel shift")
+
+
 def test_splat_known_answers(hip, dev):
     import softSplat
     sp = softSplat.Softsplat()
