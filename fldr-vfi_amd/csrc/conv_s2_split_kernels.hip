@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
                         hi[r] = (_Float16)t;
                         lo[r] = (_Float16)(x - t);
                     }
-                    if (co0 < a.cout_store && pix_ok) {
+                    if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                         unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
                         *reinterpret_cast<h4*>(q) = hi;
                         *reinterpret_cast<h4*>(q + HWo * 16) = lo;
@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                             hi[r] = (_Float16)t2;
                             lo[r] = (_Float16)(x - t2);
                         }
-                        if (co0 < a.cout_store && pix_ok) {
+                        if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                             unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
                             *reinterpret_cast<h4*>(q) = hi;
                             *reinterpret_cast<h4*>(q + HWo * 16) = lo;

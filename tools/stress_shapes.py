@@ -1,0 +1,59 @@
+"""Odd-shape stress of the kernels with variant hooks / unfused counterparts: persistent vs per-tile stride-2 conv (bit
+identity), band splat vs strip splat (summation order only), fused level-0 prep vs the unfused kernels (bit identity)."""
+import os, sys, random, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
+import fldr_hip as hip
+dev = torch.device("cuda:0")
+random.seed(0); torch.manual_seed(0)
+bad = 0
+for it in range(40):
+    N = random.choice([1, 1, 2, 3]); cin = random.choice([1, 3, 4, 5, 16, 26, 31, 33, 64]); cout = random.choice([1, 7, 16, 17, 32])
+    H = random.choice([4, 6, 10, 18, 34, 66, 130]); W = random.choice([4, 6, 12, 64, 66, 68, 130, 134, 258])
+    parts, left = [], cin
+    while left > 0:
+        c = min(left, random.choice([1, 2, 3, 5, 16])); parts.append(c); left -= c
+    parts = parts[:10] if len(parts) <= 10 else [cin]
+    srcs = [torch.randn(N, c, H, W, device=dev) for c in parts]
+    wt = torch.randn(cout, cin, 4, 4, device=dev) / 8; b = torch.randn(cout, device=dev)
+    outs = []
+    for mode in (0, 1):
+        hip.lib().fldr_debug_s2_persistent(mode)
+        o, sp = hip.conv2d(srcs, wt, b, stride=2, relu=bool(it & 1), precision="split", want_spk=True)
+        outs.append((o.clone(), sp.buf.clone()))
+    ok = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    bad += not ok
+    if not ok: print("s2 MISMATCH", N, parts, cout, H, W)
+hip.lib().fldr_debug_s2_persistent(1)
+print("stride-2 persistent vs per-tile: 40 shapes,", bad, "mismatches", flush=True)
+bad = 0
+for it in range(30):
+    N = random.choice([1, 2]); C = random.choice([1, 2, 3]); H = random.choice([1, 3, 11, 12, 13, 25, 70]); W = random.choice([1, 2, 55, 56, 57, 113, 300])
+    mode = random.choice(["summation", "average", "linear", "softmax"])
+    x = torch.rand(N, C, H, W, device=dev) * 2 - 1
+    flow = (torch.rand(N, 2, H, W, device=dev) - 0.5) * random.choice([0.0, 1.0, 8.0, 100.0])
+    if random.random() < 0.5:
+        flow = torch.nn.functional.interpolate(torch.randn(N, 2, 2, 3, device=dev) * 5, size=(H, W), mode="bilinear").contiguous()
+    z = torch.rand(N, 1, H, W, device=dev) + 0.1 if mode in ("linear", "softmax") else None
+    a = hip.softsplat_fused(x, flow, z, mode, kernel="tile"); b2 = hip.softsplat_fused(x, flow, z, mode, kernel="strip")
+    err = (a - b2).abs().max().item()
+    if not err < 5e-5: bad += 1; print("splat MISMATCH", N, C, H, W, mode, err)
+print("band vs strip splat: 30 shapes,", bad, "mismatches", flush=True)
+bad = 0
+for it in range(20):
+    N = random.choice([1, 2]); h = random.choice([1, 2, 3, 9, 20]); w = random.choice([1, 2, 5, 15, 33]); up = random.choice([2, 4, 8])
+    H, W = h * up, w * up
+    if W < 2: continue
+    lo = (torch.rand(N, 4, h, w, device=dev) - 0.5) * random.choice([1.0, 6.0, 50.0])
+    x = torch.rand(N, 3, 2, H, W, device=dev) * 2 - 1
+    I0, I1 = x[:, :, 0], x[:, :, 1]
+    t4 = torch.rand(N, 1, 1, 1, device=dev)
+    r = hip.level0_prep(lo, I0, I1, t4, H, W, -1.9, -1.8, withmask=bool(it & 1), want_z=True)
+    both = hip.resize_bilinear(lo, H, W, mul=float(up)); f10, f01 = both[:, :2], both[:, 2:]
+    I0c, I1c = I0.contiguous(), I1.contiguous()
+    ok = torch.equal(r["z0"], hip.zmetric(I0c, I1c, f01, -1.9)) and torch.equal(r["z1"], hip.zmetric(I1c, I0c, f10, -1.8))
+    fb0 = hip.bwarp_tscaled(f10, f01, t4, "t", "1-t", withmask=bool(it & 1)); fb1 = hip.bwarp_tscaled(f01, f10, t4, "1-t", "t", withmask=bool(it & 1))
+    ok = ok and torch.equal(r["flowback_0"], fb0) and torch.equal(r["flowback_1"], fb1)
+    ok = ok and torch.equal(r["im0_tot"], hip.bwarp(I0c, fb0, bool(it & 1))) and torch.equal(r["im1_tot"], hip.bwarp(I1c, fb1, bool(it & 1)))
+    bad += not ok
+    if not ok: print("prep MISMATCH", N, h, w, up)
+print("level0_prep vs unfused kernels: 20 shapes,", bad, "mismatches", flush=True)
