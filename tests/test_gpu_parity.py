@@ -733,3 +733,17 @@ def test_gpu_metrics_and_u8_roundtrip(hip, oracle, weights, dev, model):
     assert (np.abs(diff) > 0).mean() < 1e-3 and np.abs(diff).max() <= 1  # rounding ties aside, identical 8-bit frames
     want = oracle.psnr(gt[0].permute(1, 2, 0).double().numpy(), img[0].permute(1, 2, 0).cpu().double().numpy())
     assert abs(ps[0] - want) < 1e-9
+
+
+def test_odd_shape_stress_of_kernel_variants(hip, dev, capsys):
+    """tools/stress_shapes.py: ~190 random odd shapes (tiny / partial tiles, several samples, multi-source, odd channel
+    counts) of every kernel that has a variant hook or an unfused counterpart — persistent vs per-tile stride-2 conv,
+    split-packed vs register-staged 3x3 conv under both unit policies, band vs strip splat, fused level-0 prep vs the
+    kernels it replaces, one-pass vs two-pass PCA, fused dec3 + tail vs conv + tail."""
+    import os
+    import runpy
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runpy.run_path(os.path.join(root, "tools", "stress_shapes.py"), run_name="__main__")
+    out = capsys.readouterr().out
+    assert "MISMATCH" not in out, out
+    assert out.count(" 0 mismatches") == 6, out

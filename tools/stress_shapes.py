@@ -57,3 +57,53 @@ for it in range(20):
     bad += not ok
     if not ok: print("prep MISMATCH", N, h, w, up)
 print("level0_prep vs unfused kernels: 20 shapes,", bad, "mismatches", flush=True)
+
+# ---- split-packed 3x3 conv vs the register-staged split conv (bit identity), random shapes / sources / options ----
+bad = 0
+for it in range(40):
+    N = random.choice([1, 1, 2]); H = random.choice([2, 4, 8, 10, 18, 34, 66]); W = random.choice([2, 4, 16, 32, 34, 62, 66, 130])
+    nsrc = random.choice([1, 1, 2, 3]); cs = [random.choice([8, 16, 24, 48]) for _ in range(nsrc - 1)] + [random.choice([1, 3, 4, 8, 13, 48, 52])]
+    if sum(cs) > 112: cs = [48, 48, 4]
+    ups = [random.random() < 0.3 for _ in cs]
+    cout = random.choice([1, 4, 6, 16, 17, 32, 40, 48, 64, 96]); cst = random.choice([None, None, min(cout, 4)])
+    relu = bool(it & 1); res = random.random() < 0.3
+    srcs = [torch.randn(N, c, H // 2 if u else H, W // 2 if u else W, device=dev) for c, u in zip(cs, ups)]
+    wt = torch.randn(cout, sum(cs), 3, 3, device=dev) / 20; b = torch.randn(cout, device=dev)
+    rs = torch.randn(N, cst or cout, H, W, device=dev) if res else None
+    ref = hip.conv2d(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, precision="split")
+    for su in (-1, 96):
+        hip.lib().fldr_debug_spk_small_units(su)
+        got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, want_f32=True, want_spk=True)
+        ok = torch.equal(ref, got) and torch.equal(hip.spk_pack(ref).buf, gp.buf)
+        bad += not ok
+        if not ok: print("spk MISMATCH", N, cs, ups, cout, cst, H, W, relu, res, "small_units", su)
+hip.lib().fldr_debug_spk_small_units(96)
+print("split-packed conv vs split conv: 40 shapes x 2 unit policies,", bad, "mismatches", flush=True)
+
+# ---- one-pass PCA (incl. the 4-components-per-thread variant on small grids) vs the two-pass kernel ----
+bad = 0
+for it in range(16):
+    P = random.choice([6, 12]); K = random.choice([4, 8, 16]); H = 8 * random.choice([1, 2, 9, 18, 36, 40]); W = 8 * random.choice([1, 3, 15, 30, 64, 70])
+    ev = torch.randn(K, 64, device=dev, dtype=torch.float64); mean = torch.randn(64, device=dev, dtype=torch.float64) * 0.1
+    mv = torch.rand(K, device=dev, dtype=torch.float64) + 0.5
+    pl = torch.rand(P, H, W, device=dev) * 2 - 1
+    o32, o64, mm = hip.pca_project(pl, ev, mean, mv, want_f64=True)
+    s32, s64, smm, spk = hip.pca_project_stream(pl, ev, mean, mv, want_spk=True)
+    ok = torch.equal(o32, s32) and torch.equal(o64, s64) and torch.equal(mm, smm) and torch.equal(hip.spk_pack(o32.view(1, P * K, H // 8, W // 8)).buf, spk.buf)
+    bad += not ok
+    if not ok: print("pca MISMATCH", P, K, H, W)
+print("one-pass PCA vs two-pass: 16 shapes,", bad, "mismatches", flush=True)
+
+# ---- fused dec3 + tail vs conv + synth_tail ----
+bad = 0
+for it in range(12):
+    N = random.choice([1, 2]); h = random.choice([1, 2, 7, 8, 9, 20]); w = random.choice([1, 2, 31, 32, 33, 70])
+    d2 = torch.rand(N, 16, h, w, device=dev); wt = torch.randn(6, 16, 3, 3, device=dev) / 6; bs = torch.randn(6, device=dev) * 0.3
+    x = torch.rand(N, 3, 2, 2 * h, 2 * w, device=dev) * 2 - 1
+    cands = [torch.rand(N, 3, 2 * h, 2 * w, device=dev) * 2 - 1 for _ in range(4)] + [x[:, :, 0], x[:, :, 1]]
+    t = torch.rand(N, 1, device=dev)
+    out = hip.dec3_synth(d2, wt, bs, cands, t, 1.5616)
+    unf = hip.synth_tail(hip.conv2d([d2], wt, bs, up2=[True]), cands, t, 1.5616)
+    err = (out - unf).abs().max().item()
+    if not err < 3e-6: bad += 1; print("dec3 MISMATCH", N, h, w, err)
+print("fused dec3+tail vs conv + synth_tail: 12 shapes,", bad, "mismatches", flush=True)
