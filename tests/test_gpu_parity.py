@@ -515,6 +515,22 @@ def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
     _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="B=2 forward")
 
 
+@pytest.mark.parametrize("case", [(180, 300, 0.3, 3), (264, 520, 0.875, 4), (140, 700, 0.5, 5)])
+def test_model_matches_oracle_odd_sizes(hip, oracle, weights, dev, model, case):
+    """Frame sizes that are not multiples of the 256-pixel padding unit (reflect padding, partial tiles at every level)."""
+    import fldr_harness as Hn
+    H, W, tv, seed = case
+    m, a = model
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(H, W, seed=seed, quadrant=True))
+    t = torch.tensor([[tv]])
+    out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    assert out.shape[-2:] == (H, W)
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)
+    ref = ref[..., :H, :W]
+    _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="forward %dx%d" % (H, W))
+
+
 # ---------------------------------------------------------------------------------------------------
 # full-size (BASELINE config 2: 3840x2160) checks
 # ---------------------------------------------------------------------------------------------------
