@@ -763,3 +763,32 @@ def test_odd_shape_stress_of_kernel_variants(hip, dev, capsys):
     out = capsys.readouterr().out
     assert "MISMATCH" not in out, out
     assert out.count(" 0 mismatches") == 6, out
+
+
+def test_operators_random_odd_shapes_vs_oracle(hip, oracle, dev):
+    """Correlation (forward / backward), raw splat (forward / backward), bwarp and resize on random odd shapes — single
+    rows / columns, sizes that are not multiples of the 8x32 / 64x4 tiles, several samples — against the oracle."""
+    import random
+    from OpticalFlow import correlation
+    rnd = random.Random(7)
+    g = _gen(77)
+    for _ in range(6):
+        N, C, H, W = rnd.choice([1, 2]), rnd.choice([1, 2, 5, 17, 33]), rnd.choice([1, 2, 7, 9, 31, 40]), rnd.choice([1, 3, 15, 33, 65])
+        a = torch.randn(N, C, H, W, generator=g); b = torch.randn(N, C, H, W, generator=g)
+        _cmp(correlation.FunctionCorrelation(a.to(dev), b.to(dev)), oracle.correlation(a, b), atol=2e-6 * math.sqrt(C) + 1e-6, rtol=1e-5,
+             what="correlation %s" % ((N, C, H, W),))
+        gc = torch.randn(N, 81, H, W, generator=g)
+        ga, gb = hip.correlation_bwd(a.to(dev), b.to(dev), gc.to(dev))
+        ra, rb = oracle.correlation_backward(a, b, gc)
+        _cmp(ga, ra, atol=5e-6, rtol=1e-5, what="correlation gradFirst %s" % ((N, C, H, W),))
+        _cmp(gb, rb, atol=5e-6, rtol=1e-5, what="correlation gradSecond %s" % ((N, C, H, W),))
+    for _ in range(6):
+        N, C, H, W = rnd.choice([1, 2]), rnd.choice([1, 3, 4, 7, 9]), rnd.choice([1, 2, 5, 33, 40]), rnd.choice([1, 2, 63, 64, 65, 130])
+        x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+        flow = (torch.rand(N, 2, H, W, generator=g) - 0.5) * rnd.choice([0.0, 2.0, 30.0])
+        go = torch.randn(N, C, H, W, generator=g)
+        _cmp(hip.softsplat_fwd(x.to(dev), flow.to(dev)), oracle.splat_forward(x, flow), atol=3e-5, rtol=1e-5, what="raw splat %s" % ((N, C, H, W),))
+        gi, gf = hip.softsplat_bwd(x.to(dev), flow.to(dev), go.to(dev))
+        ri, rf = oracle.splat_backward(x, flow, go)
+        _cmp(gi, ri, atol=3e-6, rtol=1e-5, what="splat gradInput %s" % ((N, C, H, W),))
+        _cmp(gf, rf, atol=5e-5, rtol=1e-5, what="splat gradFlow %s" % ((N, C, H, W),))
