@@ -12,14 +12,19 @@ not in results:
   * the level-0 softmax/blend tail runs in fp64 inside one kernel (SURVEY F3) instead of ~30 fp64 passes;
   * only the test branch exists: `is_training=True` raises (training is out of scope).
 """
+import math  # noqa: F401
+import numpy as np  # noqa: F401
 import torch
 import torch.nn as nn
+import torch.nn.functional as F  # noqa: F401
 
 import fldr_hip
-from pca_comp import to_pca_diff, to_pca_diff_f32   # noqa: F401  (to_pca_diff re-exported like the reference)
+from pca_comp import pca_inverse, to_pca_diff, to_pca_diff_f32   # noqa: F401  (re-exported like the reference, fLDRnet.py:18)
 from softSplat import Softsplat
+from useful import torch_prints, numpy_prints, MyPWC  # noqa: F401  (fLDRnet.py:16)
 
-__all__ = ["DCTXVFInet", "DCTVFInet", "PCARefineUNet"]
+# No __all__: the reference's drivers do `from fLDRnet import *` (main.py:18, run_on_your_images.py:15) and pick up the
+# module's public namespace (DCTXVFInet, F, nn, torch, ...) from it; tests/golden/import_contract.json lists what they use.
 
 
 def _conv3(cin, cout):

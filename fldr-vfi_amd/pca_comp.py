@@ -1,6 +1,9 @@
 """Inference-side subset of the reference's pca_comp.py: the `DCTParams` carrier the checkpoints pickle
 (pca_comp.py:300-305) and `to_pca_diff` (pca_comp.py:473-528) on the gfx950 projection kernel.
-The PCA fitting / reconstruction experiments of the reference are training code and not provided."""
+`to_pca` (:370-471, PCA fitting with CuPy SVD) and `pca_inverse` (:309-367, reconstruction experiments) are training
+code: the names exist so that the reference's drivers (`from pca_comp import DCTParams,to_pca`, main.py:12,
+run_on_your_images.py:9; `from pca_comp import pca_inverse,to_pca_diff`, fLDRnet.py:18) import unchanged, and raise
+when CALLED — inference never calls them (main.py reaches to_pca only under --phase train)."""
 from dataclasses import dataclass
 
 import torch
@@ -41,3 +44,14 @@ def to_pca_diff_f32(im, params, args, mean, EV, mean_vec, want_spk=False):
     o32, _, _, spk = fldr_hip.pca_project_stream(im, EV.detach()[:k].contiguous(), mean.detach(),
                                                  mean_vec.detach()[:k].contiguous(), want_spk=want_spk)
     return (o32, spk) if want_spk else o32
+
+
+def to_pca(im, params, components_fraction=0, args=0, pca=0):
+    """Training-time PCA fit / transform of 8x8 blocks (pca_comp.py:370-471).  Not part of the inference path."""
+    raise NotImplementedError("to_pca fits the block PCA during training; inference projects with to_pca_diff on the "
+                              "EV8 / Mean8 / meanVec8 stored in the checkpoint")
+
+
+def pca_inverse(res, params, pcas, comps_used, cut_back=True, wanted_dim=0, args=0):
+    """Reconstruction of image blocks from PCA features (pca_comp.py:309-367), used by training experiments only."""
+    raise NotImplementedError("pca_inverse belongs to the training-time reconstruction experiments")

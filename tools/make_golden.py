@@ -245,7 +245,74 @@ def op_cases(model, fLDRnet, pca_comp, args, out_path):
     print("wrote", out_path, os.path.getsize(out_path) >> 10, "KiB")
 
 
+def import_contract(out_path):
+    """tests/golden/import_contract.json: for every module of the reference that fldr-vfi_amd/ shadows, the NAMES the
+    reference's own files import from it (explicit `from m import a, b`) or use through `from m import *` — collected
+    with `ast` from the import statements and free names of main.py, run_on_your_images.py, utils.py, fLDRnet.py,
+    useful.py and OpticalFlow/PWCNet.py.  Names only; no reference code is copied."""
+    import ast
+    import builtins
+    import json
+    shadowed = ("pca_comp", "useful", "fLDRnet", "softSplat", "OpticalFlow", "OpticalFlow.PWCNet", "OpticalFlow.correlation")
+    files = ("main.py", "run_on_your_images.py", "utils.py", "fLDRnet.py", "useful.py", "OpticalFlow/PWCNet.py")
+
+    def public_toplevel(path):
+        names = set()
+        for n in ast.parse(open(path).read()).body:
+            if isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                names.add(n.name)
+            elif isinstance(n, ast.Import):
+                names.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, ast.ImportFrom):
+                names.update(a.asname or a.name for a in n.names)
+            elif isinstance(n, (ast.Assign, ast.AnnAssign, ast.AugAssign)):
+                names.update(t.id for t in ast.walk(n) if isinstance(t, ast.Name) and isinstance(t.ctx, ast.Store))
+        return {x for x in names if not x.startswith("_")}
+
+    contract = {m: {"names": set(), "star_names": set(), "importers": set()} for m in shadowed}
+    for f in files:
+        tree = ast.parse(open(os.path.join(REF, f)).read())
+        pkg = os.path.dirname(f).replace("/", ".")
+        bound, stars = set(), []
+        for n in ast.walk(tree):
+            if isinstance(n, ast.ImportFrom):
+                mod = n.module or ""
+                if n.level:                                           # `from . import correlation` inside OpticalFlow/
+                    mod = pkg + ("." + mod if mod else "")
+                for a in n.names:
+                    if a.name == "*":
+                        stars.append(mod)
+                    else:
+                        bound.add(a.asname or a.name)
+                        if mod in contract:
+                            contract[mod]["names"].add(a.name)
+                            contract[mod]["importers"].add(f)
+            elif isinstance(n, ast.Import):
+                bound.update((a.asname or a.name).split(".")[0] for a in n.names)
+            elif isinstance(n, (ast.FunctionDef, ast.ClassDef)):
+                bound.add(n.name)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, (ast.Store, ast.Del)):
+                bound.add(n.id)
+            elif isinstance(n, ast.arg):
+                bound.add(n.arg)
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                bound.add(n.name)
+        free = {n.id for n in ast.walk(tree) if isinstance(n, ast.Name) and isinstance(n.ctx, ast.Load)} - bound - set(dir(builtins))
+        for mod in stars:
+            if mod in contract:
+                used = free & public_toplevel(os.path.join(REF, mod.replace(".", "/") + ".py"))
+                contract[mod]["star_names"].update(used)
+                contract[mod]["importers"].add(f)
+    out = {m: {k: sorted(v) for k, v in c.items()} for m, c in contract.items() if c["names"] or c["star_names"]}
+    with open(out_path, "w") as fh:
+        json.dump(out, fh, indent=1, sort_keys=True)
+    print("wrote", out_path, {m: len(c["names"]) + len(c["star_names"]) for m, c in out.items()})
+
+
 def main():
+    if "--contract-only" in sys.argv:
+        import_contract(os.path.join(ROOT, "tests", "golden", "import_contract.json"))
+        return
     if sys.flags.optimize < 1:
         raise SystemExit("run with python -O (fLDRnet.py:448 asserts a CUDA device index)")
     torch.manual_seed(0)
@@ -274,6 +341,7 @@ def main():
         json.dump({k: list(v.shape) for k, v in RefPWC().state_dict().items()}, f, indent=0)
     with open(os.path.join(gold, "args_papermodel_test5scales.json"), "w") as f:
         json.dump({n: getattr(args, n) for n in names if hasattr(args, n)}, f, indent=1, sort_keys=True)
+    import_contract(os.path.join(gold, "import_contract.json"))
 
 
 if __name__ == "__main__":
