@@ -7,45 +7,85 @@ single 4K frame pair, 5-scale test path, t = 0.5) through the MI355X-native hot 
 
 A step = one (frame pair, t) forward = the reference's `model_net(input_gpuList, t, normInput=pyramid, ...)` call
 (main.py:867) with the 6-level pyramid already resident in HBM.  Frame pairs are independent, so N ranks each
-interpolate their own pair (weak scaling, no data-path collective); the only RCCL traffic is the barrier and a
-max-reduction of the elapsed time.  Rank 0 prints ONE JSON line.
+interpolate their own pairs (weak scaling, no data-path collective); the only RCCL traffic is the barrier, a
+max-reduction of the elapsed time and a gather of the per-rank rates.  Rank 0 prints ONE JSON line.
+
+`--gpus N` without a torch.distributed environment launches the N ranks itself (torch.distributed.run as a CHILD
+process, before this process touches the GPU) and exits with the child's code; inside a launch whose WORLD_SIZE
+differs from --gpus it refuses to run.  `--backend gloo --dry` exercises launcher, barriers, reductions and the
+JSON line on CPU only (tests/test_distributed_cpu.py).
+
+The timed loop rotates DISTINCT frame pairs (>= 4, one per in-flight stream and more): consecutive steps never read
+the same pyramid, and the pyramids together (4 x 377 MB) exceed the 256 MiB Infinity Cache.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(ROOT, "fldr-vfi_amd"))
 
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 H4K, W4K = 2160, 3840
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_FP16_MFMA_TFLOPS = 2500.0      # dense fp16/bf16 matrix peak
 PEAK_HBM_GBPS = 8000.0
+# SURVEY.md App. C / BASELINE.md section 3: compulsory HBM traffic and algorithmic FLOPs of ONE forward
+PATH_MODEL = {(2160, 3840): {"hbm_bytes": 5.284e9, "flops": 0.314e12}, (2160, 4096): {"hbm_bytes": 5.636e9, "flops": 0.335e12}}
 
 
-from fldr_harness import shard_pairs, host_cores, max_over_ranks  # noqa: E402
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=3,
+                    help="independent frame-pair forwards kept in flight on separate HIP streams (1 = strictly serial)")
+    ap.add_argument("--pairs", type=int, default=4, help="distinct frame pairs rotated through the timed loop (>= streams)")
+    ap.add_argument("--sustained-s", type=float, default=3.0, help="length of the extra sustained-rate measurement (0 = skip)")
+    ap.add_argument("--height", type=int, default=H4K)
+    ap.add_argument("--width", type=int, default=W4K)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--dry", action="store_true", help="no GPU work: a step is a 1 ms sleep (CPU test of the launcher / reductions)")
+    return ap.parse_args()
 
 
-def dominant_conv_roofline(model, pyr, steps):
+def self_launch(a):
+    """Spawn the N ranks as a child `python -m torch.distributed.run`.  Nothing in this process has touched the GPU
+    (torch is not even imported yet); the parent only waits and forwards the exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["FLDR_BENCH_CHILD"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------------------------------------
+def dominant_conv_roofline(model, h, w, device, steps):
     """Roofline of the dominant kernel: the 96->96 3x3 convolution at the level-0 feature map (rec_ctx_ds.0/.2,
-    conv_flow2.0/.2 launch this instance of conv3x3_spk_kernel; the 3x3 convolutions are ~30 % of the GPU time).  It
-    runs on the fp16 matrix cores with the 3 x fp16 split (fp32-equivalent accuracy), i.e. it issues THREE fp16 MFMA
-    flops per algorithmic flop.  algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels; achieved = 3 x that /
-    launch time, against the dense fp16 MFMA peak.  Duration measured with HIP events on the launch stream, operands
-    split-packed in HBM as inside the model.  The exact fp32-MFMA kernel of the same layer (FLDR_CONV_PRECISION=fp32)
-    is timed beside it."""
+    conv_flow2.0/.2 launch this instance of conv3x3_spk_kernel; the 3x3 convolutions are ~30 % of the GPU time).
+    algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels (165 888 MAC/px for the two
+    rec_ctx_ds convolutions); `achieved` = algorithmic FLOPs / average launch time, `frac` = that over the dense
+    fp16 MFMA peak (= frac_algorithmic).  The kernel forms every product from THREE fp16 MFMAs (hi*hi + hi*lo + lo*hi,
+    fp32-equivalent accuracy), so the matrix pipe executes 3x the algorithmic flops: `frac_issued`.  Duration: HIP
+    events on the launch stream, operands split-packed in HBM as inside the model.  The exact fp32-MFMA kernel of the
+    same layer (FLDR_CONV_PRECISION=fp32) is timed beside it."""
+    import torch
     import fldr_hip
-    h, w = pyr[0].shape[3] // 8, pyr[0].shape[4] // 8
-    x = torch.rand(1, 96, h, w, device=pyr[0].device) * 2 - 1
+    x = torch.rand(1, 96, h, w, device=device) * 2 - 1
     xp = fldr_hip.spk_pack(x)
     conv = model.rec_ctx_ds[0]
-    out = torch.empty(1, 96, h, w, device=x.device)
-    n = max(10, steps)
+    out = torch.empty(1, 96, h, w, device=device)
+    n = max(20, steps)
 
     def timed(fn):
         for _ in range(3):
@@ -62,137 +102,252 @@ def dominant_conv_roofline(model, pyr, steps):
     ms = timed(lambda: fldr_hip.conv2d_spk([xp], conv.weight, conv.bias, relu=True, want_f32=False, want_spk=True))
     ms32 = timed(lambda: fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision="fp32"))
     flops = 2.0 * 96 * 96 * 9 * h * w
-    ach = 3.0 * flops / (ms * 1e-3) / 1e12
+    alg = flops / (ms * 1e-3) / 1e12
+    tr = _measured_traffic()
     return {"bound": "mfma", "kernel": "conv3x3_spk_kernel<3,3> (3x3 96->96 @%dx%d, persistent workgroups, split-packed operands, "
                                        "3 x fp16-split v_mfma_f32_16x16x32_f16)" % (h, w),
-            "achieved": round(ach, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP16_MFMA_TFLOPS, 4),
-            "traffic": _measured_traffic(), "launch_ms": round(ms, 4), "flops_per_launch": flops,
-            "issued_mfma_flops_per_launch": 3.0 * flops, "algorithmic_tflops": round(flops / (ms * 1e-3) / 1e12, 1),
+            "achieved": round(alg, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(alg / PEAK_FP16_MFMA_TFLOPS, 4),
+            "frac_algorithmic": round(alg / PEAK_FP16_MFMA_TFLOPS, 4), "frac_issued": round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
+            "frac_of_fp32_mfma_peak": round(alg / PEAK_FP32_MFMA_TFLOPS, 3),
+            "traffic": tr, "launch_ms": round(ms, 4), "flops_per_launch": flops, "issued_mfma_flops_per_launch": 3.0 * flops,
+            "algorithmic_bytes_per_launch": 2 * 96 * h * w * 4,
             "exact_fp32_mfma_kernel": {"launch_ms": round(ms32, 4), "achieved": round(flops / (ms32 * 1e-3) / 1e12, 1),
                                        "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
 
 
 def _measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
-    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE); None when no measurement is on file."""
-    p = os.path.join(ROOT, "profiles", "r01_conv96_spk_traffic.json")
+    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
+    (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate --pmc passes); newest round first."""
+    for name in ("r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
+        try:
+            return json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    return None
+
+
+def host_info():
+    model = None
     try:
-        return json.load(open(p))["hbm_bytes_per_launch"]
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
     except Exception:
-        return None
+        pass
+    from fldr_harness import host_core_budget
+    return dict(host_core_budget(), cpu_model=model)
 
 
-def cpu_baseline(frames_cpu, t_cpu):
-    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores: ONE 4K
-    frame-pair forward (pyramid excluded, like the GPU number)."""
+def cpu_baseline(frames_cpu, t_cpu, gpu_out=None):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on the SAME 4K pair:
+    1 warm-up + 3 timed forwards with every core this process may use, then 1 + 2 with 8 threads (the survey
+    container's count); pyramid excluded like the GPU number.  The warm-up's output doubles as
+    the full-size parity check of the GPU frame (PSNR of the rounded 8-bit frames, max abs error)."""
+    import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fldr_oracle as O
     import fldr_harness as Hn
-    cores = host_cores()
-    torch.set_num_threads(cores)
+    info = host_info()
+    cores = info["cores_used"]
     w = O.load_weights(Hn.DEFAULT_WEIGHTS)
     pyr = O.pad_and_pyramid(frames_cpu)
-    with torch.no_grad():
-        t0 = time.time()
-        O.forward(w, pyr, t_cpu)
-        dt = time.time() - t0
-    return {"value": round(1.0 / dt, 5), "unit": "4K frame-pairs/s", "cores": cores, "kind": "port",
-            "sample": "1 forward of the same 3840x2160 pair (seed 0, t=0.5), oracle/fldr_oracle.py on torch-CPU, %.1f s" % dt}
+    H, W = frames_cpu.shape[-2:]
+
+    def run(nthreads, nruns):
+        torch.set_num_threads(nthreads)
+        ts, ref = [], None
+        with torch.no_grad():
+            for i in range(nruns + 1):
+                t0 = time.time()
+                ref = O.forward(w, pyr, t_cpu)
+                ts.append(time.time() - t0)
+        return ts[1:], ref
+
+    ts, ref = run(cores, 3)
+    mean = sum(ts) / len(ts)
+    res = {"value": round(1.0 / mean, 5), "unit": "4K frame-pairs/s", "cores": cores, "kind": "port",
+           "sample": "oracle/fldr_oracle.py (torch-CPU) on the same %dx%d pair (seed 0, t=0.5): 1 warm-up + 3 timed forwards, "
+                     "%.2f / %.2f / %.2f s" % ((W, H) + tuple(ts)),
+           "host": info}
+    if cores != 8:
+        ts8, _ = run(min(8, cores), 2)
+        res["at_8_threads"] = {"value": round(len(ts8) / sum(ts8), 5), "runs_s": [round(x, 2) for x in ts8]}
+    parity = None
+    if gpu_out is not None:
+        ref = ref[:, :, :H, :W]
+        err = (gpu_out.double() - ref.double()).abs()
+        parity = {"vs": "oracle (CPU restatement pinned bit-for-bit by the reference's golden frames)", "max_abs_err": float(err.max()),
+                  "mean_abs_err": float(err.mean()),
+                  "psnr_8bit_db": Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(gpu_out[0])),
+                  "x_test_psnr": None,
+                  "note": "X-Test / Xiph / Inter4K are not available offline: PSNR on X-Test cannot be reported; the rounded 8-bit "
+                          "frame of this synthetic 4K pair is compared with the oracle's instead"}
+    return res, parity
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--streams", type=int, default=3,
-                    help="independent frame-pair forwards kept in flight on separate HIP streams (1 = strictly serial)")
-    ap.add_argument("--height", type=int, default=H4K)
-    ap.add_argument("--width", type=int, default=W4K)
-    a = ap.parse_args()
-
+    a = parse()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and a.gpus > 1:
+        sys.exit(self_launch(a))                         # parent: no GPU call, no torch import
+    world = int(env_world or "1")
+    if world != a.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: launch with matching values (or without a torch.distributed "
+              "environment: bench.py starts the ranks itself)" % (a.gpus, world), file=sys.stderr)
+        sys.exit(2)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("FLDR_BENCH_TEST_FAIL_RANK") == str(rank):     # launcher test: a failing rank must fail the parent
+        sys.exit(3)
+
+    import torch
+    import torch.distributed as dist
+    from fldr_harness import shard_pairs, max_over_ranks, gather_floats
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    gpu = not a.dry
+    if gpu:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
+    else:
+        device = torch.device("cpu")
     if world > 1:
-        dist.init_process_group("nccl", device_id=device)
+        if a.backend == "nccl" and gpu:
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group("gloo")
 
-    import fldr_harness as Hn
-    model, _, args = Hn.prepare_model(device)
-    pair = shard_pairs(world, rank, world)[0]                    # one pair per rank, seed = pair index
-    frames = Hn.frames_from_uint8(Hn.synthetic_pair(a.height, a.width, seed=pair)).to(device)
-    t = torch.tensor([[0.5]], device=device)
-    with torch.no_grad():
-        pyr = Hn.build_pyramid(Hn.pad_frames(frames, args), args)
+    def sync():
+        if gpu:
+            torch.cuda.synchronize()
 
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    npairs = max(a.pairs, a.streams, 1)
+    my_pairs = shard_pairs(world * npairs, rank, world)          # pair index = seed; disjoint across ranks
+    latency_ms = dt_e2e = sustained = None
+    if gpu:
+        import fldr_harness as Hn
+        model, _, args = Hn.prepare_model(device)
+        t = torch.tensor([[0.5]], device=device)
+        frames, pyrs = [], []
+        with torch.no_grad():
+            for p in my_pairs:
+                f = Hn.frames_from_uint8(Hn.synthetic_pair(a.height, a.width, seed=p)).to(device)
+                frames.append(f)
+                pyrs.append(Hn.build_pyramid(Hn.pad_frames(f, args), args))
+        pyr_bytes = sum(x.numel() * 4 for x in pyrs[0])
         # Frame pairs are independent, so a serving loop keeps several in flight: step i is enqueued on HIP stream
-        # i % streams.  Every step is a complete forward; overlapping them fills the CUs that the latency-bound
-        # coarse pyramid levels (9x15 ... 72x120 feature maps) leave idle.
+        # i % streams and interpolates pair i % npairs.  Every step is a complete forward; overlapping them fills the
+        # CUs that the latency-bound coarse pyramid levels (9x15 ... 72x120 feature maps) leave idle.
         streams = [torch.cuda.Stream(device=device) for _ in range(max(1, a.streams))]
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream())
 
         def step(i):
-            with torch.cuda.stream(streams[i % len(streams)]):
-                return Hn.interpolate(model, args, frames, t, pyramid=pyr)
+            k = i % npairs
+            with torch.cuda.stream(streams[i % len(streams)]), torch.no_grad():
+                return Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k])
+    else:
+        def step(i):
+            time.sleep(1e-3)
+            return None
 
-        for i in range(len(streams)):          # prime every stream's allocator pool once (untimed, before the W warm-ups)
-            out = step(i)
-        torch.cuda.synchronize()
-        for i in range(a.warmup):
-            out = step(i)
-        torch.cuda.synchronize()
-        # single-stream latency of one forward (informational)
-        tl = time.perf_counter()
-        for _ in range(3):
-            Hn.interpolate(model, args, frames, t, pyramid=pyr)
-        torch.cuda.synchronize()
+    out = None
+    for i in range(max(len(streams) if gpu else 1, npairs)):      # prime every stream's allocator pool once (untimed)
+        out = step(i)
+    sync()
+    for i in range(a.warmup):
+        out = step(i)
+    sync()
+    if gpu:
+        tl = time.perf_counter()                                   # single-stream latency of one forward (informational)
+        for k in range(3):
+            Hn.interpolate(model, args, frames[k % npairs], t, pyramid=pyrs[k % npairs])
+        sync()
         latency_ms = (time.perf_counter() - tl) / 3 * 1e3
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.steps):
+    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides -------------
+    barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = step(i)
+    sync()
+    barrier()
+    dt_local = time.perf_counter() - t0
+    # ---- sustained rate: the same loop for >= --sustained-s seconds (clocks settle, caches in steady state) ---
+    if gpu and a.sustained_s > 0:
+        n_s = max(a.steps, int(a.sustained_s / max(dt_local / a.steps, 1e-5)) + 1)
+        barrier()
+        sync()
+        t1 = time.perf_counter()
+        for i in range(n_s):
             out = step(i)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
+        sync()
+        barrier()
+        d_s = max_over_ranks(time.perf_counter() - t1, device)
+        sustained = {"seconds": round(d_s, 3), "steps": n_s, "ms_per_step": round(d_s / n_s * 1e3, 3),
+                     "value": round(world * n_s / d_s, 3)}
+    if gpu:
         # end-to-end on the device (informational, single stream): uint8 frames -> ingest kernels (normalise, reflect
         # pad, bicubic pyramid) -> forward -> rounded uint8 frame (fldr_frame_metrics)
-        u8 = Hn.synthetic_pair(a.height, a.width, seed=pair).unsqueeze(0).to(device)
-        for _ in range(3):                      # this path runs on the default stream: let its allocator pool settle first
+        u8 = Hn.synthetic_pair(a.height, a.width, seed=my_pairs[0]).unsqueeze(0).to(device)
+        for _ in range(3):
             Hn.interpolate_u8(model, args, u8, t)
-        torch.cuda.synchronize()
+        sync()
         t1 = time.perf_counter()
         for _ in range(max(1, a.steps // 4)):
             Hn.interpolate_u8(model, args, u8, t)
-        torch.cuda.synchronize()
+        sync()
         dt_e2e = (time.perf_counter() - t1) / max(1, a.steps // 4)
-    assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
-    dt = max_over_ranks(dt, device)
+        assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
+    dt = max_over_ranks(dt_local, device)
+    per_rank = gather_floats(a.steps / dt_local, device)
 
     if rank == 0:
+        hp = ((a.height + 255) // 256 * 256, (a.width + 255) // 256 * 256)
         res = {
             "metric": "4K frame-pairs interpolated/sec", "value": round(world * a.steps / dt, 3), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3x3 convs: 3 x fp16-split MFMA with fp32 accumulation, error <= exact fp32 MFMA; rest fp32/fp64)", "data": "synthetic",
-            "config": {"workload": "single %dx%d frame pair per GPU (padded 2304x3840), fLDRnet 5-scale test path "
-                                   "(--papermodel --test5scales), t=0.5, shipped checkpoint weights, fp64 output frame"
-                                   % (a.width, a.height),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (3x3 convs: 3 x fp16-split MFMA with fp32 accumulation, error <= exact fp32 MFMA; rest fp32/fp64)",
+            "data": "synthetic",
+            "config": {"workload": "single %dx%d frame pair per step (padded %dx%d), fLDRnet 5-scale test path "
+                                   "(--papermodel --test5scales), t=0.5, shipped checkpoint weights, fp64 output frame; "
+                                   "%d distinct pairs per GPU rotated through the loop" % (a.width, a.height, hp[0], hp[1], npairs),
                        "parallelism": "dp%d (independent pairs, no data-path collective)" % world,
-                       "pairs_in_flight": len(streams), "single_stream_latency_ms": round(latency_ms, 3),
-                       "ms_uint8_in_to_uint8_out_single_stream": round(dt_e2e * 1e3, 3)},
+                       "pairs_in_flight": a.streams, "distinct_pairs_per_gpu": npairs,
+                       "per_rank_pairs_per_s": [round(x, 2) for x in per_rank]},
         }
-        res["roofline"] = dominant_conv_roofline(model, pyr, a.steps)
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(frames.cpu(), t.cpu())
-        print(json.dumps(res))
+        if a.dry:
+            res["dry"] = True
+            res["data"] = "none (dry run: 1 ms sleep per step)"
+        if gpu:
+            res["config"].update({"pyramid_bytes_per_pair": pyr_bytes, "single_stream_latency_ms": round(latency_ms, 3),
+                                  "ms_uint8_in_to_uint8_out_single_stream": round(dt_e2e * 1e3, 3)})
+            if sustained:
+                res["sustained"] = sustained
+            res["roofline"] = dominant_conv_roofline(model, hp[0] // 8, hp[1] // 8, device, a.steps)
+            pm = PATH_MODEL.get((a.height, a.width))
+            if pm:
+                ms_step = dt / a.steps * 1e3
+                floor_hbm = pm["hbm_bytes"] / (PEAK_HBM_GBPS * 1e9) * 1e3
+                floor_mfma = 3 * pm["flops"] / (PEAK_FP16_MFMA_TFLOPS * 1e12) * 1e3
+                res["roofline"]["path"] = {
+                    "what": "whole forward against its binding floor: compulsory HBM traffic of SURVEY App. C at 8 TB/s (the 3 x fp16-split "
+                            "matrix work is the smaller term)", "hbm_bytes": pm["hbm_bytes"], "hbm_floor_ms": round(floor_hbm, 3),
+                    "mfma_floor_ms_split_fp16": round(floor_mfma, 3), "fp32_mfma_floor_ms": round(pm["flops"] / (PEAK_FP32_MFMA_TFLOPS * 1e12) * 1e3, 3),
+                    "ms_per_step": round(ms_step, 3), "frac": round(max(floor_hbm, floor_mfma) / ms_step, 4),
+                    "frac_single_stream": round(max(floor_hbm, floor_mfma) / latency_ms, 4),
+                    "achieved_GBps": round(pm["hbm_bytes"] / (ms_step * 1e-3) / 1e9, 1)}
+            if world == 1 and not a.no_cpu_baseline:
+                with torch.no_grad():
+                    g0 = Hn.interpolate(model, args, frames[0], t, pyramid=pyrs[0]).cpu()
+                res["cpu_baseline"], res["parity"] = cpu_baseline(frames[0].cpu(), t.cpu(), g0)
+        print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "fldr_hip.h"
 
 #define FLDR_CHECK_ARG(cond) do { if (!(cond)) return FLDR_E_ARG; } while (0)
@@ -9,6 +10,21 @@
 
 static inline hipStream_t fldr_s(fldr_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int fldr_cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device only: remember it per (kernel
+// instantiation, device ordinal) — `done` is one function-local static bit mask per instantiation — so that a process
+// driving several GPUs raises the limit on each of them.  Returns 0 or the hipError_t.
+static inline int fldr_set_max_lds(const void* fn, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return 0;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    done.fetch_or(bit, std::memory_order_release);
+    return 0;
+}
 
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
 // the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.

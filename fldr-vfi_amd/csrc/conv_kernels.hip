@@ -415,13 +415,9 @@ static int conv_launch(const ConvArgs& a, int N, hipStream_t s) {
     b.tiles_x = fldr_cdiv(a.Wout, Cfg::TW);
     const int tiles_y = fldr_cdiv(a.Hout, Cfg::TH);
     const size_t lds = sizeof(float) * Cfg::LDS_FLOATS;
-    static bool attr_done = false;
-    if (!attr_done && lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (lds > 64 * 1024)
+        if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>), (int)lds, attr_done)) return e;
     hipLaunchKernelGGL((conv_mfma_kernel<KS, STRIDE, MT, NMT, PT, CC>), dim3(b.tiles_x * tiles_y * b.groups, N), dim3(256), lds, s, b);
     FLDR_LAUNCH_RET();
 }

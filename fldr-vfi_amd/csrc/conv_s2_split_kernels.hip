@@ -654,13 +654,8 @@ extern "C" int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout,
 template <int MT, int NMT, int PT>
 static int s2_launch(S2Args& a, int N, hipStream_t s) {
     using Cfg = S2Cfg<MT, NMT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4x4s2_split_kernel<MT, NMT, PT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv4x4s2_split_kernel<MT, NMT, PT>), Cfg::LDS_BYTES, attr_done)) return e;
     a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
     const int tiles_y = fldr_cdiv(a.Hout, S2_TH);
     a.n_tiles = a.tiles_x * tiles_y;
@@ -675,12 +670,14 @@ extern "C" int fldr_debug_s2_persistent(int v) { if (v >= 0) g_s2_persistent = v
 
 template <int MT, int NMT, int PT>
 static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {
-    static int attr_bytes = 0;
-    if (attr_bytes < lds_bytes) {
+    static std::atomic<int> attr_bytes[64];                      // per device ordinal: the attribute is per device
+    int dev = 0;
+    if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
+    if (attr_bytes[dev & 63].load(std::memory_order_acquire) < lds_bytes) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4x4s2_pers_kernel<MT, NMT, PT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
-        attr_bytes = lds_bytes;
+        attr_bytes[dev & 63].store(lds_bytes, std::memory_order_release);
     }
     a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
     a.n_tiles = a.tiles_x * fldr_cdiv(a.Hout, S2_TH);

@@ -665,13 +665,8 @@ extern "C" int fldr_debug_spk_wgs_per_xcd(int v) { if (v > 0) g_spk_wgs_per_xcd 
 template <int NMT, int TERMS, bool HAS_RES>
 static int spk_launch2(SpkArgs& a, int N, hipStream_t s) {
     using Cfg = SpkCfg<NMT>;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_spk_kernel<NMT, TERMS, HAS_RES>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_spk_kernel<NMT, TERMS, HAS_RES>), Cfg::LDS_BYTES, attr_done)) return e;
     a.tiles_x = fldr_cdiv(a.W, SPK_TW);
     a.n_tiles = a.tiles_x * fldr_cdiv(a.H, SPK_TH);
     a.n_units = N * a.n_tiles * a.groups;

@@ -426,13 +426,8 @@ static int split_launch(const SplitArgs& a, int N, hipStream_t s) {
     SplitArgs b = a;
     b.tiles_x = fldr_cdiv(a.W, SP_TW);
     const int tiles_y = fldr_cdiv(a.H, SP_TH);
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_split_kernel<NMT, TERMS>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, Cfg::LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_split_kernel<NMT, TERMS>), Cfg::LDS_BYTES, attr_done)) return e;
     b.n_tiles = b.tiles_x * tiles_y;
     b.tiles_per_xcd = (b.n_tiles + 7) / 8;
     hipLaunchKernelGGL((conv3x3_split_kernel<NMT, TERMS>), dim3(8 * b.tiles_per_xcd * b.groups, N), dim3(512), Cfg::LDS_BYTES, s, b);

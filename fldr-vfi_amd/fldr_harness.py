@@ -220,24 +220,53 @@ def reduce_psnr(psnr_sum, count, device="cpu"):
     return (t[0] / t[1].clamp(min=1)).item(), int(t[1].item())
 
 
-def host_cores():
-    """CPU cores this process may actually use: min(affinity, cgroup cpu.max quota); 16 if unknown but huge."""
-    n = os.cpu_count() or 1
+def gather_floats(value, device="cpu"):
+    """One float per rank -> list over ranks (all_gather of 8 bytes; [value] without a process group)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return [float(value)]
+    mine = torch.tensor([value], device=device, dtype=torch.float64)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(x.item()) for x in out]
+
+
+GPU_BOX_CPU_SHARE = 16      # CPUs a one-GPU lease of the benchmark pool is entitled to when the host exposes all of its cores
+
+
+def host_core_budget():
+    """What this process may use of the host, stated rather than guessed: logical CPUs, the affinity mask, the cgroup
+    CPU quota if one is set, and the thread count the CPU baseline runs with = min(affinity, quota).  Only when NO limit
+    is discoverable on a large shared host (> 64 CPUs visible) the count is held to the pool's per-GPU share and
+    `capped_to_share` says so."""
+    n_all = os.cpu_count() or 1
+    aff = n_all
     try:
-        n = len(os.sched_getaffinity(0))
+        aff = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    quota = None
     for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
         try:
             txt = open(path).read().split()
             if path.endswith("cpu.max"):
                 if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+                    quota = max(1, int(int(txt[0]) / int(txt[1])))
             else:
                 q = int(txt[0])
                 if q > 0:
-                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                    n = min(n, max(1, q // per))
+                    quota = max(1, q // int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read()))
         except Exception:
             pass
-    return min(n, 16) if n > 64 else n
+        if quota is not None:
+            break
+    used = min(aff, quota) if quota is not None else aff
+    capped = False
+    if quota is None and aff == n_all and used > 64:
+        used, capped = GPU_BOX_CPU_SHARE, True
+    return {"logical_cpus": n_all, "affinity": aff, "cgroup_quota": quota, "cores_used": used, "capped_to_share": capped}
+
+
+def host_cores():
+    """Threads the CPU baseline uses (see host_core_budget)."""
+    return host_core_budget()["cores_used"]

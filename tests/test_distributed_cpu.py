@@ -59,3 +59,36 @@ def test_single_process_helpers_are_noops():
     assert Hn.max_over_ranks(1.5) == 1.5
     assert Hn.reduce_psnr(90.0, 3) == (30.0, 3)
     assert 1 <= Hn.host_cores() <= 64
+
+
+def _run_bench(extra, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    return r, ([json.loads(l) for l in lines])
+
+
+def test_bench_self_launches_n_ranks_gloo_dry():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts the two ranks itself (the parent never
+    touches the GPU); --backend gloo --dry runs the same launcher / barrier / MAX-reduction / JSON path on CPU."""
+    r, js = _run_bench(["--gpus", "2", "--backend", "gloo", "--dry", "--steps", "4", "--warmup", "1"])
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert len(js) == 1, r.stdout                          # rank 0 prints ONE line
+    j = js[0]
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 1 and j["scaling"] == "weak" and j["dry"] is True
+    assert len(j["config"]["per_rank_pairs_per_s"]) == 2
+    assert j["value"] == pytest.approx(2 * 4 / (j["ms_per_step"] * 4e-3), rel=1e-3)
+    assert j["value"] < sum(j["config"]["per_rank_pairs_per_s"]) * 1.001        # whole-job rate uses the MAX over ranks
+
+
+def test_bench_launcher_failure_modes():
+    r, js = _run_bench(["--gpus", "2", "--backend", "gloo", "--dry", "--steps", "2", "--warmup", "0"],
+                       {"FLDR_BENCH_TEST_FAIL_RANK": "1"})
+    assert r.returncode != 0 and not js                     # a failing child fails the parent, no result line
+    r, js = _run_bench(["--gpus", "2", "--dry"], {"WORLD_SIZE": "3", "RANK": "0"})
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr

@@ -1,0 +1,99 @@
+"""Full-size parity at the X-Test / Xiph geometry (4096x2160 -> padded 2304x4096; main.py:795): BASELINE configs 3
+(8x multi-frame, t = 1/8 .. 7/8, pair-invariant cache) and 5 (fp16-input convolutions), through the C ABI, against the
+CPU oracle on the same seeded pair.  The 288x512 feature maps have different tile counts / XCD splits than the 3840-wide
+case (16 tiles per row, 1152 conv units) in the persistent conv, band splat and stride-2 encoder kernels.
+Tolerances are ~10x the errors measured on MI355X, not looser."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+H, W = 2160, 4096
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import fldr_hip
+    fldr_hip.lib()
+    return fldr_hip
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    import fldr_harness as Hn
+    m, _, a = Hn.prepare_model(dev)
+    return m, a
+
+
+@pytest.fixture(scope="module")
+def xtest(dev, oracle, weights):
+    """One synthetic 4096x2160 pair with per-quadrant motion (occlusions / holes) + the oracle's frames at t = 0.5 and
+    t = 0.125 (two CPU forwards of ~10 s each on the GPU box)."""
+    import fldr_harness as Hn
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(H, W, seed=2, quadrant=True))
+    torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    pyr = oracle.pad_and_pyramid(frames)
+    assert tuple(pyr[0].shape[-2:]) == (2304, 4096)
+    refs = {}
+    with torch.no_grad():
+        for tv in (0.5, 0.125):
+            refs[tv] = oracle.forward(weights, pyr, torch.tensor([[tv]]))[:, :, :H, :W]
+    return frames.to(dev), refs
+
+
+def _errs(out, ref):
+    import fldr_harness as Hn
+    err = (out.double().cpu() - ref.double()).abs()
+    return err.max().item(), err.mean().item(), Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
+
+
+@pytest.mark.timeout(900)
+def test_xtest_geometry_forward_matches_oracle(hip, dev, model, xtest):
+    """Config 3 geometry, t = 0.5: whole forward vs the oracle (fp32-class bounds: max 1e-4, mean 1e-6, >= 90 dB)."""
+    import fldr_harness as Hn
+    m, a = model
+    frames, refs = xtest
+    out = Hn.interpolate(m, a, frames, torch.tensor([[0.5]], device=dev))
+    assert out.shape == (1, 3, H, W) and out.dtype == torch.float64 and torch.isfinite(out).all()
+    mx, mean, p = _errs(out, refs[0.5])
+    print("4096x2160 t=0.5: max|err| %.2e mean %.2e PSNR(8-bit) %.1f dB" % (mx, mean, p))
+    assert mx <= 1e-4 and mean <= 1e-6 and p >= 90.0
+
+
+@pytest.mark.timeout(900)
+def test_xtest_geometry_multi_t_pair_cache(hip, dev, model, xtest):
+    """Config 3: the 7 outputs of a pair (main.py:833-867) with the pair-invariant stage computed once == 7 independent
+    forwards (1e-5: only the feature splat's atomic order differs) and == the oracle at t = 1/8 and 1/2."""
+    import fldr_harness as Hn
+    m, a = model
+    frames, refs = xtest
+    ts = [k / 8 for k in range(1, 8)]
+    cached = Hn.interpolate_multi(m, a, frames, ts)
+    assert m.pair_cache is False and m._pair_state is None and len(cached) == 7
+    for tv, c in zip(ts, cached):
+        plain = Hn.interpolate(m, a, frames, torch.tensor([[tv]], device=dev))
+        d = (c - plain).abs().max().item()
+        assert d <= 1e-5, "cached vs uncached at t=%g: %.2e" % (tv, d)
+        if tv in refs:
+            mx, mean, p = _errs(c, refs[tv])
+            print("4096x2160 multi-t t=%g: max|err| %.2e mean %.2e PSNR(8-bit) %.1f dB" % (tv, mx, mean, p))
+            assert mx <= 1e-4 and mean <= 1e-6 and p >= 90.0
+
+
+@pytest.mark.timeout(900)
+def test_xiph_geometry_fp16_conv_mode(hip, dev, model, xtest):
+    """Config 5 at its real size: 3x3 convolutions with plain fp16 inputs (fp32 accumulation).  Not fp32-class by design:
+    the PSNR of its rounded 8-bit frame against the oracle's is reported; >= 65 dB (measured 74 dB at 512x768), i.e. an
+    error four orders of magnitude below the 0.02 dB budget of north_star."""
+    import fldr_harness as Hn
+    m, a = model
+    frames, refs = xtest
+    prev = hip.CONV_PRECISION
+    try:
+        hip.CONV_PRECISION = "fp16"
+        out = Hn.interpolate(m, a, frames, torch.tensor([[0.5]], device=dev))
+    finally:
+        hip.CONV_PRECISION = prev
+    mx, mean, p = _errs(out, refs[0.5])
+    print("4096x2160 fp16-input convs: max|err| %.2e mean %.2e PSNR(8-bit vs oracle) %.1f dB" % (mx, mean, p))
+    assert torch.isfinite(out).all() and p >= 65.0 and mean <= 2e-4

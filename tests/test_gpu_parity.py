@@ -6,8 +6,9 @@ Tolerances (fp32 path; stated per test):
   * the splat uses fp32 atomics (order non-deterministic, as in the reference: SURVEY F9) -> 1e-5 relative
     to the accumulated magnitude;
   * convolutions: exact fp32 products, fp32 accumulation in a different order than MKL-DNN -> 2e-5 * sqrt(K);
-  * whole model: the coarse-to-fine cascade amplifies rounding; bound = 2e-3 on the [-1,1] frame (1/4 of an
-    8-bit step) and >= 60 dB PSNR between the rounded 8-bit frames.
+  * whole model: ~10x the errors measured on MI355X (7e-7 at 256x256, 1.9e-6 at 200x500, 1.3e-5 at 4K; 97-101 dB):
+    max 2e-5 on the small golden cases, max 1e-4 / mean 1e-6 elsewhere, >= 90 dB PSNR between the rounded 8-bit
+    frames.  A 10x numerical regression fails.
 """
 import math
 
@@ -491,15 +492,15 @@ def test_model_matches_reference_golden(hip, oracle, golden, dev, model, case):
             feat = m.extract_features(pca.view(1, 96, h // 8, w // 8))
             _cmp(feat, torch.from_numpy(g["feat%d" % level]), atol=2e-5, what="feat L%d" % level)
             flow = m.vfinet(feat, flow, t.view(1, 1, 1, 1), level=level, is_training=False, normInput=pyr[level])
-            _cmp(flow, torch.from_numpy(g["flow%d" % level]), atol=2e-3, rtol=1e-3, what="flow L%d" % level)
+            _cmp(flow, torch.from_numpy(g["flow%d" % level]), atol=2e-4, rtol=1e-4, what="flow L%d" % level)
         out = Hn.interpolate(m, a, frames, t, pyramid=pyr)
     assert out.dtype == torch.float64
     H, W = frames.shape[3:]
     ref = torch.from_numpy(g["out"]).double()[:, :, :H, :W]
-    err = _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="final frame")
+    err = _cmp(out, ref, atol=2e-5, what="final frame")
     p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
     print("%s: max|err| %.2e, PSNR(8-bit) gpu vs reference %.1f dB" % (case, err, p))
-    assert p > 60.0
+    assert p > 90.0
 
 
 def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
@@ -512,7 +513,9 @@ def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
     out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
     with torch.no_grad():
         ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)
-    _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="B=2 forward")
+    err = _cmp(out, ref, atol=1e-4, what="B=2 forward")
+    print("B=2: max|err| %.2e" % err)
+    assert (out.cpu() - ref).abs().mean().item() <= 1e-6
 
 
 @pytest.mark.parametrize("case", [(180, 300, 0.3, 3), (264, 520, 0.875, 4), (140, 700, 0.5, 5)])
@@ -528,7 +531,9 @@ def test_model_matches_oracle_odd_sizes(hip, oracle, weights, dev, model, case):
     with torch.no_grad():
         ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)
     ref = ref[..., :H, :W]
-    _cmp(out, ref, atol=2e-3, max_outlier_frac=1e-4, what="forward %dx%d" % (H, W))
+    err = _cmp(out, ref, atol=1e-4, what="forward %dx%d" % (H, W))
+    print("%dx%d: max|err| %.2e" % (H, W, err))
+    assert (out.cpu() - ref).abs().mean().item() <= 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -592,7 +597,7 @@ def test_4k_forward_matches_oracle(hip, oracle, weights, dev, model, frames4k):
     err = (out - ref).abs()
     p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
     print("4K: max|err| %.2e mean %.2e; PSNR(8-bit) gpu vs oracle %.1f dB" % (err.max().item(), err.mean().item(), p))
-    assert err.mean().item() < 1e-4 and (err > 4e-3).double().mean().item() < 1e-4 and p > 55.0
+    assert err.max().item() <= 1e-4 and err.mean().item() <= 1e-6 and p >= 90.0
 
 
 def test_pwcnet_forward_runs_on_the_correlation_kernel(hip, oracle, dev):
@@ -655,7 +660,7 @@ def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
         if tv in (0.125, 0.5):
             with torch.no_grad():
                 ref = oracle.forward(weights, pyr, t)[:, :, :256, :384]
-            _cmp(c, ref, atol=2e-3, max_outlier_frac=1e-4, what="cached vs oracle t=%g" % tv)
+            _cmp(c, ref, atol=1e-4, what="cached vs oracle t=%g" % tv)
     # a different pair must not hit the cache
     m.pair_cache = True
     try:

@@ -5,7 +5,7 @@ import fldr_harness as Hn, fldr_hip
 if os.environ.get("LIB"): fldr_hip.LIB_PATH = os.environ["LIB"]      # experimental build (tools/stamps/build_variant.sh)
 dev = torch.device("cuda:0")
 model, _, args = Hn.prepare_model(dev)
-frames = Hn.frames_from_uint8(Hn.synthetic_pair(2160, 3840, seed=0)).to(dev)
+frames = Hn.frames_from_uint8(Hn.synthetic_pair(int(os.environ.get('FH', 2160)), int(os.environ.get('FW', 3840)), seed=0)).to(dev)
 t = torch.tensor([[0.5]], device=dev)
 with torch.no_grad():
     pyr = Hn.build_pyramid(Hn.pad_frames(frames, args), args)
