@@ -1,0 +1,518 @@
+// 3x3 / stride 1 / pad 1 convolutions on split-packed activations: LOADER / CONSUMER RING (no per-iteration barrier).
+//
+// Same arithmetic, operand layouts, weight pack, unit walk and LDS stage image as conv_spk_kernels.hip (x = hi + lo in
+// fp16; hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_f16, fp32 accumulation, chunk -> tap pair -> term order per
+// accumulator), so results are bit-identical to it and to conv_split_kernels.hip.  What changes is who does what:
+//
+//   * The barrier pipeline let all 8 waves issue LDS-DMA between their MFMAs and closed every 16-channel iteration with
+//     one s_barrier.  Its phase stamps showed the cost: an LDS-DMA instruction holds its wave's
+//     issue port for 60-180 cycles (7 per wave and iteration), the two waves of a SIMD had to be skewed to hide
+//     bookkeeping, and the early wave then idled ~1,800 of 4,400 cycles per iteration at the barrier — the matrix pipe
+//     was busy 47 % of the time.
+//   * Here the first NC waves are CONSUMERS (NC = 8: one tile row each, two per SIMD, so that one's epilogue, poll and
+//     LDS latencies hide under the other's MFMAs — the default; NC = 4: two rows each, 30 % fewer LDS operand reads per
+//     MFMA but nothing to hide its epilogue under: measured 3-5 % slower) and never touch global memory inside the
+//     loop except for the epilogue of a unit; the last four waves are LOADERS (one per SIMD): loader w streams
+//     plane w of the input tile (hi g0, hi g1, lo g0, lo g1) and a quarter of the weight slab of every iteration by
+//     LDS-DMA.  Their hand-off is a 3-slot ring with two LDS words per slot (MI355X_MICROARCH.md, ring-gemm):
+//         FULL[slot] += 1  by each loader once its part of the fill has landed (counted s_waitcnt vmcnt),
+//         FREE[slot] += 1  by each consumer after its last operand read of the slot;
+//     a consumer spins on FULL[slot] >= 4 * use, a loader on FREE[slot] >= 4 * (use - 1) before refilling.  Waves
+//     therefore run up to two iterations apart instead of meeting at a barrier 6 times per unit.
+//   * Every spin is bounded (RING_SPIN_LIMIT polls, then the wave gives up, counts the event in fldr_ring_timeouts and
+//     runs on): the grid always drains.
+#include "spk_common.h"
+
+#define RING_SLOTS 3
+#define RING_NLOAD 4
+#define RING_NXI 6                              // 64-pixel DMA pieces per input plane (352 slots, the last two overlap)
+#define RING_SPIN_LIMIT (1 << 21)
+#ifndef RING_LOADER_PRIO
+#define RING_LOADER_PRIO 0                      // wave priority of the loaders (0 / 1 / 3 measured equal within noise)
+#endif
+#ifndef RING_FIN_PRIO
+#define RING_FIN_PRIO 0                         // wave priority of a consumer during its epilogue (0 = unchanged)
+#endif
+#ifndef RING_EARLY_FREE
+#define RING_EARLY_FREE 0                       // 1: FREE is signalled right after the last operand read is ISSUED (step 3)
+#endif
+
+#ifdef RING_STAMPS
+// Diagnostic build only (tools/stamps): per-phase s_memtime sums of consumer wave 0 and loader wave 4 of two workgroups.
+__device__ unsigned long long fldr_ring_stamp_buf[4 * 8];
+__device__ unsigned long long fldr_ring_trace[4 * 24 * 4];            // [wave slot][iteration < 24][event] absolute s_memtime, workgroup 0
+extern "C" int fldr_debug_read_ring_trace(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_ring_trace), sizeof(unsigned long long) * 4 * 24 * 4);
+}
+#define RSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+extern "C" int fldr_debug_read_ring_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_ring_stamp_buf), sizeof(unsigned long long) * 32);
+}
+#else
+#define RSTAMP(var)
+#endif
+
+__device__ int fldr_ring_timeouts;
+extern "C" int fldr_debug_ring_timeouts(void) {
+    int v = -1;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_ring_timeouts), sizeof(int)) != hipSuccess) return -1;
+    return v;
+}
+
+template <int NMT>
+struct RingCfg {
+    static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;
+    static constexpr int NBLK = SPK_STEPS * NMT * 2;                    // 1-KB weight blocks per chunk: (step, m, kind)
+    static constexpr int NWL = (NBLK + RING_NLOAD - 1) / RING_NLOAD;    // weight blocks per loader wave
+    static constexpr int K_DMA = NWL + RING_NXI;                        // DMA instructions per loader wave and fill
+    static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
+    static constexpr int CTR_OFF = RING_SLOTS * STAGE;                  // FULL[3] at +0, FREE[3] at +16
+    static constexpr int LDS_BYTES = CTR_OFF + 64;
+    static_assert(K_DMA <= 15, "counted vmcnt wait uses the 4 low bits");
+    static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
+};
+
+__device__ __forceinline__ uint32_t ring_peek(uint32_t lds_addr) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr) : "memory");
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// Spin until the counter at lds_addr reaches `target` (counters only grow).  Bounded: see the file header.
+__device__ __forceinline__ void ring_wait_ge(uint32_t lds_addr, uint32_t target, int lane) {
+    if (ring_peek(lds_addr) >= target) return;
+    int spins = 0;
+    while (true) {
+        __builtin_amdgcn_s_sleep(1);
+        if (ring_peek(lds_addr) >= target) return;
+        if (++spins > RING_SPIN_LIMIT) {
+            if (lane == 0) atomicAdd(&fldr_ring_timeouts, 1);
+            return;
+        }
+    }
+}
+
+// One lane adds 1.  LDS instructions of a wave execute in issue order, so everything the wave read from (or, for a
+// loader after its counted vmcnt wait, everything its DMA wrote to) the slot is done when the add lands.
+__device__ __forceinline__ void ring_signal(uint32_t lds_addr, int lane) {
+    __builtin_amdgcn_sched_barrier(0);
+    if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(lds_addr), "v"(1u) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NMT, int TERMS, bool HAS_RES, int NC>
+__global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(SpkArgs a) {
+    // NC consumer waves (4: two tile rows each, one consumer per SIMD; 8: one row each, two per SIMD)
+    using Cfg = RingCfg<NMT>;
+    constexpr int RING_NCONS = NC;
+    constexpr int MTOT = 16 * NMT;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_chunks = a.n_chunks;
+    const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);   // LDS byte address of FULL[0]; FREE[s] at +16 + 4 s
+
+    if (tid < 8) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
+    __syncthreads();                                                      // the only workgroup barrier of the kernel
+
+    // Units of this workgroup: as in conv_spk_kernels.hip (XCD x owns the contiguous range [x*upx, (x+1)*upx)).
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int u_end = min((xcd + 1) * a.units_per_xcd, a.n_units);
+    const int u_first = xcd * a.units_per_xcd + slot_id;
+    if (u_first >= u_end) return;                                        // workgroup-uniform
+    const int my_units = (u_end - u_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_units * n_chunks;
+    const int grp0 = u_first % a.groups;                                 // the output group is constant over a workgroup's units
+
+    if (wave >= RING_NCONS) {
+        // =========================================== loader ===========================================
+        __builtin_amdgcn_s_setprio(RING_LOADER_PRIO);
+        const int lw = wave - RING_NCONS;
+        const int ip = lw, ikind = ip >> 1, igrp = ip & 1;               // LDS plane: kind = ip >> 1, group of the chunk = ip & 1
+        const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
+        const int sub = a.pack_nmt / NMT;
+        const int pgrp = grp0 / sub, msel = (grp0 - pgrp * sub) * NMT;
+        const int pack_w_bytes = SPK_STEPS * a.pack_nmt * 2 * 1024;
+        int w_blk[Cfg::NWL], x_piece[RING_NXI];
+        uint32_t w_voff[Cfg::NWL];
+#pragma unroll
+        for (int i = 0; i < Cfg::NWL; ++i) {
+            w_blk[i] = min(lw * Cfg::NWL + i, Cfg::NBLK - 1);            // (past the slab: re-fetch its last block)
+            const int step = w_blk[i] / (2 * NMT), mk = w_blk[i] - step * 2 * NMT;
+            w_voff[i] = (uint32_t)((step * a.pack_nmt + msel) * 2 + mk) * 1024u + (uint32_t)lane * 16u;
+        }
+#pragma unroll
+        for (int i = 0; i < RING_NXI; ++i) x_piece[i] = min(i * 64, SPK_PLANE / 16 - 64);
+        // input-group table in VGPR lanes (lane l = group l, advanced to this wave's hi or lo plane)
+        unsigned long long tab_ptr;
+        long long tab_bs;
+        {
+            const auto* kt = (const __attribute__((address_space(4))) unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();
+            const int l = lane < SPK_MAX_GROUPS ? lane : 0;
+            unsigned long long e = kt[l];
+            tab_bs = (long long)kt[SPK_MAX_GROUPS + l];
+            const bool up2 = (e & 1ull) != 0ull;
+            const long long plane = up2 ? (long long)(a.H >> 1) * (a.W >> 1) * 16 : (long long)a.H * a.W * 16;
+            if (e != 0ull && ikind) e += (unsigned long long)plane;
+            tab_ptr = e;
+        }
+        int iss_u = u_first, iss_c = 0, iss_n = 0;
+        uint32_t g_full[RING_NXI], g_half[RING_NXI];                      // byte offsets in a plane; ~0u = outside the image
+        auto issue_geometry = [&]() {
+            const int t = spk_div(iss_u, a.m_groups, a.groups);
+            iss_n = spk_div(t, a.m_tiles, a.n_tiles);
+            const int tile = t - iss_n * a.n_tiles;
+            const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+#pragma unroll
+            for (int i = 0; i < RING_NXI; ++i) {
+                const int e = x_piece[i] + lane;
+                const int y = e / SPK_IW, x = e % SPK_IW;
+                const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
+                const bool ok = e < SPK_IH * SPK_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                g_full[i] = ok ? (uint32_t)(gy * a.W + gx) * 16u : ~0u;
+                g_half[i] = ok ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : ~0u;
+            }
+        };
+        const char* const iss_w = reinterpret_cast<const char*>(a.wpack + SPK_HDR) + (int64_t)pgrp * n_chunks * pack_w_bytes;
+        issue_geometry();
+        int st = 0;                                                       // slot of fill k
+        uint32_t free_target = 0;                                         // RING_NCONS * (uses of the slot so far)
+#ifdef RING_STAMPS
+        unsigned long long ls_prep = 0, ls_free = 0, ls_fire = 0, ls_land = 0;
+        RSTAMP(l_begin)
+#endif
+        for (int k = 0; k < total; ++k) {
+            RSTAMP(l0)
+            // addresses of fill k (before the FREE wait: they do not depend on it)
+            const char* wbase = iss_w + (int64_t)iss_c * pack_w_bytes;
+            const int gi = iss_c * 2 + igrp;
+            const uint32_t e_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_ptr, gi), e_hi = __builtin_amdgcn_readlane((int)(uint32_t)(tab_ptr >> 32), gi);
+            const uint32_t b_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_bs, gi), b_hi = __builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)tab_bs >> 32), gi);
+            const unsigned long long e = ((unsigned long long)e_hi << 32) | e_lo;
+            const long long bs = (long long)(((unsigned long long)b_hi << 32) | b_lo);
+            const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
+            const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * bs;
+            const char* dptr[RING_NXI];
+#pragma unroll
+            for (int i = 0; i < RING_NXI; ++i) {
+                const uint32_t off = up2 ? g_half[i] : g_full[i];
+                dptr[i] = (off != ~0u && !nul) ? base + off : zero_blk;
+            }
+            if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
+            RSTAMP(l1)
+            if (free_target) ring_wait_ge(ctr + 16 + 4 * st, free_target, lane);
+            RSTAMP(l2)
+            unsigned char* stage = smem + st * Cfg::STAGE;
+#pragma unroll
+            for (int i = 0; i < Cfg::NWL; ++i)
+                __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_voff[i]), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RING_NXI; ++i)
+                __builtin_amdgcn_global_load_lds((kgptr_t)dptr[i], (klptr_t)(stage + Cfg::W_BYTES + ip * SPK_PLANE + x_piece[i] * 16), 16, 0, 0);
+            RSTAMP(l3)
+            if (k > 0) {                                                  // fill k-1 has landed once at most K_DMA of my loads are outstanding
+                __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_DMA);
+                ring_signal(ctr + 4 * (st == 0 ? RING_SLOTS - 1 : st - 1), lane);
+            }
+            RSTAMP(l4)
+#ifdef RING_STAMPS
+            ls_prep += l1 - l0; ls_free += l2 - l1; ls_fire += l3 - l2; ls_land += l4 - l3;
+            if (blockIdx.x == 0 && (lw == 0 || lw == 3) && lane == 0 && k < 24) {
+                unsigned long long* tr = fldr_ring_trace + ((lw == 0 ? 2 : 3) * 24 + k) * 4;
+                tr[0] = l1; tr[1] = l2; tr[2] = l3; tr[3] = l4;
+            }
+#endif
+            if (++st == RING_SLOTS) { st = 0; free_target += RING_NCONS; }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
+        ring_signal(ctr + 4 * (st == 0 ? RING_SLOTS - 1 : st - 1), lane);
+#ifdef RING_STAMPS
+        RSTAMP(l_end)
+        if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == RING_NCONS && lane == 0) {
+            unsigned long long* o = fldr_ring_stamp_buf + ((blockIdx.x == 0 ? 0 : 2) + 1) * 8;
+            o[0] = ls_prep; o[1] = ls_free; o[2] = ls_fire; o[3] = ls_land; o[5] = total; o[6] = l_end - l_begin;
+        }
+#endif
+        return;
+    }
+
+    // ============================================= consumer =============================================
+    constexpr int ROWS = SPK_TH / NC;                                     // tile rows per consumer wave
+    const int cw = wave;                                                  // rows ROWS * cw ... of the 8 x 32 tile
+    const int lj = lane & 15, lg = lane >> 4;
+    constexpr int NQ = 2 * ROWS;                                          // pixel blocks: q = row_in_wave * 2 + column block
+    int boff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+        boff[q] = Cfg::W_BYTES + (lg & 1) * SPK_PLANE + ((ROWS * cw + (q >> 1)) * SPK_IW + (q & 1) * 16 + lj) * 16;
+    const int tap_sel = lg >> 1;
+    f4 acc[NMT][NQ];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[m][q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int cur_u = u_first, cur_c = 0;
+    const float inv_scale = a.wpack[0];
+    const int64_t HW = (int64_t)a.H * a.W;
+    const uint32_t HW32 = (uint32_t)HW;                                   // byte offsets below fit 32 bits (host-checked)
+    const int gout = (a.cout_store + 7) >> 3;
+    const int cbase = grp0 * MTOT;
+    float bias_r[NMT][4];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int co = cbase + m * 16 + lg * 4 + r;
+            co = co < a.cout ? co : a.cout - 1;
+            bias_r[m][r] = a.bias ? a.bias[co] : 0.0f;
+        }
+    auto unit_pixels = [&](int u, uint32_t (&po)[NQ], int& n) {
+        const int t = spk_div(u, a.m_groups, a.groups);
+        n = spk_div(t, a.m_tiles, a.n_tiles);
+        const int tile = t - n * a.n_tiles;
+        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+        const int ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int oy = ty * SPK_TH + ROWS * cw + (q >> 1);
+            const int ox = ox0 + (q & 1) * 16 + lj;
+            po[q] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
+        }
+    };
+    float res_r[HAS_RES ? NMT : 1][HAS_RES ? NQ : 1][4];
+    auto residual_prefetch = [&]() {
+        uint32_t po[NQ]; int n;
+        unit_pixels(cur_u, po, n);
+        const float* resn = a.residual + (int64_t)n * a.cout_store * HW;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int co = cbase + m * 16 + lg * 4 + r;
+                    co = co < a.cout_store ? co : a.cout_store - 1;
+                    res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r] = resn[(uint32_t)co * HW32 + (po[q] != ~0u ? po[q] : 0u)];
+                }
+    };
+    // Epilogue of a unit: scale, bias, ReLU, residual, hi/lo split and the stores, block by block (registers of a block
+    // are dead once it is stored; the stores drain under the next unit's MFMAs — a consumer never waits on vmcnt
+    // except for the residual it prefetched one iteration earlier).  Two paths, chosen per unit by a wave-uniform test:
+    // the FAST one (tile inside the image, every channel of the group stored — all of the 4K forward's big launches)
+    // has no predication at all: ~20 VALU instructions and the stores per (pixel block, 16-channel block); the general
+    // one predicates every store.  ReLU is max(v, floor) with floor = 0 or -FLT_MAX: no select.
+    const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
+    const bool grp_full = cbase + MTOT <= a.cout_store && !(a.cout_store & 7);      // wave-uniform, constant over the kernel
+    auto finish_store = [&]() {
+        const int t = spk_div(cur_u, a.m_groups, a.groups);
+        const int n = spk_div(t, a.m_tiles, a.n_tiles);
+        const int tile = t - n * a.n_tiles;
+        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+        const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+        char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) : nullptr;
+        char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride : nullptr;
+        const bool inside = oy0 + ROWS <= a.H && ox0 + SPK_TW <= a.W;    // wave-uniform
+        if (grp_full && inside) {
+            const uint32_t p0 = (uint32_t)(oy0 * a.W + ox0 + lj);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                const uint32_t pq = p0 + (uint32_t)((q >> 1) * a.W + (q & 1) * 16);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    const int co0 = cbase + m * 16 + lg * 4;
+                    float ov[4];
+                    h4 ohi, olo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float v = fmaxf(acc[m][q][r] * inv_scale + bias_r[m][r], relu_floor);
+                        if constexpr (HAS_RES) v += res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r];
+                        ov[r] = v;
+                        acc[m][q][r] = 0.0f;
+                        _Float16 h, l;
+                        spk_split(v, h, l);
+                        ohi[r] = h; olo[r] = l;
+                    }
+                    if (outn) {
+                        const uint32_t off = ((uint32_t)co0 * HW32 + pq) * 4u;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[r];
+                    }
+                    if (spkn) {
+                        const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)(lg & 1) * 8u;
+                        *reinterpret_cast<h4*>(spkn + off) = ohi;
+                        *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+                    }
+                }
+            }
+            return;
+        }
+        uint32_t po[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1) * 16 + lj;
+            po[q] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
+        }
+        const bool quads = !(a.cout_store & 3);                          // whole quads of channels: one predicate per 4 stores
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const int co0 = cbase + m * 16 + lg * 4;
+                float ov[4];
+                h4 ohi, olo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float v = fmaxf(acc[m][q][r] * inv_scale + bias_r[m][r], relu_floor);
+                    if constexpr (HAS_RES) v += res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r];
+                    ov[r] = v;
+                    acc[m][q][r] = 0.0f;
+                    const float x = co0 + r < a.cout_store ? v : 0.0f;
+                    _Float16 h, l;
+                    spk_split(x, h, l);
+                    ohi[r] = h; olo[r] = l;
+                }
+                if (outn) {
+                    const uint32_t off = ((uint32_t)co0 * HW32 + po[q]) * 4u;
+                    if (quads) {
+                        if (co0 < a.cout_store && po[q] != ~0u) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (co0 + r < a.cout_store && po[q] != ~0u) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[r];
+                    }
+                }
+                if (spkn) {
+                    const int go = co0 >> 3;
+                    if (go < gout && po[q] != ~0u) {
+                        const uint32_t off = ((uint32_t)go * 2u * HW32 + po[q]) * 16u + (uint32_t)(lg & 1) * 8u;
+                        *reinterpret_cast<h4*>(spkn + off) = ohi;
+                        *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+                    }
+                }
+            }
+    };
+
+    int st_cur = 0;
+    uint32_t full_target = RING_NLOAD;                                    // RING_NLOAD * (use index of the slot + 1)
+#ifdef RING_STAMPS
+    unsigned long long cs_wait = 0, cs_steps = 0, cs_fin = 0;
+    RSTAMP(c_begin)
+#endif
+    for (int g = 0; g < total; ++g) {
+        const bool last = cur_c == n_chunks - 1;                          // workgroup-uniform
+        if constexpr (HAS_RES) { if (last) residual_prefetch(); }
+        RSTAMP(c0)
+        ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
+        RSTAMP(c1)
+        const unsigned char* sb = smem + st_cur * Cfg::STAGE;
+        const unsigned char* win = sb + lane * 16;
+        h8 bh[2][NQ], bl[2][NQ], ah[2][NMT], al[2][NMT];
+        auto ld = [&](int buf, int s) {
+            // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values);
+            // issue order = consumption order of the term-major MFMA sequence (hi x hi, hi x lo, lo x hi)
+            const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
+            const int offA = ((tA / 3) * SPK_IW + tA % 3) * 16, offB = ((tB / 3) * SPK_IW + tB % 3) * 16;
+            const int toff = tap_sel ? offB : offA;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) bh[buf][q] = *reinterpret_cast<const h8*>(sb + boff[q] + toff);
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) ah[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+            if constexpr (TERMS > 1) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bl[buf][q] = *reinterpret_cast<const h8*>(sb + 2 * SPK_PLANE + boff[q] + toff);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) al[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            }
+        };
+        constexpr int N_MFMA = NQ * TERMS * NMT, N_DS = TERMS > 1 ? 2 * NQ + 2 * NMT : NQ + NMT;
+        constexpr int N_TAIL = N_MFMA >= 12 ? 4 : (N_MFMA >= 6 ? 2 : 0);
+        ld(0, 0);
+        __builtin_amdgcn_sched_barrier(0);                               // keep step 0's reads out of the interleave pattern below
+#pragma unroll
+        for (int s = 0; s < SPK_STEPS; ++s) {
+            if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);               // lands while this step's MFMAs run
+#if RING_EARLY_FREE
+            if (s + 2 == SPK_STEPS) { if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(ctr + 16 + 4 * st_cur), "v"(1u) : "memory"); }
+#endif
+#pragma unroll
+            for (int term = 0; term < TERMS; ++term)
+#pragma unroll
+                for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        const h8 av = term == 2 ? al[s & 1][m] : ah[s & 1][m];
+                        const h8 bv = term == 1 ? bl[s & 1][q] : bh[s & 1][q];
+                        acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][q], 0, 0, 0);
+                    }
+            // spread the next step's LDS reads evenly between this step's MFMAs
+            spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);
+        }
+#if !RING_EARLY_FREE
+        ring_signal(ctr + 16 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
+#endif
+        RSTAMP(c2)
+        if (last) {
+            if constexpr (HAS_RES) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the residual prefetched at the top
+            if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(RING_FIN_PRIO);
+            finish_store();
+            if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(0);
+            cur_c = 0; cur_u += a.wgs_per_xcd;
+        } else {
+            ++cur_c;
+        }
+        RSTAMP(c3)
+#ifdef RING_STAMPS
+        cs_wait += c1 - c0; cs_steps += c2 - c1; cs_fin += c3 - c2;
+        if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && g < 24) {
+            unsigned long long* tr = fldr_ring_trace + ((wave == 0 ? 0 : 1) * 24 + g) * 4;
+            tr[0] = c0; tr[1] = c1; tr[2] = c2; tr[3] = c3;
+        }
+#endif
+        if (++st_cur == RING_SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
+    }
+#ifdef RING_STAMPS
+    RSTAMP(c_end)
+    if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == 0 && lane == 0) {
+        unsigned long long* o = fldr_ring_stamp_buf + (blockIdx.x == 0 ? 0 : 2) * 8;
+        o[0] = cs_wait; o[1] = cs_steps; o[2] = cs_fin; o[5] = total; o[6] = c_end - c_begin;
+    }
+#endif
+}
+
+static int g_ring_consumers = 8;
+extern "C" int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
+
+template <int NMT, int TERMS, bool HAS_RES, int NC>
+static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
+    using Cfg = RingCfg<NMT>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC>), Cfg::LDS_BYTES, attr_done)) return e;
+    if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max)) return e;
+    hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC>), dim3(8 * a.wgs_per_xcd), dim3((NC + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+template <int NMT, int TERMS, bool HAS_RES>
+static int ring_launch2(SpkArgs& a, int N, int wpx, hipStream_t s) {
+    return g_ring_consumers == 4 ? ring_launch3<NMT, TERMS, HAS_RES, 4>(a, N, wpx, s) : ring_launch3<NMT, TERMS, HAS_RES, 8>(a, N, wpx, s);
+}
+
+template <int NMT, int TERMS>
+static int ring_launch(SpkArgs& a, int N, int wpx, hipStream_t s) {
+    return a.residual ? ring_launch2<NMT, TERMS, true>(a, N, wpx, s) : ring_launch2<NMT, TERMS, false>(a, N, wpx, s);
+}
+
+int fldr_spk_ring_dispatch(SpkArgs& a, int N, int nmt, int terms, int wgs_per_xcd_max, hipStream_t s) {
+    if (terms == 1) {
+        if (nmt == 1) return ring_launch<1, 1>(a, N, wgs_per_xcd_max, s);
+        if (nmt == 2) return ring_launch<2, 1>(a, N, wgs_per_xcd_max, s);
+        return ring_launch<3, 1>(a, N, wgs_per_xcd_max, s);
+    }
+    if (nmt == 1) return ring_launch<1, 3>(a, N, wgs_per_xcd_max, s);
+    if (nmt == 2) return ring_launch<2, 3>(a, N, wgs_per_xcd_max, s);
+    return ring_launch<3, 3>(a, N, wgs_per_xcd_max, s);
+}

@@ -36,112 +36,7 @@ extern "C" int fldr_debug_read_spk_stamps(unsigned long long* host) {
 #define KSTAMP(var)
 #endif
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(1))) const void* kgptr_t;
-typedef __attribute__((address_space(3))) void* klptr_t;
-
-#define SPK_MAX_GROUPS 14                       // 112 input channels
-#define SPK_TH 8
-#define SPK_TW 32
-#define SPK_IH (SPK_TH + 2)
-#define SPK_IW (SPK_TW + 2)
-#define SPK_PLANE 5632                          // bytes per LDS plane: 340 px * 16 B rounded up to a multiple of 256
-#define SPK_IN_BYTES (4 * SPK_PLANE)
-#define SPK_STEPS 5                             // tap pairs per 16-channel chunk (9 taps + 1 zero tap)
-#define SPK_HDR 8                               // floats before the packed weights: {1/scale, scale, max|w|, 0, 0,0,0,0}
-
-struct SpkArgs {
-    unsigned long long grp_ptr[SPK_MAX_GROUPS];   // hi plane of input group g, sample 0; bit 0 = stored at half resolution (nearest x2 read); 0 = padding group
-    int64_t grp_bstride[SPK_MAX_GROUPS];          // bytes between samples
-    const float* wpack;
-    const float* bias;
-    const float* residual;
-    float* out_f32;                               // [N, cout_store, H, W] or null
-    unsigned char* out_spk;                       // SPK tensor of cout_store channels or null
-    int64_t out_spk_bstride;                      // bytes between samples
-    int32_t n_chunks, cout, cout_store;
-    int32_t H, W;
-    int32_t relu;
-    int32_t tiles_x, n_tiles, groups;             // groups: output-channel groups of 16*NMT channels the launch is split into
-    int32_t pack_nmt;                             // 16-channel blocks per weight-pack group (>= NMT, a multiple of it: small
-                                                  // launches run the NMT=1 kernel on sub-groups of an NMT=3 pack)
-    int32_t n_units, units_per_xcd, wgs_per_xcd;
-    uint32_t m_groups, m_tiles, m_tiles_x;        // floor(2^32 / d) + 1: u / d == umulhi(u, m) for u * d < 2^32 (d > 1)
-};
-
-template <int NMT>
-struct SpkCfg {
-    static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;          // one chunk of one output group, hi + lo
-    static constexpr int PIECES = W_BYTES / 16;
-    static constexpr int NWI = (PIECES + 511) / 512;
-    static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
-    static constexpr int LDS_BYTES = 3 * STAGE;
-    static constexpr int K_MIN = 3 + NWI;                               // DMA instructions every wave issues per iteration
-    static_assert(PIECES % 64 == 0, "weight slab must be a whole number of wave-wide DMA pieces");
-};
-
-__device__ __forceinline__ int spk_div(int u, uint32_t m, int d) {     // exact for 0 <= u, u * d < 2^32 (host-checked)
-    return d == 1 ? u : (int)__umulhi((uint32_t)u, m);
-}
-
-__device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo) {
-    const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);     // 11 significant bits: exact in fp16
-    hi = (_Float16)t;
-    lo = (_Float16)(x - t);
-}
-
-// Scheduling pattern of one MFMA step: N_DS groups of {a share of the N_MFMA matrix instructions, one LDS read}.
-template <int N_MFMA, int N_DS, int I>
-struct SpkInterleave {
-    static __device__ __forceinline__ void run() {
-        constexpr int cnt = (N_MFMA * (I + 1)) / N_DS - (N_MFMA * I) / N_DS;
-        if constexpr (cnt > 0) __builtin_amdgcn_sched_group_barrier(0x008, cnt, 0);
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        SpkInterleave<N_MFMA, N_DS, I + 1>::run();
-    }
-};
-template <int NV, int I>
-struct SpkInterleaveV {                                             // {1 MFMA, 1 vector-memory instruction} x NV
-    static __device__ __forceinline__ void run() {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-        SpkInterleaveV<NV, I + 1>::run();
-    }
-};
-template <int NV>
-struct SpkInterleaveV<NV, NV> {
-    static __device__ __forceinline__ void run() {}
-};
-template <int N_MFMA, int N_DS>
-struct SpkInterleave<N_MFMA, N_DS, N_DS> {
-    static __device__ __forceinline__ void run() {}
-};
-
-// One MFMA step: {1 MFMA, 1 DMA} per DMA instruction of the step, then the next step's LDS reads spread over all but
-// the last N_TAIL MFMAs (which cover the latency of the last read: the wait in front of the next step is an
-// lgkmcnt(0)); the last step has no reads.
-template <int N_MFMA, int N_DS, int N_TAIL, int NV>
-__device__ __forceinline__ void spk_step_pattern_n(bool reads) {
-    SpkInterleaveV<NV, 0>::run();
-    constexpr int rest = N_MFMA - NV;
-    if (reads) {
-        constexpr int tail = rest - N_TAIL >= N_DS / 2 ? N_TAIL : 0;
-        SpkInterleave<rest - tail, N_DS, 0>::run();
-        if constexpr (tail > 0) __builtin_amdgcn_sched_group_barrier(0x008, tail, 0);
-    } else {
-        if constexpr (rest > 0) __builtin_amdgcn_sched_group_barrier(0x008, rest, 0);
-    }
-}
-template <int N_MFMA, int N_DS, int N_TAIL, int K_DMA>
-__device__ __forceinline__ void spk_step_pattern(int s) {            // s is a constant after unrolling
-    const int nv = ((s + 1) * K_DMA + SPK_STEPS - 1) / SPK_STEPS - (s * K_DMA + SPK_STEPS - 1) / SPK_STEPS;
-    const bool reads = s + 1 < SPK_STEPS;
-    if (nv == 0) spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(reads);
-    else if (nv == 1) spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 1>(reads);
-    else spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 2>(reads);
-}
+#include "spk_common.h"
 
 template <int NMT, int TERMS, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
@@ -661,25 +556,17 @@ static int g_spk_wgs_per_xcd = 32;
 static int g_spk_small_units = 96;                 // launches with at most this many units use 16-channel sub-groups (-1: never)
 extern "C" int fldr_debug_spk_small_units(int v) { if (v != 0) g_spk_small_units = v; return g_spk_small_units; }
 extern "C" int fldr_debug_spk_wgs_per_xcd(int v) { if (v > 0) g_spk_wgs_per_xcd = v; return g_spk_wgs_per_xcd; }
+// Pipeline variant: 1 (default) = loader / consumer ring without per-iteration barriers (conv_ring_kernels.hip),
+// 0 = the barrier pipeline of this file.  Same arithmetic, bit-identical results.
+static int g_spk_variant = 1;
+extern "C" int fldr_debug_spk_variant(int v) { if (v >= 0) g_spk_variant = v; return g_spk_variant; }
 
 template <int NMT, int TERMS, bool HAS_RES>
 static int spk_launch2(SpkArgs& a, int N, hipStream_t s) {
     using Cfg = SpkCfg<NMT>;
     static std::atomic<uint64_t> attr_done{0};
     if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_spk_kernel<NMT, TERMS, HAS_RES>), Cfg::LDS_BYTES, attr_done)) return e;
-    a.tiles_x = fldr_cdiv(a.W, SPK_TW);
-    a.n_tiles = a.tiles_x * fldr_cdiv(a.H, SPK_TH);
-    a.n_units = N * a.n_tiles * a.groups;
-    a.units_per_xcd = (a.n_units + 7) / 8;
-    a.units_per_xcd = (a.units_per_xcd + a.groups - 1) / a.groups * a.groups;      // whole tiles per XCD
-    a.wgs_per_xcd = a.units_per_xcd < g_spk_wgs_per_xcd ? a.units_per_xcd : g_spk_wgs_per_xcd;
-    a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;                           // one output group per workgroup (bias kept in registers)
-    if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
-    const int64_t dmax = a.n_tiles > a.groups ? a.n_tiles : a.groups;
-    if (((int64_t)a.n_units + 8 * a.units_per_xcd) * dmax >= (1ll << 32)) return FLDR_E_SHAPE;      // exactness of spk_div
-    a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
-    a.m_tiles = (uint32_t)((1ull << 32) / (uint32_t)a.n_tiles) + 1u;
-    a.m_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x) + 1u;
+    if (int e = spk_fill_geometry(a, N, g_spk_wgs_per_xcd)) return e;
     hipLaunchKernelGGL((conv3x3_spk_kernel<NMT, TERMS, HAS_RES>), dim3(8 * a.wgs_per_xcd), dim3(512), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }
@@ -729,6 +616,7 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
         if (units <= g_spk_small_units) { a.groups = (d->cout + 15) / 16; nmt = 1; }
     }
     hipStream_t s = fldr_s(stream);
+    if (g_spk_variant == 1) return fldr_spk_ring_dispatch(a, d->N, nmt, d->precision == 1 ? 1 : 3, g_spk_wgs_per_xcd, s);
     if (d->precision == 1) {
         if (nmt == 1) return spk_launch<1, 1>(a, d->N, s);
         if (nmt == 2) return spk_launch<2, 1>(a, d->N, s);

@@ -1,0 +1,134 @@
+// Definitions shared by the split-packed 3x3 convolution kernels (conv_spk_kernels.hip: barrier pipeline;
+// conv_ring_kernels.hip: loader / consumer ring): argument block, LDS stage geometry, the hi/lo split and the MFMA /
+// LDS-read interleave patterns.
+#pragma once
+#include "common.h"
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* kgptr_t;
+typedef __attribute__((address_space(3))) void* klptr_t;
+
+#define SPK_MAX_GROUPS 14                       // 112 input channels
+#define SPK_TH 8
+#define SPK_TW 32
+#define SPK_IH (SPK_TH + 2)
+#define SPK_IW (SPK_TW + 2)
+#define SPK_PLANE 5632                          // bytes per LDS plane: 340 px * 16 B rounded up to a multiple of 256
+#define SPK_IN_BYTES (4 * SPK_PLANE)
+#define SPK_STEPS 5                             // tap pairs per 16-channel chunk (9 taps + 1 zero tap)
+#define SPK_HDR 8                               // floats before the packed weights: {1/scale, scale, max|w|, 0, 0,0,0,0}
+
+struct SpkArgs {
+    unsigned long long grp_ptr[SPK_MAX_GROUPS];   // hi plane of input group g, sample 0; bit 0 = stored at half resolution (nearest x2 read); 0 = padding group
+    int64_t grp_bstride[SPK_MAX_GROUPS];          // bytes between samples
+    const float* wpack;
+    const float* bias;
+    const float* residual;
+    float* out_f32;                               // [N, cout_store, H, W] or null
+    unsigned char* out_spk;                       // SPK tensor of cout_store channels or null
+    int64_t out_spk_bstride;                      // bytes between samples
+    int32_t n_chunks, cout, cout_store;
+    int32_t H, W;
+    int32_t relu;
+    int32_t tiles_x, n_tiles, groups;             // groups: output-channel groups of 16*NMT channels the launch is split into
+    int32_t pack_nmt;                             // 16-channel blocks per weight-pack group (>= NMT, a multiple of it: small
+                                                  // launches run the NMT=1 kernel on sub-groups of an NMT=3 pack)
+    int32_t n_units, units_per_xcd, wgs_per_xcd;
+    uint32_t m_groups, m_tiles, m_tiles_x;        // floor(2^32 / d) + 1: u / d == umulhi(u, m) for u * d < 2^32 (d > 1)
+};
+
+template <int NMT>
+struct SpkCfg {
+    static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;          // one chunk of one output group, hi + lo
+    static constexpr int PIECES = W_BYTES / 16;
+    static constexpr int NWI = (PIECES + 511) / 512;
+    static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
+    static constexpr int LDS_BYTES = 3 * STAGE;
+    static constexpr int K_MIN = 3 + NWI;                               // DMA instructions every wave issues per iteration
+    static_assert(PIECES % 64 == 0, "weight slab must be a whole number of wave-wide DMA pieces");
+};
+
+__device__ __forceinline__ int spk_div(int u, uint32_t m, int d) {     // exact for 0 <= u, u * d < 2^32 (host-checked)
+    return d == 1 ? u : (int)__umulhi((uint32_t)u, m);
+}
+
+__device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo) {
+    const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);     // 11 significant bits: exact in fp16
+    hi = (_Float16)t;
+    lo = (_Float16)(x - t);
+}
+
+// Scheduling pattern of one MFMA step: N_DS groups of {a share of the N_MFMA matrix instructions, one LDS read}.
+template <int N_MFMA, int N_DS, int I>
+struct SpkInterleave {
+    static __device__ __forceinline__ void run() {
+        constexpr int cnt = (N_MFMA * (I + 1)) / N_DS - (N_MFMA * I) / N_DS;
+        if constexpr (cnt > 0) __builtin_amdgcn_sched_group_barrier(0x008, cnt, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        SpkInterleave<N_MFMA, N_DS, I + 1>::run();
+    }
+};
+template <int NV, int I>
+struct SpkInterleaveV {                                             // {1 MFMA, 1 vector-memory instruction} x NV
+    static __device__ __forceinline__ void run() {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        SpkInterleaveV<NV, I + 1>::run();
+    }
+};
+template <int NV>
+struct SpkInterleaveV<NV, NV> {
+    static __device__ __forceinline__ void run() {}
+};
+template <int N_MFMA, int N_DS>
+struct SpkInterleave<N_MFMA, N_DS, N_DS> {
+    static __device__ __forceinline__ void run() {}
+};
+
+// One MFMA step: {1 MFMA, 1 DMA} per DMA instruction of the step, then the next step's LDS reads spread over all but
+// the last N_TAIL MFMAs (which cover the latency of the last read: the wait in front of the next step is an
+// lgkmcnt(0)); the last step has no reads.
+template <int N_MFMA, int N_DS, int N_TAIL, int NV>
+__device__ __forceinline__ void spk_step_pattern_n(bool reads) {
+    SpkInterleaveV<NV, 0>::run();
+    constexpr int rest = N_MFMA - NV;
+    if (reads) {
+        constexpr int tail = rest - N_TAIL >= N_DS / 2 ? N_TAIL : 0;
+        SpkInterleave<rest - tail, N_DS, 0>::run();
+        if constexpr (tail > 0) __builtin_amdgcn_sched_group_barrier(0x008, tail, 0);
+    } else {
+        if constexpr (rest > 0) __builtin_amdgcn_sched_group_barrier(0x008, rest, 0);
+    }
+}
+template <int N_MFMA, int N_DS, int N_TAIL, int K_DMA>
+__device__ __forceinline__ void spk_step_pattern(int s) {            // s is a constant after unrolling
+    const int nv = ((s + 1) * K_DMA + SPK_STEPS - 1) / SPK_STEPS - (s * K_DMA + SPK_STEPS - 1) / SPK_STEPS;
+    const bool reads = s + 1 < SPK_STEPS;
+    if (nv == 0) spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(reads);
+    else if (nv == 1) spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 1>(reads);
+    else spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 2>(reads);
+}
+
+// Launch geometry shared by both pipelines: tiles, (sample, tile, group) units, XCD-contiguous unit ranges, persistent
+// workgroups per XCD (a multiple of `groups`: one output group per workgroup) and the magic numbers of spk_div.
+static inline int spk_fill_geometry(SpkArgs& a, int N, int wgs_per_xcd_max) {
+    a.tiles_x = fldr_cdiv(a.W, SPK_TW);
+    a.n_tiles = a.tiles_x * fldr_cdiv(a.H, SPK_TH);
+    a.n_units = N * a.n_tiles * a.groups;
+    a.units_per_xcd = (a.n_units + 7) / 8;
+    a.units_per_xcd = (a.units_per_xcd + a.groups - 1) / a.groups * a.groups;      // whole tiles per XCD
+    a.wgs_per_xcd = a.units_per_xcd < wgs_per_xcd_max ? a.units_per_xcd : wgs_per_xcd_max;
+    a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;                           // one output group per workgroup (bias kept in registers)
+    if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
+    const int64_t dmax = a.n_tiles > a.groups ? a.n_tiles : a.groups;
+    if (((int64_t)a.n_units + 8 * a.units_per_xcd) * dmax >= (1ll << 32)) return FLDR_E_SHAPE;      // exactness of spk_div
+    a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
+    a.m_tiles = (uint32_t)((1ull << 32) / (uint32_t)a.n_tiles) + 1u;
+    a.m_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x) + 1u;
+    return 0;
+}
+
+// conv_ring_kernels.hip: the loader / consumer ring pipeline (nmt in {1,2,3}, terms in {1,3})
+int fldr_spk_ring_dispatch(SpkArgs& a, int N, int nmt, int terms, int wgs_per_xcd_max, hipStream_t s);

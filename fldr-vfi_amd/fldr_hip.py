@@ -106,6 +106,9 @@ _SIGNATURES = {
     "fldr_conv2d_spk": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_void_p]),
     "fldr_debug_spk_wgs_per_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_small_units": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_spk_variant": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_ring_consumers": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_ring_timeouts": (ctypes.c_int, []),
     "fldr_sizeof_desc": (ctypes.c_int, [ctypes.c_int]),
     "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),

@@ -254,6 +254,9 @@ int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
 int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc — binding self-check */
 int fldr_debug_spk_small_units(int v);                              /* tuning hook: launches of <= v units run as 16-channel sub-groups (default 96; -1: never; 0: query) */
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
+int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */
+int fldr_debug_ring_consumers(int v);                              /* tuning hook of the ring pipeline: 8 (default; two consumer waves per SIMD) or 4 consumer waves; other: query */
+int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */
 
 /* ------------------------------------------------------------------------------------------
  * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.

@@ -166,9 +166,19 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape):
     rs = torch.randn(N, cst or cout, H, W, generator=g).to(dev) if res else None
     up2 = [bool(u) for u in ups]
     ref = hip.conv2d(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=up2, precision="split")
-    got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=up2, want_f32=True, want_spk=True)
-    assert torch.equal(ref, got)
-    assert torch.equal(hip.spk_pack(ref).buf, gp.buf)
+    L = hip.lib()
+    try:
+        # every pipeline of fldr_conv2d_spk: loader/consumer ring with 8 (default) and 4 consumer waves, barrier pipeline
+        for variant, cons in ((0, 8), (1, 4), (1, 8)):
+            L.fldr_debug_spk_variant(variant)
+            L.fldr_debug_ring_consumers(cons)
+            got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=up2, want_f32=True, want_spk=True)
+            assert torch.equal(ref, got), (variant, cons)
+            assert torch.equal(hip.spk_pack(ref).buf, gp.buf), (variant, cons)
+    finally:
+        L.fldr_debug_spk_variant(1)
+        L.fldr_debug_ring_consumers(8)
+    assert L.fldr_debug_ring_timeouts() == 0
     if len(cs) == 1 and cst is None and cout % 8 == 0:
         w2 = (torch.randn(48, cout, 3, 3, generator=g) / 20).to(dev)
         assert torch.equal(hip.conv2d([ref], w2, None, precision="split"), hip.conv2d_spk([gp], w2, None))

@@ -73,12 +73,15 @@ for it in range(40):
     ref = hip.conv2d(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, precision="split")
     for su in (-1, 96):
         hip.lib().fldr_debug_spk_small_units(su)
-        got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, want_f32=True, want_spk=True)
-        ok = torch.equal(ref, got) and torch.equal(hip.spk_pack(ref).buf, gp.buf)
-        bad += not ok
-        if not ok: print("spk MISMATCH", N, cs, ups, cout, cst, H, W, relu, res, "small_units", su)
-hip.lib().fldr_debug_spk_small_units(96)
-print("split-packed conv vs split conv: 40 shapes x 2 unit policies,", bad, "mismatches", flush=True)
+        for variant, cons in ((0, 8), (1, 4), (1, 8)):          # barrier pipeline, ring with 4 / 8 consumer waves
+            hip.lib().fldr_debug_spk_variant(variant); hip.lib().fldr_debug_ring_consumers(cons)
+            got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, want_f32=True, want_spk=True)
+            ok = torch.equal(ref, got) and torch.equal(hip.spk_pack(ref).buf, gp.buf)
+            bad += not ok
+            if not ok: print("spk MISMATCH", N, cs, ups, cout, cst, H, W, relu, res, "small_units", su, "variant", variant, cons)
+hip.lib().fldr_debug_spk_small_units(96); hip.lib().fldr_debug_spk_variant(1); hip.lib().fldr_debug_ring_consumers(8)
+bad += hip.lib().fldr_debug_ring_timeouts() != 0
+print("split-packed conv (3 pipelines) vs split conv: 40 shapes x 2 unit policies,", bad, "mismatches", flush=True)
 
 # ---- one-pass PCA (incl. the 4-components-per-thread variant on small grids) vs the two-pass kernel ----
 bad = 0
