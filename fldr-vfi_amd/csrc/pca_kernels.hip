@@ -11,25 +11,13 @@
 
 #define PCA_MAXK 16
 
-__device__ __forceinline__ double atomic_min_f64(double* addr, double v) {
-    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
-    unsigned long long old = *a, assumed;
-    do {
-        assumed = old;
-        if (__longlong_as_double(assumed) <= v) break;
-        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    } while (assumed != old);
-    return __longlong_as_double(old);
+// Hardware fp64 atomics at the L2 (global_atomic_min_f64 / max_f64), fire and forget: see pca_pyramid_kernels.hip for what
+// the compare-and-swap loop they replace cost.
+__device__ __forceinline__ void atomic_min_f64(double* addr, double v) {
+    (void)__hip_atomic_fetch_min(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__device__ __forceinline__ double atomic_max_f64(double* addr, double v) {
-    unsigned long long* a = reinterpret_cast<unsigned long long*>(addr);
-    unsigned long long old = *a, assumed;
-    do {
-        assumed = old;
-        if (__longlong_as_double(assumed) >= v) break;
-        old = atomicCAS(a, assumed, (unsigned long long)__double_as_longlong(v));
-    } while (assumed != old);
-    return __longlong_as_double(old);
+__device__ __forceinline__ void atomic_max_f64(double* addr, double v) {
+    (void)__hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __global__ void pca_init_minmax(double* mm) { mm[0] = 1.0e300; mm[1] = -1.0e300; }

@@ -1,0 +1,380 @@
+// Low-dimensional feature projection of ALL pyramid levels in two launches (pca_comp.py:473-528 called once per level
+// at fLDRnet.py:146): same arithmetic as pca_kernels.hip (fp64, (x - mean) * ev summed over the 64 pixels in row-major
+// order, / meanvec, global min/max per level, ((y - min) / range) * 2 - 1, cast to fp32), bit-identical results.
+//
+// What was slow in the per-level kernels (rocprof, round 2 start: 383 us per 4K forward for 353 MB of algorithmic traffic):
+//   * 18 launches (init + projection + rescale per level), five levels too small to fill the chip;
+//   * the projection parked 106 MB of raw fp64 at level 0 and a streaming kernel read it back (and wrote the rescaled
+//     fp64 in place although the model only consumes the fp32 cast and its split-packed twin);
+//   * the coefficient matrix was read k-major: per (row, component) one 64-byte scalar load feeding EIGHT DEPENDENT
+//     FMAs on one accumulator — the fp64 pipe ran latency-bound at ~45 % (ablation: 62 us with the pixel loads
+//     compiled out, against ~28 us of issue time for 0.95 G fp64 operations at level 0).
+// Here:
+//   * a prepacked table holds the coefficients PIXEL-major (64 rows of K coefficients + the pixel's mean): one row of
+//     scalar loads per pixel feeds K INDEPENDENT FMAs (one per accumulator), so the FMAs issue back to back;
+//   * pass A (one launch over the blocks of all levels) only reduces min / max per level — no stores; pass B (one
+//     launch) recomputes the projection (same code => same bits) and emits fp32 + split-packed directly.  The raw fp64
+//     never touches memory: level 0 moves 2 x 212 MB in (the second read mostly from the Infinity Cache) + 106 MB out
+//     instead of 212 + 106 + 106 in / out + 212 of rescale traffic;
+//   * y / meanvec[k] and (y - min) / range divide by wave-uniform values: the quotient is formed by the Markstein
+//     sequence q = y * r, e = fma(-q, c, y), q' = fma(e, r, q) on the correctly rounded reciprocal r = RN(1 / c),
+//     which is the correctly rounded quotient (checked against true division: tests/test_host_cpu.py on exact rational
+//     arithmetic, tests/test_gpu_parity.py bit-for-bit against pca_kernels.hip) — 3 FMAs instead of ~14 instructions
+//     of which one quarter-rate.
+#include "common.h"
+
+#define PCAP_MAX_LEVELS 8
+#ifndef PCAP_H
+#define PCAP_H 16                       // coefficients per scalar request (16: whole rows for K = 16, 64 cycles of FMAs per request)
+#endif
+
+struct PcapLevel {
+    const float* planes;
+    float* out32;
+    unsigned char* spk;
+    int32_t P, H, W;
+    int32_t wg_start;                 // first workgroup of the level in the launch
+    int64_t nblocks;                  // P * (H/8) * (W/8)
+};
+struct PcapArgs {
+    PcapLevel lv[PCAP_MAX_LEVELS];
+    const double* table;              // 64 rows {K coefficients, mean, 0}, meanvec[K], RN(1 / meanvec)[K] (fldr_pca_prepack)
+    double* mm;                       // [n_levels][2] {min, max}
+    int32_t n_levels;
+};
+
+// Per-level min / max: ONE hardware fp64 atomic per workgroup and bound (global_atomic_min_f64 / max_f64, executed at the
+// L2, nothing returned, nothing waited for).  The compare-and-swap loop of pca_kernels.hip pre-reads the current value
+// through the per-CU L1, which is not coherent with the L2 where atomics execute: nearly every workgroup then saw a stale
+// value, entered the loop, and 2 x 3,240 dependent same-line CAS round trips serialised — that, not HBM or the fp64 pipe,
+// was most of the 125-148 us of a level-0 projection (the same kernel's emit pass, without atomics: 66 us).
+__device__ __forceinline__ void pcap_atomic_min(double* addr, double v) {
+    (void)__hip_atomic_fetch_min(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pcap_atomic_max(double* addr, double v) {
+    (void)__hip_atomic_fetch_max(addr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// x / c for a wave-uniform c with r = RN(1 / c): correctly rounded (Markstein), see the file header
+__device__ __forceinline__ double pcap_div(double x, double c, double r) {
+    const double q = x * r;
+    const double e = fma(-q, c, x);
+    return fma(e, r, q);
+}
+
+__global__ void pcap_init_kernel(double* mm, int n) {
+    if ((int)threadIdx.x < n) { mm[2 * threadIdx.x] = 1.0e300; mm[2 * threadIdx.x + 1] = -1.0e300; }
+}
+
+// table from the module's parameters (EV8 [K,64] k-major, Mean8 [64], meanVec8 [K]); one block of 64 x K threads
+template <int K>
+__global__ void pcap_prepack_kernel(const double* __restrict__ ev, const double* __restrict__ mean, const double* __restrict__ mv,
+                                    double* __restrict__ tab) {
+    const int i = threadIdx.x;                       // pixel
+    for (int k = 0; k < K; ++k) tab[i * (K + 2) + k] = ev[k * 64 + i];
+    tab[i * (K + 2) + K] = mean[i];
+    tab[i * (K + 2) + K + 1] = 0.0;
+    if (i < K) { tab[64 * (K + 2) + i] = mv[i]; tab[64 * (K + 2) + K + i] = 1.0 / mv[i]; }
+}
+
+// Pixels of one 8x8 block: 16 x dwordx4, all issued back to back (the consumer runs a whole block later).
+__device__ __forceinline__ void pcap_load(const float* __restrict__ p, int W, float (&x)[64]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)i * W);
+        const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)i * W + 4);
+        x[i * 8 + 0] = a.x; x[i * 8 + 1] = a.y; x[i * 8 + 2] = a.z; x[i * 8 + 3] = a.w;
+        x[i * 8 + 4] = b.x; x[i * 8 + 5] = b.y; x[i * 8 + 6] = b.z; x[i * 8 + 7] = b.w;
+    }
+}
+
+// y[k] of one 8x8 block, fp64: the accumulation order per component (pixels row-major) and the operations are those of
+// pca_block in pca_kernels.hip.  Table (fldr_pca_prepack): 64 rows {K coefficients, mean, 0} of K + 2 doubles, then
+// meanvec[K], RN(1 / meanvec)[K].
+//
+// The coefficient stream is hand-issued scalar loads in HALF rows of H = min(K, 8) coefficients, one half row ahead of the
+// FMAs that consume it: {request half h+1; H FMAs with half h; s_waitcnt lgkmcnt(0)}.  Two half rows + the mean = 34
+// SGPRs.  Left to the compiler, inside the item loop below, the 140 scalar loads of a block are all placed before the
+// first FMA and parked in VGPR lanes (observed: 4,400 v_writelane / v_readlane per block against 1,024 FMAs), or become
+// vector loads when the pointer is not provably un-aliased by the kernel's own stores.
+typedef double pcap_d8 __attribute__((ext_vector_type(8)));
+typedef double pcap_d4 __attribute__((ext_vector_type(4)));
+
+// `after`: accumulators whose pending FMAs must be placed BEFORE this request (dummy register operands, not referenced by
+// the instruction).  asm volatile statements keep their order among themselves, but the plain FMAs between them do not:
+// without the operands the compiler moves all 128 request / wait pairs of a block in front of the first FMA.
+template <int H> struct PcapHalf;
+template <> struct PcapHalf<8> {
+    pcap_d8 c;
+    __device__ __forceinline__ void request(const double* tab, int byte_off, const double* after) {   // byte_off: compile-time after unrolling
+        if (after) asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(c) : "s"(tab), "i"(byte_off), "v"(after[0]), "v"(after[1]), "v"(after[2]),
+                                "v"(after[3]), "v"(after[4]), "v"(after[5]), "v"(after[6]), "v"(after[7]));
+        else asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(c) : "s"(tab), "i"(byte_off));
+    }
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c)); }
+};
+template <> struct PcapHalf<16> {                                    // a whole row of K = 16: two 16-dword tuples
+    struct { pcap_d8 lo, hi; __device__ __forceinline__ double operator[](int k) const { return k < 8 ? lo[k] : hi[k - 8]; } } c;
+    __device__ __forceinline__ void request(const double* tab, int byte_off, const double* after) {
+        if (after) asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=s"(c.lo), "=s"(c.hi) : "s"(tab), "i"(byte_off), "i"(byte_off + 64),
+                                "v"(after[0]), "v"(after[1]), "v"(after[2]), "v"(after[3]), "v"(after[4]), "v"(after[5]), "v"(after[6]), "v"(after[7]),
+                                "v"(after[8]), "v"(after[9]), "v"(after[10]), "v"(after[11]), "v"(after[12]), "v"(after[13]), "v"(after[14]), "v"(after[15]));
+        else asm volatile("s_load_dwordx16 %0, %2, %3\n\ts_load_dwordx16 %1, %2, %4" : "=s"(c.lo), "=s"(c.hi) : "s"(tab), "i"(byte_off), "i"(byte_off + 64));
+    }
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c.lo), "+s"(c.hi)); }
+};
+template <> struct PcapHalf<4> {
+    pcap_d4 c;
+    __device__ __forceinline__ void request(const double* tab, int byte_off, const double* after) {
+        if (after) asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(c) : "s"(tab), "i"(byte_off), "v"(after[0]), "v"(after[1]), "v"(after[2]), "v"(after[3]));
+        else asm volatile("s_load_dwordx8 %0, %1, %2" : "=s"(c) : "s"(tab), "i"(byte_off));
+    }
+    __device__ __forceinline__ void arrived() { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(c)); }
+};
+
+template <int K>
+__device__ __forceinline__ void pcap_project(const float (&x)[64], const double* tab, double (&y)[K]) {
+    constexpr int H = PCAP_H < K ? PCAP_H : K, NH = K / H, ROW = (K + 2) * 8;      // coefficients per request; requests per pixel; bytes per table row
+#pragma unroll
+    for (int k = 0; k < K; ++k) y[k] = 0.0;
+    PcapHalf<H> buf[2];
+    double mean = 0.0, mean_next = 0.0;
+    // prologue: half 0 of pixel 0 and its mean
+    asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(mean) : "s"(tab), "i"(K * 8));
+    buf[0].request(tab, 0, nullptr);
+    buf[0].arrived();
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mean));
+#pragma unroll
+    for (int h = 0; h < 64 * NH; ++h) {
+        const int i = h / NH, j = h % NH;                               // pixel, half
+        if (h + 1 < 64 * NH) {
+            const int i1 = (h + 1) / NH, j1 = (h + 1) % NH;
+            // ordered after the FMAs of half h-1 (they wrote y[jp*H ...]): keeps the stream one half row ahead, no more
+            const int jp = (h + NH - 1) % NH;
+            buf[(h + 1) & 1].request(tab, i1 * ROW + j1 * H * 8, h > 0 ? &y[jp * H] : nullptr);
+            if (j1 == 0) asm volatile("s_load_dwordx2 %0, %1, %2" : "=s"(mean_next) : "s"(tab), "i"(i1 * ROW + K * 8));
+        }
+        const double d = (double)x[i] - mean;                           // pca_comp.py:502
+#pragma unroll
+        for (int k = 0; k < H; ++k) y[j * H + k] = fma(d, buf[h & 1].c[k], y[j * H + k]);   // :507
+        if (h + 1 < 64 * NH) {
+            buf[(h + 1) & 1].arrived();
+            if ((h + 1) % NH == 0) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(mean_next)); mean = mean_next; }
+        }
+    }
+    // meanvec and its reciprocals behind the rows
+    const double* tail = tab + 64 * (K + 2);
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+        PcapHalf<H> mv, rmv;
+        mv.request(tail, j * H * 8, nullptr);
+        rmv.request(tail, (K + j * H) * 8, nullptr);
+        mv.arrived();
+        rmv.arrived();
+#pragma unroll
+        for (int k = 0; k < H; ++k) y[j * H + k] = pcap_div(y[j * H + k], mv.c[k], rmv.c[k]);   // :511
+    }
+}
+
+// Work item = 256 consecutive blocks of one level (one block per thread); items are numbered level by level.
+struct PcapWhere { int level; bool live; int p; int64_t pix, BHW; const float* src; int W; };
+
+__device__ __forceinline__ PcapWhere pcap_locate(const PcapArgs& a, int item) {
+    PcapWhere w;
+    w.level = 0;
+#pragma unroll
+    for (int l = 1; l < PCAP_MAX_LEVELS; ++l)
+        if (l < a.n_levels && item >= a.lv[l].wg_start) w.level = l;  // workgroup-uniform
+    const PcapLevel& L = a.lv[w.level];
+    const int64_t b = (int64_t)(item - L.wg_start) * 256 + threadIdx.x;
+    w.live = b < L.nblocks;
+    const int BW = L.W >> 3;
+    w.BHW = (int64_t)(L.H >> 3) * BW;
+    const int64_t bb = w.live ? b : 0;                                  // dead lanes read block 0 of the level
+    w.p = (int)(bb / w.BHW);
+    w.pix = bb - (int64_t)w.p * w.BHW;
+    const int by = (int)(w.pix / BW), bx = (int)(w.pix - (int64_t)by * BW);
+    w.W = L.W;
+    w.src = L.planes + (int64_t)w.p * L.H * L.W + (int64_t)by * 8 * L.W + (int64_t)bx * 8;
+    return w;
+}
+
+// Both passes as ONE persistent, double-buffered loop: a workgroup walks the items blockIdx.x, + gridDim.x, ... and the 16
+// row loads of item i+1 are in flight while item i's ~1,200 fp64 operations run.  (One block per thread without the
+// prefetch ran as lock-stepped generations — every resident wave loading, then every wave computing — and reached
+// 107 us for the level-0 min/max pass against 58 us of arithmetic and 37 us of cold HBM read measured separately.)
+//   EMIT = false: pass A, min / max per level (flushed with one hardware atomic pair whenever the level changes);
+//   EMIT = true : pass B, recompute (same code => same bits), rescale, emit fp32 NCHW and / or the split-packed twin.
+template <int K, bool EMIT>
+__global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* __restrict__ table, int total_items) {
+#pragma clang fp contract(off)
+    __shared__ double slo[4], shi[4];
+    float xa[64], xb[64];
+    double lo = 1.0e300, hi = -1.0e300;
+    int cur_level = -1;
+
+    auto flush = [&]() {                                                // workgroup-uniform call sites only
+        if (cur_level < 0) return;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {                        // wave64 shuffle reduction
+            const double ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+            lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+        }
+        __syncthreads();                                                // slo / shi of the previous flush have been read
+        if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < 4; ++i) { lo = slo[i] < lo ? slo[i] : lo; hi = shi[i] > hi ? shi[i] : hi; }
+            pcap_atomic_min(a.mm + 2 * cur_level, lo);
+            pcap_atomic_max(a.mm + 2 * cur_level + 1, hi);
+        }
+        lo = 1.0e300; hi = -1.0e300;
+    };
+
+    auto process = [&](const PcapWhere& w, const float (&x)[64]) {
+        double y[K];
+        // The table pointer is laundered once per block: its 1,100 scalar loads are loop-invariant, and hoisted out of the
+        // item loop they would need ~2,200 SGPRs (observed: thousands of spills).
+        pcap_project<K>(x, table, y);
+        if constexpr (!EMIT) {
+            if (w.level != cur_level) { flush(); cur_level = w.level; }
+            if (w.live) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { lo = y[k] < lo ? y[k] : lo; hi = y[k] > hi ? y[k] : hi; }
+            }
+        } else {
+            if (!w.live) return;
+            const PcapLevel& L = a.lv[w.level];
+            const double mi = a.mm[2 * w.level], range = a.mm[2 * w.level + 1] - mi;
+            const double rr = 1.0 / range;                               // one true division per block; K Markstein quotients
+            float f[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                const double v = pcap_div(y[k] - mi, range, rr) * 2.0 - 1.0;    // pca_comp.py:523-526
+                f[k] = (float)v;                                         // fLDRnet.py:146 .float()
+            }
+            if (L.out32) {
+                float* o = L.out32 + (int64_t)w.p * K * w.BHW + w.pix;
+#pragma unroll
+                for (int k = 0; k < K; ++k) o[(int64_t)k * w.BHW] = f[k];
+            }
+            if (L.spk) {
+                // channel c = p*K + k lives in group c >> 3, slot c & 7: [group][hi, lo][pixel][8 halves]
+                if constexpr (K % 8 == 0) {
+                    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+                    for (int g = 0; g < K / 8; ++g) {
+                        h8 vh, vl;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const float t = __uint_as_float(__float_as_uint(f[g * 8 + k]) & 0xFFFFE000u);   // the split of conv_spk_kernels.hip
+                            vh[k] = (_Float16)t;
+                            vl[k] = (_Float16)(f[g * 8 + k] - t);
+                        }
+                        unsigned char* d = L.spk + (((int64_t)w.p * (K / 8) + g) * 2 * w.BHW + w.pix) * 16;
+                        *reinterpret_cast<h8*>(d) = vh;
+                        *reinterpret_cast<h8*>(d + w.BHW * 16) = vl;
+                    }
+                } else {
+                    static_assert(K == 4, "split-packed output: K must be 4 or a multiple of 8");
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 vh, vl;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float t = __uint_as_float(__float_as_uint(f[k]) & 0xFFFFE000u);
+                        vh[k] = (_Float16)t;
+                        vl[k] = (_Float16)(f[k] - t);
+                    }
+                    unsigned char* d = L.spk + (((int64_t)(w.p >> 1)) * 2 * w.BHW + w.pix) * 16 + (w.p & 1) * 8;
+                    *reinterpret_cast<h4*>(d) = vh;
+                    *reinterpret_cast<h4*>(d + w.BHW * 16) = vl;
+                    if ((L.P & 1) && w.p == L.P - 1) {                   // padding half of the last group: zeros, never uninitialised
+                        const h4 z = {(_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0};
+                        *reinterpret_cast<h4*>(d + 8) = z;
+                        *reinterpret_cast<h4*>(d + w.BHW * 16 + 8) = z;
+                    }
+                }
+            }
+        }
+    };
+
+    const int stride = gridDim.x;
+    int item = blockIdx.x;
+    if (item >= total_items) return;
+    PcapWhere wa = pcap_locate(a, item), wb = wa;
+    pcap_load(wa.src, wa.W, xa);
+    while (true) {
+        int next = item + stride;                                        // workgroup-uniform control flow throughout
+        if (next < total_items) { wb = pcap_locate(a, next); pcap_load(wb.src, wb.W, xb); }
+        __builtin_amdgcn_sched_barrier(0);                               // the prefetch is issued before the arithmetic below
+        process(wa, xa);
+        if (next >= total_items) break;
+        item = next;
+        next = item + stride;
+        if (next < total_items) { wa = pcap_locate(a, next); pcap_load(wa.src, wa.W, xa); }
+        __builtin_amdgcn_sched_barrier(0);
+        process(wb, xb);
+        if (next >= total_items) break;
+        item = next;
+    }
+    if constexpr (!EMIT) flush();
+}
+
+extern "C" int64_t fldr_pca_table_size(int K) {
+    if (K != 4 && K != 8 && K != 16) return FLDR_E_ARG;
+    return 64 * (K + 2) + 2 * K;
+}
+
+extern "C" int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K,
+                                fldr_stream_t stream) {
+    FLDR_CHECK_ARG(ev && mean && meanvec && table);
+    hipStream_t s = fldr_s(stream);
+    switch (K) {
+        case 16: hipLaunchKernelGGL(pcap_prepack_kernel<16>, dim3(1), dim3(64), 0, s, ev, mean, meanvec, table); break;
+        case 8:  hipLaunchKernelGGL(pcap_prepack_kernel<8>, dim3(1), dim3(64), 0, s, ev, mean, meanvec, table); break;
+        case 4:  hipLaunchKernelGGL(pcap_prepack_kernel<4>, dim3(1), dim3(64), 0, s, ev, mean, meanvec, table); break;
+        default: return FLDR_E_ARG;
+    }
+    FLDR_LAUNCH_RET();
+}
+
+static int g_pcap_wgs = 512;                      // persistent workgroups (2 per CU: ~190 VGPRs per thread with both pixel buffers)
+extern "C" int fldr_debug_pca_workgroups(int v) { if (v > 0) g_pcap_wgs = v; return g_pcap_wgs; }
+
+template <int K>
+static void pcap_launch(const PcapArgs& a, int total_items, hipStream_t s) {
+    const int grid = total_items < g_pcap_wgs ? total_items : g_pcap_wgs;
+    hipLaunchKernelGGL(pcap_init_kernel, dim3(1), dim3(64), 0, s, a.mm, a.n_levels);
+    hipLaunchKernelGGL((pcap_kernel<K, false>), dim3(grid), dim3(256), 0, s, a, a.table, total_items);
+    hipLaunchKernelGGL((pcap_kernel<K, true>), dim3(grid), dim3(256), 0, s, a, a.table, total_items);
+}
+
+extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K,
+                                        double* minmax_ws, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(levels && table && minmax_ws && n_levels >= 1 && n_levels <= PCAP_MAX_LEVELS);
+    PcapArgs a;
+    int64_t wg = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const fldr_pca_level& in = levels[l];
+        FLDR_CHECK_ARG(in.planes && (in.out_f32 || in.out_spk) && in.P > 0 && in.H > 0 && in.W > 0);
+        if (in.H % 8 != 0 || in.W % 8 != 0) return FLDR_E_SHAPE;       // pca_comp.py:486-487
+        if (((uintptr_t)in.planes & 15) != 0) return FLDR_E_ARG;       // dwordx4 row loads
+        PcapLevel& L = a.lv[l];
+        L.planes = in.planes; L.out32 = in.out_f32; L.spk = reinterpret_cast<unsigned char*>(in.out_spk);
+        L.P = in.P; L.H = in.H; L.W = in.W;
+        L.nblocks = (int64_t)in.P * (in.H / 8) * (in.W / 8);
+        L.wg_start = (int)wg;
+        wg += (L.nblocks + 255) / 256;
+        if (wg >= (1ll << 30)) return FLDR_E_SHAPE;
+    }
+    for (int l = n_levels; l < PCAP_MAX_LEVELS; ++l) { a.lv[l] = a.lv[0]; a.lv[l].wg_start = 0x7fffffff; a.lv[l].nblocks = 0; }
+    a.table = table; a.mm = minmax_ws; a.n_levels = n_levels;
+    hipStream_t s = fldr_s(stream);
+    switch (K) {
+        case 16: pcap_launch<16>(a, (int)wg, s); break;
+        case 8:  pcap_launch<8>(a, (int)wg, s); break;
+        case 4:  pcap_launch<4>(a, (int)wg, s); break;
+        default: return FLDR_E_ARG;
+    }
+    FLDR_LAUNCH_RET();
+}

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F  # noqa: F401
 
 import fldr_hip
-from pca_comp import pca_inverse, to_pca_diff, to_pca_diff_f32   # noqa: F401  (re-exported like the reference, fLDRnet.py:18)
+from pca_comp import pca_inverse, to_pca_diff, to_pca_diff_f32, to_pca_diff_f32_pyramid   # noqa: F401  (re-exported like the reference, fLDRnet.py:18)
 from softSplat import Softsplat
 from useful import torch_prints, numpy_prints, MyPWC  # noqa: F401  (fLDRnet.py:16)
 
@@ -137,17 +137,19 @@ class DCTXVFInet(nn.Module):
         t4 = t_value.view(B2, 1, 1, 1)
         state = self._pair_lookup(x_l[0]) if self.pair_cache else None
         if state is None:
+            spk = fldr_hip.use_spk()
+            B = x_l[0].shape[0]
+            nch = a.dctvfi_nf * 6
+            # all six projections in two launches (pass A: per-level min / max, pass B: emit): fLDRnet.py:133-146
+            r = to_pca_diff_f32_pyramid([x_l[i].reshape(B * 6, x_l[i].shape[3], x_l[i].shape[4]) for i in range(n_levels)],
+                                        self.params, a, self.pca_means[i8], self.EVs[i8], self.mean_vecs[i8], want_spk=spk)
+            pcas, pcas_p = r if spk else (r, [None] * n_levels)
             feats = []
             for i in range(n_levels):
-                B, _, _, h, w = x_l[i].shape
-                spk = fldr_hip.use_spk()
-                pca = to_pca_diff_f32(x_l[i].reshape(B * 6, h, w), self.params[i], a, self.pca_means[i8], self.EVs[i8],
-                                      self.mean_vecs[i8], want_spk=spk)                              # :146
-                pca_p = None
-                if spk:                                   # [1, 96B, h, w] packed == [B, 96, h, w] packed (12 whole groups per sample)
-                    pca, pca_p = pca
-                    pca_p = fldr_hip.Spk(pca_p.buf, (B, a.dctvfi_nf * 6, h // 8, w // 8))
-                pca = pca.view(B, a.dctvfi_nf * 6, h // 8, w // 8)
+                h, w = x_l[i].shape[3], x_l[i].shape[4]
+                pca = pcas[i].view(B, nch, h // 8, w // 8)
+                # [1, 96B, h, w] packed == [B, 96, h, w] packed (12 whole groups per sample)
+                pca_p = fldr_hip.Spk(pcas_p[i].buf, (B, nch, h // 8, w // 8)) if spk else None
                 feats.append(self._extract_features(pca, pca_p) if a.ref_feat_extrac else (pca, pca_p))
             flow = None
             for level in range(a.S_tst, -1, -1):                                                       # :210-218

@@ -51,6 +51,11 @@ class PrepDesc(ctypes.Structure):
     ]
 
 
+class PcaLevel(ctypes.Structure):
+    _fields_ = [("planes", ctypes.c_void_p), ("out_f32", ctypes.c_void_p), ("out_spk", ctypes.c_void_p),
+                ("P", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class SpkConvDesc(ctypes.Structure):
     _fields_ = [
         ("src", ctypes.c_void_p * MAX_SRC),
@@ -83,6 +88,10 @@ _SIGNATURES = {
     "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project_stream": (ctypes.c_int, [_c_float_p] * 8 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_pca_table_size": (ctypes.c_int64, [ctypes.c_int]),
+    "fldr_pca_prepack": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int, ctypes.c_void_p]),
+    "fldr_pca_project_pyramid": (ctypes.c_int, [ctypes.POINTER(PcaLevel), ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
+    "fldr_debug_pca_workgroups": (ctypes.c_int, [ctypes.c_int]),
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "fldr_resize_bilinear": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
@@ -325,6 +334,54 @@ def pca_project_stream(planes, ev, mean, meanvec, want_spk=False):
         raise Exception("in to_pca_diff the image is not padded right." + str(H) + " " + str(W))   # pca_comp.py:487
     _check(code, "fldr_pca_project_stream")
     return o32, o64, mm, spk
+
+
+def pca_table(ev, mean, meanvec):
+    """Prepacked projection table for pca_project_pyramid, cached on the EV tensor (keyed by the versions / addresses of
+    the three parameters)."""
+    key = (ev._version, ev.data_ptr(), mean._version, mean.data_ptr(), meanvec._version, meanvec.data_ptr(), ev.shape[0])
+    hit = getattr(ev, "_fldr_pca_table", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    K = ev.shape[0]
+    n = lib().fldr_pca_table_size(K)
+    if n < 0:
+        raise FldrError("unsupported number of PCA components %d" % K)
+    tab = torch.empty(n, device=ev.device, dtype=torch.float64)
+    _check(lib().fldr_pca_prepack(_dev(ev.detach().contiguous(), "EV", torch.float64), _dev(mean.detach().contiguous(), "mean", torch.float64),
+                                  _dev(meanvec.detach().contiguous(), "mean_vec", torch.float64), _dev(tab, "table", torch.float64), K, _stream()),
+           "fldr_pca_prepack")
+    ev._fldr_pca_table = (key, tab)
+    return tab
+
+
+def pca_project_pyramid(planes_list, ev, mean, meanvec, want_f32=True, want_spk=False):
+    """to_pca_diff(...).float() of every pyramid level in two launches (fLDRnet.py:133-146).  planes_list: [P,H_l,W_l]
+    fp32 tensors.  -> (list of fp32 [P*K,h,w] or None, list of Spk [1,P*K,h,w] or None, minmax [n_levels,2])."""
+    ev = ev.detach()
+    K = ev.shape[0]
+    tab = pca_table(ev, mean.detach(), meanvec.detach())
+    n = len(planes_list)
+    arr = (PcaLevel * n)()
+    outs32, outsp, keep = [], [], []
+    for i, pl in enumerate(planes_list):
+        P, H, W = pl.shape
+        if H % 8 or W % 8:
+            raise Exception("in to_pca_diff the image is not padded right." + str(H) + " " + str(W))   # pca_comp.py:487
+        pl = pl.contiguous()
+        keep.append(pl)
+        o32 = torch.empty(P * K, H // 8, W // 8, device=pl.device, dtype=torch.float32) if want_f32 else None
+        osp = _spk_alloc(1, P * K, H // 8, W // 8, pl.device) if want_spk else None
+        outs32.append(o32)
+        outsp.append(osp)
+        arr[i].planes = _dev(pl, "planes").value
+        arr[i].out_f32 = o32.data_ptr() if o32 is not None else None
+        arr[i].out_spk = osp.buf.data_ptr() if osp is not None else None
+        arr[i].P, arr[i].H, arr[i].W = P, H, W
+    mm = torch.empty(n, 2, device=planes_list[0].device, dtype=torch.float64)
+    _check(lib().fldr_pca_project_pyramid(arr, n, _dev(tab, "table", torch.float64), K, _dev(mm, "minmax", torch.float64), _stream()),
+           "fldr_pca_project_pyramid")
+    return (outs32 if want_f32 else None), (outsp if want_spk else None), mm
 
 
 def bwarp(x, flo, withmask=True):

@@ -46,6 +46,19 @@ def to_pca_diff_f32(im, params, args, mean, EV, mean_vec, want_spk=False):
     return (o32, spk) if want_spk else o32
 
 
+def to_pca_diff_f32_pyramid(ims, params, args, mean, EV, mean_vec, want_spk=False):
+    """to_pca_diff(...).float() for ALL pyramid levels of a forward (the loop of fLDRnet.py:133-146) in two launches:
+    ims = [x_l[i].reshape(B*6, h_i, w_i)]; the same EV8 / Mean8 / meanVec8 at every level (fLDRnet.py:135).
+    -> list of fp32 [P*K,h,w] (and, with want_spk, the list of split-packed twins)."""
+    k = _check(ims[0], params[0], args, mean_vec)
+    for p in params[:len(ims)]:
+        if _check(ims[0], p, args, mean_vec) != k:
+            raise NotImplementedError("pyramid levels with different numbers of components")
+    o32, spk, _ = fldr_hip.pca_project_pyramid(ims, EV.detach()[:k].contiguous(), mean.detach(), mean_vec.detach()[:k].contiguous(),
+                                               want_f32=True, want_spk=want_spk)
+    return (o32, spk) if want_spk else o32
+
+
 def to_pca(im, params, components_fraction=0, args=0, pca=0):
     """Training-time PCA fit / transform of 8x8 blocks (pca_comp.py:370-471).  Not part of the inference path."""
     raise NotImplementedError("to_pca fits the block PCA during training; inference projects with to_pca_diff on the "

@@ -119,6 +119,23 @@ int fldr_pca_project_stream(const float* planes, const double* ev, const double*
                             float* out_f32_or_null, double* out_f64, void* out_spk_or_null, double* minmax_ws,
                             int P, int K, int H, int W, fldr_stream_t stream);
 
+/* All pyramid levels of a forward in two launches (the six to_pca_diff calls of fLDRnet.py:133-146): pass A reduces the
+ * per-level min / max, pass B recomputes the projection and emits the fp32 cast and / or its split-packed twin — no fp64
+ * intermediate in memory.  Same arithmetic and bit-identical results to fldr_pca_project per level.  `table` comes from
+ * fldr_pca_prepack (fldr_pca_table_size(K) doubles: coefficients pixel-major, mean, meanvec and its reciprocals);
+ * minmax_ws: 2 * n_levels doubles, on completion {min, max} per level.  n_levels <= 8; K in {4, 8, 16}. */
+typedef struct fldr_pca_level {
+    const float* planes;       /* [P, H, W] fp32, 16-byte aligned; H, W multiples of 8 */
+    float*       out_f32;      /* [P*K, H/8, W/8] or NULL */
+    void*        out_spk;      /* packed [1, P*K, H/8, W/8] (fldr_spk_bytes) or NULL */
+    int32_t      P, H, W, reserved;
+} fldr_pca_level;
+int64_t fldr_pca_table_size(int K);
+int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K, fldr_stream_t stream);
+int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K, double* minmax_ws,
+                             fldr_stream_t stream);
+int fldr_debug_pca_workgroups(int v);                             /* tuning hook: persistent workgroups of the two pyramid passes (default 512); 0: query */
+
 /* ------------------------------------------------------------------------------------------
  * Gathers and resizes — replace DCTVFInet.bwarp and the F.interpolate calls of fLDRnet.py.
  * ------------------------------------------------------------------------------------------ */

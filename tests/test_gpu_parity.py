@@ -150,6 +150,27 @@ def test_pca_stream_equals_two_pass(hip, dev, model):
     assert torch.equal(hip.spk_pack(o32.view(1, 192, 9, 17)).buf, spk.buf)
 
 
+@pytest.mark.parametrize("K", [16, 8, 4])
+def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K):
+    """fldr_pca_project_pyramid (all levels in two launches, pixel-major table, Markstein quotients, no fp64 intermediate)
+    against the per-level one-pass kernels of fldr_pca_project_stream: fp32 output, split-packed twin and min / max are
+    the same bits at every level, including levels of a few blocks and an odd number of planes."""
+    m, _ = model
+    g = _gen(31)
+    ev, mean, mv = m.EV8.detach()[:K].contiguous(), m.Mean8.detach(), m.meanVec8.detach()[:K].contiguous()
+    P = 6 if K != 4 else 5
+    levels = [(64, 96), (32, 48), (16, 24), (8, 8), (40, 520)]
+    planes = [(torch.rand(P, h, w, generator=g) * 2 - 1).to(dev) for (h, w) in levels]
+    o32, osp, mm = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=True, want_spk=True)
+    for i, pl in enumerate(planes):
+        s32, s64, smm, spk = hip.pca_project_stream(pl, ev, mean, mv, want_spk=True)
+        assert torch.equal(smm, mm[i]), (i, smm, mm[i])
+        assert torch.equal(s32, o32[i]), (i, (s32 - o32[i]).abs().max().item())
+        assert torch.equal(spk.buf, osp[i].buf), i
+    only_spk = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=False, want_spk=True)[1]
+    assert all(torch.equal(a.buf, b.buf) for a, b in zip(only_spk, osp))
+
+
 @pytest.mark.parametrize("shape", [(1, [96], [0], 96, None, 9, 15, True, True), (2, [96], [0], 48, None, 20, 37, True, False),
                                    (1, [48, 48, 4], [0, 0, 0], 96, None, 36, 60, True, False), (1, [48], [0], 6, 4, 9, 15, False, False),
                                    (1, [64, 32], [1, 0], 32, None, 24, 40, True, False), (1, [32, 16], [1, 0], 16, None, 48, 80, True, False),

@@ -219,3 +219,31 @@ print("OK", type(model).__module__)
 ''' % os.path.join(ROOT, "fldr-vfi_amd")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "OK fLDRnet" in r.stdout, r.stdout + r.stderr
+
+
+def test_markstein_quotient_is_the_correctly_rounded_fp64_division():
+    """pca_pyramid_kernels.hip divides by wave-uniform values with q = x*r, e = fma(-q, c, x), q' = fma(e, r, q) on
+    r = RN(1/c) instead of the IEEE division sequence.  Exact rational arithmetic (float(Fraction) rounds to nearest
+    even) shows q' == RN(x / c) for the divisors this path meets: the 16 meanVec8 entries of the shipped checkpoint and
+    min/max ranges of projected features, over random and adversarial numerators."""
+    from fractions import Fraction as Fr
+    import random
+    z = np.load(os.path.join(ROOT, "fldr-vfi_amd", "weights", "fLDRnet_X4K1000FPS_exp1_best_PSNR.npz"))
+    divisors = [float(v) for v in z["meanVec8"]] + [3.0, 7.345678901234567, 1.0 / 3.0, 41.70302134, 0.1, 1e-3 + 1e-19, 123456.789]
+
+    def fma(a, b, c):
+        return float(Fr(a) * Fr(b) + Fr(c))
+
+    rng = random.Random(5)
+    checked = 0
+    for c in divisors:
+        r = float(Fr(1) / Fr(c))                      # RN(1 / c)
+        xs = [rng.uniform(-40.0, 40.0) for _ in range(400)] + [rng.uniform(-1e-3, 1e-3) for _ in range(100)]
+        xs += [c * k for k in (1.0, 3.0, 0.5, 1 + 2 ** -52, 1 - 2 ** -53)] + [float(np.nextafter(c * 5.0, 0.0)), float(np.nextafter(c * 5.0, 100.0))]
+        for x in xs:
+            q = float(Fr(x) * Fr(r))
+            e = fma(-q, c, x)
+            q2 = fma(e, r, q)
+            assert q2 == float(Fr(x) / Fr(c)), (x, c, q2)
+            checked += 1
+    assert checked > 10000
