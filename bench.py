@@ -304,6 +304,8 @@ def main():
         sync()
         dt_e2e = (time.perf_counter() - t1) / max(1, a.steps // 4)
         assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
+        import fldr_hip
+        fldr_hip.check_range()                         # no activation left the range of the fp16 hi/lo split (would raise)
     dt = max_over_ranks(dt_local, device)
     per_rank = gather_floats(a.steps / dt_local, device)
 

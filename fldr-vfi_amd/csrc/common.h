@@ -26,6 +26,42 @@ static inline int fldr_set_max_lds(const void* fn, int bytes, std::atomic<uint64
     return 0;
 }
 
+// ---- fp16 hi/lo split with a range guard ---------------------------------------------------------------------------
+// x = hi + lo, hi = x truncated to 11 significant bits (exact in fp16), lo = fp16(x - hi): the operand form of the
+// 3 x fp16-split MFMA convolutions.  fp16 ends at 65504: beyond it a plain conversion gives hi = inf and the convolution
+// NaN where the fp32 reference stays finite.  Guard: both halves are clamped to +-65504 (|x| < 131008 is then still
+// represented, to fp16 precision of the excess: absolute error <= 16; beyond that — and for NaN inputs — the value
+// SATURATES to a finite number) and the event is recorded in a sticky per-library flag that fldr_range_status()
+// reports, so it is never silent: the accurate remedy for such data is FLDR_CONV_PRECISION=fp32.  In-range values produce the same
+// bits as the unguarded split (2 v_med3 + 1 compare per element more).
+#define FLDR_F16_MAX 65504.0f
+static __device__ int fldr_tu_range_flag;                 // one per translation unit (read by fldr_tu_range_read below)
+__device__ __forceinline__ void fldr_split_hl(float x, _Float16& hi, _Float16& lo, bool& bad) {
+#ifdef FLDR_NO_RANGE_GUARD                               // A/B builds only (tools/build_lib_variant.sh): the unguarded split
+    const float t0 = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+    hi = (_Float16)t0; lo = (_Float16)(x - t0);
+    return;
+#endif
+    bad |= !(fabsf(x) <= FLDR_F16_MAX);                  // overflow or NaN
+    const float t = __builtin_amdgcn_fmed3f(__uint_as_float(__float_as_uint(x) & 0xFFFFE000u), -FLDR_F16_MAX, FLDR_F16_MAX);
+    hi = (_Float16)t;
+    lo = (_Float16)__builtin_amdgcn_fmed3f(x - t, -FLDR_F16_MAX, FLDR_F16_MAX);
+}
+__device__ __forceinline__ void fldr_note_range(bool bad) { if (bad) fldr_tu_range_flag = 1; }
+static inline int fldr_tu_range_read(int reset) {
+    int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_tu_range_flag), sizeof(int)) != hipSuccess) return -1;
+    if (v && reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(fldr_tu_range_flag), &z, sizeof(int)); }
+    return v;
+}
+// translation units that split: each exports its flag through one of these (aggregated by fldr_range_status)
+int fldr_range_read_spk(int reset);
+int fldr_range_read_ring(int reset);
+int fldr_range_read_conv(int reset);
+int fldr_range_read_s2(int reset);
+int fldr_range_read_split(int reset);
+int fldr_range_read_warp(int reset);
+
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
 // the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.
 // Call it on a whole batch of loaded values AFTER all loads of the batch have been written down.

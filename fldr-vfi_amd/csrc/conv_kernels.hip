@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, ((MT == 16 && NMT == 3) || (KS == 4 && MT == 1
     const int64_t HWo = (int64_t)a.Hout * a.Wout;
     float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
     unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
+    bool range_bad = false;
     const float* resn = a.residual ? a.residual + (int64_t)n * a.cout_store * HWo : nullptr;
     float bias_r[NMT][NR];
 #pragma unroll
@@ -339,9 +340,9 @@ __global__ __launch_bounds__(256, ((MT == 16 && NMT == 3) || (KS == 4 && MT == 1
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                        const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
-                        hi[r] = (_Float16)t;
-                        lo[r] = (_Float16)(x - t);
+                        _Float16 h_, l_;
+                        fldr_split_hl(x, h_, l_, range_bad);
+                        hi[r] = h_; lo[r] = l_;
                     }
                     if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                         unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -352,7 +353,10 @@ __global__ __launch_bounds__(256, ((MT == 16 && NMT == 3) || (KS == 4 && MT == 1
             }
         }
     }
+    if (spkn) fldr_note_range(range_bad);
 }
+
+int fldr_range_read_conv(int reset) { return fldr_tu_range_read(reset); }
 
 // ------------------------------------------------------------------------------------------------
 // weight prepack: [cout,cin,k,k] -> [cin_pad][taps][mtot], zero padded

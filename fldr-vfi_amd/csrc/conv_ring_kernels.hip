@@ -59,6 +59,8 @@ extern "C" int fldr_debug_ring_timeouts(void) {
     return v;
 }
 
+int fldr_range_read_ring(int reset) { return fldr_tu_range_read(reset); }
+
 template <int NMT>
 struct RingCfg {
     static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;
@@ -303,6 +305,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     // has no predication at all: ~20 VALU instructions and the stores per (pixel block, 16-channel block); the general
     // one predicates every store.  ReLU is max(v, floor) with floor = 0 or -FLT_MAX: no select.
     const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
+    bool range_bad = false;
     const bool grp_full = cbase + MTOT <= a.cout_store && !(a.cout_store & 7);      // wave-uniform, constant over the kernel
     auto finish_store = [&]() {
         const int t = spk_div(cur_u, a.m_groups, a.groups);
@@ -330,7 +333,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                         ov[r] = v;
                         acc[m][q][r] = 0.0f;
                         _Float16 h, l;
-                        spk_split(v, h, l);
+                        spk_split(v, h, l, range_bad);
                         ohi[r] = h; olo[r] = l;
                     }
                     if (outn) {
@@ -369,7 +372,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     acc[m][q][r] = 0.0f;
                     const float x = co0 + r < a.cout_store ? v : 0.0f;
                     _Float16 h, l;
-                    spk_split(x, h, l);
+                    spk_split(x, h, l, range_bad);
                     ohi[r] = h; olo[r] = l;
                 }
                 if (outn) {
@@ -474,6 +477,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
         if (++st_cur == RING_SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
     }
+    if (a.out_spk) fldr_note_range(range_bad);
 #ifdef RING_STAMPS
     RSTAMP(c_end)
     if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == 0 && lane == 0) {

@@ -182,6 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             dst[2 * i] = v0; dst[2 * i + 1] = v1;
         }
     };
+    bool range_bad = false;
     auto store_inputs = [&](unsigned char* stage, const float (&src)[2 * S2_NI]) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2* hi = reinterpret_cast<h2*>(stage + Cfg::W_BYTES) + wave * CHS;
@@ -190,11 +191,9 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
         for (int i = 0; i < S2_NI; ++i) {
             if (l_dw[i] < 0) continue;
             const float x0 = src[2 * i], x1 = src[2 * i + 1];
-            const float t0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u);    // the split of conv_split_kernels.hip
-            const float t1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
-            h2 h, l;
-            h[0] = (_Float16)t0; h[1] = (_Float16)t1;
-            l[0] = (_Float16)(x0 - t0); l[1] = (_Float16)(x1 - t1);
+            h2 h, l;                                                               // the guarded split of common.h
+            { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[0] = a_; l[0] = b_; }
+            { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[1] = a_; l[1] = b_; }
             hi[l_dw[i]] = h;                                                       // half 0 = the even row of the pair
             lo[l_dw[i]] = l;
         }
@@ -287,9 +286,9 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                        const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
-                        hi[r] = (_Float16)t;
-                        lo[r] = (_Float16)(x - t);
+                        _Float16 h_, l_;
+                        fldr_split_hl(x, h_, l_, range_bad);
+                        hi[r] = h_; lo[r] = l_;
                     }
                     if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                         unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -300,6 +299,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             }
         }
     }
+    fldr_note_range(range_bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -410,6 +410,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         dst[2 * S2_NI] = __uint_as_float(live ? iss_m0 : 0u); dst[2 * S2_NI + 1] = __uint_as_float(live ? iss_m1 : 0u);
         if (++iss_c == n_chunks) { iss_c = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }      // (past the end: the last tile again)
     };
+    bool range_bad = false;
     auto store_inputs = [&](unsigned char* stage, const float (&src)[2 * S2_NI + 2]) __attribute__((always_inline)) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const unsigned m0 = __float_as_uint(src[2 * S2_NI]), m1 = __float_as_uint(src[2 * S2_NI + 1]);
@@ -419,11 +420,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int i = 0; i < S2_NI; ++i) {
             if (l_dw[i] < 0) continue;
             const float x0 = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
-            const float t0 = __uint_as_float(__float_as_uint(x0) & 0xFFFFE000u);
-            const float t1 = __uint_as_float(__float_as_uint(x1) & 0xFFFFE000u);
             h2 h, l;
-            h[0] = (_Float16)t0; h[1] = (_Float16)t1;
-            l[0] = (_Float16)(x0 - t0); l[1] = (_Float16)(x1 - t1);
+            { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[0] = a_; l[0] = b_; }
+            { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[1] = a_; l[1] = b_; }
             hi[l_dw[i]] = h;
             lo[l_dw[i]] = l;
         }
@@ -531,9 +530,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                            const float t2 = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
-                            hi[r] = (_Float16)t2;
-                            lo[r] = (_Float16)(x - t2);
+                            _Float16 h_, l_;
+                            fldr_split_hl(x, h_, l_, range_bad);
+                            hi[r] = h_; lo[r] = l_;
                         }
                         if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                             unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -573,7 +572,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (cur_c == n_chunks - 1) { epilogue(); cur_c = 0; ++cur_k; } else ++cur_c;
         __syncthreads();
     }
+    fldr_note_range(range_bad);
 }
+
+int fldr_range_read_s2(int reset) { return fldr_tu_range_read(reset); }
 
 // ------------------------------------------------------------------------------------------------
 // prepack: max|w| -> power-of-two scale -> hi/lo halves in A-operand order [chunk][step][m][kind][lane][8 halves]

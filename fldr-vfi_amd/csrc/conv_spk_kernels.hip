@@ -232,6 +232,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
                     res_r[m][p][r] = resn[(uint32_t)co * HW32 + (po[p] != ~0u ? po[p] : 0u)];
                 }
     };
+    bool range_bad = false;
     auto finish = [&]() {
         unit_pixels(cur_u, st_po, st_n);
 #pragma unroll
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
                     acc[m][p][r] = 0.0f;
                     const float x = cbase + m * 16 + lg * 4 + r < a.cout_store ? v : 0.0f;
                     _Float16 h, l;
-                    spk_split(x, h, l);
+                    spk_split(x, h, l, range_bad);
                     ohi[m][p][r] = h; olo[m][p][r] = l;
                 }
             }
@@ -406,6 +407,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
         st_iss = st_iss == 2 ? 0 : st_iss + 1;
     }
     if (store_pending) store();
+    if (a.out_spk) fldr_note_range(range_bad);
 #ifdef SPK_STAMPS
     KSTAMP(k_end)
     if ((blockIdx.x == 0 || blockIdx.x == 101) && (wave == 0 || wave == 4) && lane == 0) {
@@ -428,8 +430,10 @@ __global__ void spk_pack_kernel(const float* __restrict__ src, int64_t src_bstri
 #pragma unroll
     for (int k = 0; k < 8; ++k) x[k] = g * 8 + k < C ? s[(int64_t)k * HW] : 0.0f;
     h8 hi, lo;
+    bool bad = false;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { _Float16 h, l; spk_split(x[k], h, l); hi[k] = h; lo[k] = l; }
+    for (int k = 0; k < 8; ++k) { _Float16 h, l; spk_split(x[k], h, l, bad); hi[k] = h; lo[k] = l; }
+    fldr_note_range(bad);
     unsigned char* d = dst + (int64_t)n * dst_bstride + ((int64_t)g * 2 * HW + pix) * 16;
     *reinterpret_cast<h8*>(d) = hi;
     *reinterpret_cast<h8*>(d + HW * 16) = lo;
@@ -445,6 +449,18 @@ __global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t
 #pragma unroll
     for (int k = 0; k < 8; ++k)
         if (g * 8 + k < C) dst[((int64_t)n * C + g * 8 + k) * HW + pix] = (float)hi[k] + (float)lo[k];
+}
+
+int fldr_range_read_spk(int reset) { return fldr_tu_range_read(reset); }
+
+// Sticky range status of the fp16 hi/lo splits (common.h: fldr_split_hl): 1 if any value beyond +-65504 (or a NaN) was
+// split — and saturated — since the last reset on the current device, else 0; negative on a HIP error.  Synchronises.
+extern "C" int fldr_range_status(int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    int v = 0;
+    int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp};
+    for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x; }
+    return v;
 }
 
 // sizeof of the descriptor structs as this library was compiled (binding self-check: tests/test_host_cpu.py)

@@ -82,14 +82,16 @@ struct SplitCfg {
 
 // x = hi + lo with hi = x truncated to 11 significant bits (exactly representable in fp16 for normal-range x, so its
 // conversion is exact) and lo = fp16(x - hi): 3 VALU ops per element instead of 5-6 for the round-to-nearest split.
-__device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo) {
+__device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo, bool& bad) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float t = __uint_as_float(__float_as_uint(x[k]) & 0xFFFFE000u);
-        hi[k] = (_Float16)t;
-        lo[k] = (_Float16)(x[k] - t);
+        _Float16 h, l;
+        fldr_split_hl(x[k], h, l, bad);                                  // the guarded split of common.h
+        hi[k] = h; lo[k] = l;
     }
 }
+
+int fldr_range_read_split(int reset) { return fldr_tu_range_read(reset); }
 
 // TERMS = 3: hi*hi + hi*lo + lo*hi (fp32-equivalent); TERMS = 1: hi*hi only = plain fp16 inputs, fp32 accumulate
 // (BASELINE config 5, "fp16 path with MFMA convs"; 11-bit operands, error ~1e-3 relative).
@@ -173,13 +175,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
             }
         }
     };
+    bool range_bad = false;
     auto store_inputs = [&](int chunk) {                        // -> input stage chunk & 1
         unsigned char* stage = smem + Cfg::X_OFF + (chunk & 1) * SP_IN_BYTES;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             if (l_off[i] < 0) continue;
             h8 hi, lo;
-            split8(pre[i], hi, lo);
+            split8(pre[i], hi, lo, range_bad);
             *reinterpret_cast<h8*>(stage + l_off[i]) = hi;
             *reinterpret_cast<h8*>(stage + 2 * SP_CG_STRIDE + l_off[i]) = lo;
         }
@@ -340,6 +343,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_split_kernel(SplitArgs a) {
                 if (co < a.cout_store && pix_ok) outn[(int64_t)co * HW + po] = v;
             }
     }
+    fldr_note_range(range_bad);
 }
 
 // ------------------------------------------------------------------------------------------------

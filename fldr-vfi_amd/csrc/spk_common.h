@@ -54,11 +54,7 @@ __device__ __forceinline__ int spk_div(int u, uint32_t m, int d) {     // exact 
     return d == 1 ? u : (int)__umulhi((uint32_t)u, m);
 }
 
-__device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo) {
-    const float t = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);     // 11 significant bits: exact in fp16
-    hi = (_Float16)t;
-    lo = (_Float16)(x - t);
-}
+__device__ __forceinline__ void spk_split(float x, _Float16& hi, _Float16& lo, bool& bad) { fldr_split_hl(x, hi, lo, bad); }
 
 // Scheduling pattern of one MFMA step: N_DS groups of {a share of the N_MFMA matrix instructions, one LDS read}.
 template <int N_MFMA, int N_DS, int I>

@@ -232,6 +232,7 @@ __global__ __launch_bounds__(256) void splat_finish_spk_kernel(const float* __re
     float norm = 1.0f;
     if (NORMALISE) { norm = a[(int64_t)C * HW]; if (norm == 0.0f) norm = 1.0f; }
     h8 hi, lo;
+    bool bad = false;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int c = g * 8 + k;
@@ -241,14 +242,17 @@ __global__ __launch_bounds__(256) void splat_finish_spk_kernel(const float* __re
             if (NORMALISE) v = v / norm;
             v = (v - 0.5f) * 2.0f;
         }
-        const float t = __uint_as_float(__float_as_uint(v) & 0xFFFFE000u);
-        hi[k] = (_Float16)t;
-        lo[k] = (_Float16)(v - t);
+        _Float16 h_, l_;
+        fldr_split_hl(v, h_, l_, bad);                                   // the guarded split of common.h
+        hi[k] = h_; lo[k] = l_;
     }
+    fldr_note_range(bad);
     unsigned char* d = out + (((int64_t)n * G + g) * 2 * HW + i) * 16;
     *reinterpret_cast<h8*>(d) = hi;
     *reinterpret_cast<h8*>(d + HW * 16) = lo;
 }
+
+int fldr_range_read_warp(int reset) { return fldr_tu_range_read(reset); }
 
 extern "C" int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
                                   int N, int C, int H, int W, fldr_stream_t stream) {

@@ -12,7 +12,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfldr_hip.so")
+LIB_PATH = os.environ.get("FLDR_LIB") or os.path.join(_HERE, "libfldr_hip.so")     # FLDR_LIB: an experimental build (A/B measurements)
 
 MAX_SRC = 12
 _c_float_p = ctypes.c_void_p
@@ -114,6 +114,7 @@ _SIGNATURES = {
     "fldr_conv_spk_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_spk": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_void_p]),
     "fldr_debug_spk_wgs_per_xcd": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_range_status": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_small_units": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_consumers": (ctypes.c_int, [ctypes.c_int]),
@@ -479,6 +480,23 @@ def conv_prepack(weight):
 # "fp32" = exact fp32 MFMA, "fp16" = fp16 inputs with fp32 accumulation (BASELINE config 5; NOT fp32-equivalent).
 # Stride-2 4x4 convolutions always use the exact fp32 MFMA kernel.
 CONV_PRECISION = os.environ.get("FLDR_CONV_PRECISION", "split")
+
+
+def range_status(reset=True):
+    """True if an activation left the range of the fp16 hi/lo split (|x| >= 65504, or NaN) since the last reset: such
+    values SATURATE (finite, never inf / NaN from finite inputs) and are flagged here.  Synchronises the device."""
+    v = lib().fldr_range_status(int(bool(reset)))
+    if v < 0:
+        raise FldrError("fldr_range_status failed (%d)" % v)
+    return bool(v)
+
+
+def check_range():
+    """Raise if the split-precision convolutions saturated an activation (see range_status); the remedy is
+    FLDR_CONV_PRECISION=fp32 (exact fp32 MFMA everywhere)."""
+    if range_status(reset=True):
+        raise FldrError("an activation exceeded the fp16 split range (|x| >= 65504 or NaN) and was saturated; "
+                        "rerun with FLDR_CONV_PRECISION=fp32")
 
 
 def use_spk():

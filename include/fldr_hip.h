@@ -269,6 +269,11 @@ int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
 int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
 int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc — binding self-check */
+/* Range status of the fp16 hi/lo splits behind the split-precision convolutions (fp32-equivalent for |x| <= 65504; up to
+ * 131008 the excess is kept to fp16 precision; beyond that, and for NaN inputs, values SATURATE to a finite number —
+ * never inf / NaN out of finite inputs): 1 if that happened on
+ * the current device since the last reset, 0 if not, negative on a HIP error.  Synchronises the device. */
+int fldr_range_status(int reset);
 int fldr_debug_spk_small_units(int v);                              /* tuning hook: launches of <= v units run as 16-channel sub-groups (default 96; -1: never; 0: query) */
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */

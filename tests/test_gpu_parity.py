@@ -730,6 +730,45 @@ def test_split_fp16_conv_is_fp32_equivalent(hip, dev, shape):
     assert e["split"][0] <= 1.5 * e["fp32"][0] + 1e-8 and e["split"][1] <= 2.0 * e["fp32"][1] + 1e-7
 
 
+def test_split_conv_range_guard(hip, dev):
+    """fp16 ends at 65504: the hi/lo split behind the split-precision convolutions must never turn a finite activation
+    into inf / NaN.  Up to 131008 the value is still represented (hi saturates, lo carries the excess to fp16
+    precision: absolute error <= 16); beyond it the value saturates to a finite number; both cases and NaN inputs raise
+    the sticky status flag (fldr_range_status), in-range data does not."""
+    g = _gen(41)
+    N, C, H, W = 1, 48, 24, 40
+    wt = (torch.randn(32, C, 3, 3, generator=g) * 0.02).to(dev)
+    x = (torch.randn(N, C, H, W, generator=g) * 50).to(dev)
+    hip.range_status(reset=True)
+    ref = hip.conv2d([x], wt, None, precision="fp32")
+    got = hip.conv2d_spk([x], wt, None)
+    assert not hip.range_status() and (got - ref).abs().max().item() <= 1e-3
+    big = x.clone()
+    big[0, 3, 5, 7] = 1.0e5                                 # beyond fp16, inside the extended exact range
+    big[0, 9, 11, 13] = -9.0e4
+    ref = hip.conv2d([big], wt, None, precision="fp32")
+    for srcs in ([big], [hip.spk_pack(big)]):               # packed on the fly / packed by the caller
+        hip.range_status(reset=True)
+        got = hip.conv2d_spk(srcs if not isinstance(srcs[0], hip.Spk) else srcs, wt, None)
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 16.0 * wt.abs().max().item() * 1.01     # <= 16 absolute on the one big input of a window
+    hip.spk_pack(big)
+    assert hip.range_status()                               # ... and it was flagged
+    assert not hip.range_status()                           # sticky until read with reset
+    huge = x.clone()
+    huge[0, 0, 0, 0] = 3.0e7
+    huge[0, 1, 2, 3] = float("nan")
+    got = hip.conv2d_spk([huge], wt, None, want_f32=True, want_spk=True)
+    assert torch.isfinite(got[0]).all() and torch.isfinite(got[1].float()).all()      # saturated, never inf / NaN
+    with pytest.raises(hip.FldrError):
+        hip.check_range()
+    # the stride-2 encoders and the register-staged split conv stage fp32 sources through the same guarded split
+    w4 = (torch.randn(16, C, 4, 4, generator=g) * 0.02).to(dev)
+    o = hip.conv2d([huge.nan_to_num(0.0)], w4, None, stride=2)
+    o2 = hip.conv2d([huge.nan_to_num(0.0)], wt, None, precision="split")
+    assert torch.isfinite(o).all() and torch.isfinite(o2).all() and hip.range_status()
+
+
 def test_fp16_conv_path_config5(hip, oracle, weights, dev, model):
     """BASELINE config 5: 3x3 convs with plain fp16 inputs (fp32 accumulate).  Not fp32-equivalent: report the error
     and the PSNR between its rounded 8-bit frame and the oracle's (the fp32-class paths are at ~100 dB)."""
