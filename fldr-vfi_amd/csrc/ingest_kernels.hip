@@ -105,3 +105,105 @@ extern "C" int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8
     else             hipLaunchKernelGGL(metrics_kernel<float>, grid, dim3(256), 0, fldr_s(stream), (const float*)pred, target_u8_or_null, out_u8_or_null, sse_zeroed_or_null, H, W, Hp, Wp);
     FLDR_LAUNCH_RET();
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// SSIM of the Y channel (utils.ssim_bgr, utils.py:662-669, called at main.py:911) on the device.
+// pred / target: uint8 [B,3,H,W], channel 0 = B, 1 = G, 2 = R (cv2 order, utils.py:237-251).  Y = 0.2568 R + 0.5041 G +
+// 0.0979 B + 16 in fp64 (utils.py:690-711); scikit-image's structural_similarity defaults: 7x7 uniform window, sample
+// covariance, K1 = 0.01, K2 = 0.03, data_range = max(Y_pred) - min(Y_pred), mean over the map cropped by 3 pixels.
+// Pass 1 writes both Y planes (fp64) and reduces min / max of Y_pred; pass 2 evaluates the map from LDS tiles and
+// accumulates its sum.  ws per sample: [2 H W] Y planes, then {min, max, sum, unused}.
+// ------------------------------------------------------------------------------------------------
+__global__ void ssim_init_kernel(double* ws, int64_t stride, int B, int64_t planes) {
+    if ((int)threadIdx.x < B) { double* s = ws + threadIdx.x * stride + planes; s[0] = 1.0e300; s[1] = -1.0e300; s[2] = 0.0; s[3] = 0.0; }
+}
+
+__global__ __launch_bounds__(256) void ssim_y_kernel(const uint8_t* __restrict__ pred, const uint8_t* __restrict__ target,
+                                                     double* __restrict__ ws, int64_t stride, int64_t HW) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    double yp = 0.0, lo = 1.0e300, hi = -1.0e300;
+    if (i < HW) {
+        const uint8_t* p = pred + (int64_t)b * 3 * HW + i;
+        const uint8_t* t = target + (int64_t)b * 3 * HW + i;
+        // np.dot of the (R, G, B) row with T[0]: ((R t0 + G t1) + B t2), then + 16 — products and sums in fp64
+        yp = ((double)p[2 * HW] * 0.256788235294118 + (double)p[HW] * 0.504129411764706) + (double)p[0] * 0.097905882352941 + 16.0;
+        const double yt = ((double)t[2 * HW] * 0.256788235294118 + (double)t[HW] * 0.504129411764706) + (double)t[0] * 0.097905882352941 + 16.0;
+        double* w = ws + (int64_t)b * stride;
+        w[i] = yt;                                                   // plane 0: Y_true, plane 1: Y_pred
+        w[HW + i] = yp;
+        lo = hi = yp;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+        lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        double* s = ws + (int64_t)b * stride + 2 * HW;
+        (void)__hip_atomic_fetch_min(s, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void)__hip_atomic_fetch_max(s + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+#define SSIM_TW 32
+#define SSIM_TH 8
+__global__ __launch_bounds__(256) void ssim_map_kernel(double* __restrict__ ws, int64_t stride, int H, int W) {
+#pragma clang fp contract(off)
+    __shared__ double tx[SSIM_TH + 6][SSIM_TW + 6], ty[SSIM_TH + 6][SSIM_TW + 6];
+    const int b = blockIdx.z;
+    const int64_t HW = (int64_t)H * W;
+    const double* X = ws + (int64_t)b * stride;
+    const double* Y = X + HW;
+    double* stat = ws + (int64_t)b * stride + 2 * HW;
+    const int x0 = blockIdx.x * SSIM_TW + 3, y0 = blockIdx.y * SSIM_TH + 3;       // first output pixel of the tile (interior only)
+    for (int e = threadIdx.x; e < (SSIM_TH + 6) * (SSIM_TW + 6); e += 256) {
+        const int r = e / (SSIM_TW + 6), c = e - r * (SSIM_TW + 6);
+        const int gy = min(y0 - 3 + r, H - 1), gx = min(x0 - 3 + c, W - 1);      // clamped taps are only read by masked outputs
+        tx[r][c] = X[(int64_t)gy * W + gx];
+        ty[r][c] = Y[(int64_t)gy * W + gx];
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (SSIM_TW - 1), ly = threadIdx.x / SSIM_TW;
+    const int ox = x0 + lx, oy = y0 + ly;
+    double s = 0.0;
+    if (ox < W - 3 && oy < H - 3) {
+        double sx = 0.0, sy = 0.0, sxx = 0.0, syy = 0.0, sxy = 0.0;
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int c = 0; c < 7; ++c) {
+                const double a = tx[ly + r][lx + c], d = ty[ly + r][lx + c];
+                sx += a; sy += d; sxx += a * a; syy += d * d; sxy += a * d;
+            }
+        const double R = stat[1] - stat[0];
+        const double C1 = (0.01 * R) * (0.01 * R), C2 = (0.03 * R) * (0.03 * R);
+        const double ux = sx / 49.0, uy = sy / 49.0, uxx = sxx / 49.0, uyy = syy / 49.0, uxy = sxy / 49.0;
+        const double cn = 49.0 / 48.0;
+        const double vx = cn * (uxx - ux * ux), vy = cn * (uyy - uy * uy), vxy = cn * (uxy - ux * uy);
+        s = ((2.0 * ux * uy + C1) * (2.0 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    __shared__ double part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(stat + 2, (part[0] + part[1]) + (part[2] + part[3]));
+}
+
+extern "C" int64_t fldr_ssim_y_ws_doubles(int B, int H, int W) {
+    if (B <= 0 || H <= 0 || W <= 0) return FLDR_E_ARG;
+    return (int64_t)B * (2ll * H * W + 4);
+}
+
+extern "C" int fldr_ssim_y_u8(const uint8_t* pred_u8, const uint8_t* target_u8, double* ws, int B, int H, int W,
+                              fldr_stream_t stream) {
+    FLDR_CHECK_ARG(pred_u8 && target_u8 && ws && B > 0 && B <= 64);
+    if (H < 7 || W < 7) return FLDR_E_SHAPE;                            // the 7x7 window must fit (skimage raises too)
+    const int64_t HW = (int64_t)H * W, stride = 2 * HW + 4;
+    hipStream_t s = fldr_s(stream);
+    hipLaunchKernelGGL(ssim_init_kernel, dim3(1), dim3(64), 0, s, ws, stride, B, 2 * HW);
+    hipLaunchKernelGGL(ssim_y_kernel, dim3(fldr_cdiv(HW, 256), B), dim3(256), 0, s, pred_u8, target_u8, ws, stride, HW);
+    hipLaunchKernelGGL(ssim_map_kernel, dim3(fldr_cdiv(W - 6, SSIM_TW), fldr_cdiv(H - 6, SSIM_TH), B), dim3(256), 0, s, ws, stride, H, W);
+    FLDR_LAUNCH_RET();
+}

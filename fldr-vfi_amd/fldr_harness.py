@@ -131,20 +131,23 @@ def interpolate_multi(model, args, frames, t_values, pyramid=None):
     return outs
 
 
-def interpolate_u8(model, args, frames_u8, t_value, target_u8=None):
+def interpolate_u8(model, args, frames_u8, t_value, target_u8=None, want_ssim=False):
     """End-to-end on the device: uint8 frames [B,2,3,H,W] (I0, I1) -> normalise + reflect pad + bicubic pyramid
     (fldr_ingest_u8 / fldr_pyramid_bicubic) -> forward -> rounded uint8 frame [B,3,H,W] (and, with a uint8 ground
-    truth, the per-sample PSNR list) via fldr_frame_metrics.  Only uint8 crosses PCIe in either direction."""
+    truth, the per-sample PSNR list; with want_ssim (PSNR list, SSIM-Y list): main.py:910-911) via fldr_frame_metrics /
+    fldr_ssim_y_u8.  Only uint8 crosses PCIe in either direction."""
     import fldr_hip
     B, T, C, H, W = frames_u8.shape
     with torch.no_grad():
         pyr = fldr_hip.ingest_pyramid(frames_u8, args.S_tst + 1)
         pred, _ = model([None] * (args.S_tst + 1), t_value, normInput=pyr, is_training=False, validation=False)
         sse, img = fldr_hip.frame_metrics(pred, min(H, pred.shape[2]), min(W, pred.shape[3]), target_u8, want_u8=True)
+        ssim = fldr_hip.ssim_y_u8(img, target_u8) if (want_ssim and target_u8 is not None) else None
     if sse is None:
         return img, None
     mse = (sse / (3.0 * H * W)).cpu()
-    return img, [float("inf") if m == 0 else 10 * math.log10(255.0 ** 2 / m) for m in mse.tolist()]
+    ps = [float("inf") if m == 0 else 10 * math.log10(255.0 ** 2 / m) for m in mse.tolist()]
+    return (img, (ps, ssim.cpu().tolist())) if ssim is not None else (img, ps)
 
 
 def to_uint8_image(pred):
@@ -157,6 +160,15 @@ def psnr(img_true, img_pred):
     """utils.psnr with XVFIPSNR False (utils.py:644-652): data_range 255 over all channels."""
     err = np.mean((np.asarray(img_true, dtype=np.float64) - np.asarray(img_pred, dtype=np.float64)) ** 2)
     return float("inf") if err == 0 else 10 * math.log10(255.0 ** 2 / err)
+
+
+def ssim_bgr(img_true, img_pred):
+    """utils.ssim_bgr (utils.py:662-669) for two [H,W,3] BGR images with rounded values in [0,255] (numpy or tensors),
+    computed on the device by fldr_ssim_y_u8."""
+    dev = torch.device('cuda', torch.cuda.current_device())
+    to = lambda a: torch.as_tensor(np.asarray(a)).round().clamp(0, 255).to(torch.uint8).permute(2, 0, 1).unsqueeze(0).to(dev)
+    import fldr_hip
+    return float(fldr_hip.ssim_y_u8(to(img_pred), to(img_true))[0].item())
 
 
 def frames_from_uint8(u8):

@@ -130,6 +130,8 @@ _SIGNATURES = {
                                                _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_ssim_y_ws_doubles": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "fldr_ssim_y_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_frame_metrics": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
                            + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
 }
@@ -822,3 +824,22 @@ def frame_metrics(pred, H, W, target_u8=None, want_u8=False):
                                     _dev(sse, "sse", torch.float64) if sse is not None else None,
                                     B, H, W, Hp, Wp, _stream()), "fldr_frame_metrics")
     return sse, img
+
+
+def ssim_y_u8(pred_u8, target_u8):
+    """utils.ssim_bgr (utils.py:662-669) on the device: uint8 [B,3,H,W] images in cv2 channel order -> SSIM-Y per sample
+    as a [B] fp64 DEVICE tensor (no synchronisation)."""
+    B, C, H, W = pred_u8.shape
+    assert C == 3 and target_u8.shape == pred_u8.shape
+    pred_u8, target_u8 = pred_u8.contiguous(), target_u8.contiguous()
+    n = lib().fldr_ssim_y_ws_doubles(B, H, W)
+    if n < 0:
+        raise FldrError("bad SSIM shape")
+    ws = torch.empty(n, device=pred_u8.device, dtype=torch.float64)
+    code = lib().fldr_ssim_y_u8(_dev(pred_u8, "pred", torch.uint8), _dev(target_u8, "target", torch.uint8),
+                                _dev(ws, "ws", torch.float64), B, H, W, _stream())
+    if code == -2:
+        raise ValueError("win_size exceeds image extent (7x7 window)")
+    _check(code, "fldr_ssim_y_u8")
+    stats = ws.view(B, 2 * H * W + 4)[:, 2 * H * W:]
+    return stats[:, 2] / float((H - 6) * (W - 6))

@@ -326,6 +326,15 @@ int fldr_pyramid_bicubic(const float* level0, float* level_i, int planes, int Hp
 int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8_t* target_u8_or_null, uint8_t* out_u8_or_null,
                        double* sse_zeroed_or_null, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream);
 
+/* utils.ssim_bgr (utils.py:662-669; main.py:911) on the device: SSIM of the Y channel of two uint8 images [B,3,H,W]
+ * in cv2 channel order (0 = B, 1 = G, 2 = R) — the rounded frame fldr_frame_metrics writes and the ground truth — with
+ * scikit-image's structural_similarity defaults (7x7 uniform window, sample covariance, K1 0.01, K2 0.03, data_range =
+ * max - min of Y_pred, map cropped by 3 pixels), all in fp64.  ws: fldr_ssim_y_ws_doubles(B,H,W) doubles; on completion
+ * sample b's statistics sit at ws[b * (2 H W + 4) + 2 H W ...] = {min Y_pred, max Y_pred, sum of the SSIM map, 0}:
+ * SSIM = sum / ((H - 6) (W - 6)).  H, W >= 7. */
+int64_t fldr_ssim_y_ws_doubles(int B, int H, int W);
+int fldr_ssim_y_u8(const uint8_t* pred_u8, const uint8_t* target_u8, double* ws, int B, int H, int W, fldr_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -378,6 +378,39 @@ def psnr(img_true, img_pred):
     return float("inf") if err == 0 else 10 * math.log10(255.0 ** 2 / err)
 
 
+_YCBCR_Y = (0.256788235294118, 0.504129411764706, 0.097905882352941)      # utils.py:695 (first row of T), offset 16
+
+
+def ssim_y(img_true, img_pred):
+    """utils.ssim_bgr (utils.py:662-669): SSIM of the Y channel of two [H,W,3] BGR images holding rounded values in
+    [0,255].  `to_uint8(x, 0, 255)` (utils.py:637-641) re-rounds in float32, `[:, :, ::-1]` makes it RGB, `_rgb2ycbcr`
+    (:690-711) gives Y = T[0] . (R,G,B) + 16 in float64, and `structural_similarity(Y_true, Y_pred, data_range =
+    Y_pred.max() - Y_pred.min())` is scikit-image 0.19.3 (requirements.txt:4; NOT installed here) with its defaults,
+    restated from its published algorithm (Wang et al. 2004 as implemented in skimage.metrics._structural_similarity):
+    win_size 7, uniform window via scipy.ndimage.uniform_filter (the same scipy routine skimage calls), sample covariance
+    (NP / (NP - 1)), K1 = 0.01, K2 = 0.03, mean of the SSIM map cropped by (win_size - 1) // 2 = 3 pixels per side.
+    Parity unpinned by reference vectors (the reference holds none for SSIM); pinned by known-answer tests."""
+    from scipy.ndimage import uniform_filter
+
+    def y_of(img):
+        x = np.asarray(img).astype("float32")
+        x = np.clip(np.round((x - 0) / (255 - 0) * 255), 0, 255)[:, :, ::-1]        # to_uint8, BGR -> RGB
+        t = x.reshape(-1, 3).astype(np.float64) @ np.asarray(_YCBCR_Y, dtype=np.float64)
+        return (t + 16.0).reshape(x.shape[0], x.shape[1])
+
+    X, Y = y_of(img_true), y_of(img_pred)
+    R = Y.max() - Y.min()
+    win, NP = 7, 49
+    cov_norm = NP / (NP - 1.0)
+    ux, uy = uniform_filter(X, size=win), uniform_filter(Y, size=win)
+    uxx, uyy, uxy = uniform_filter(X * X, size=win), uniform_filter(Y * Y, size=win), uniform_filter(X * Y, size=win)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win - 1) // 2
+    return float(S[pad:-pad, pad:-pad].mean(dtype=np.float64))
+
+
 def synthetic_pair(H, W, seed=0, quadrant=False, device="cpu"):
     """Seeded synthetic uint8 frame pair (bench.py, tests, golden fixtures): a multi-octave (1/f-like) random
     texture, so that every pyramid level sees structure as in natural video; I1 is I0 shifted by (6,4) px, or by

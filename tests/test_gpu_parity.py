@@ -808,6 +808,18 @@ def test_gpu_ingest_matches_cpu_caller(hip, oracle, dev, size):
         _cmp(got[i], ref[i], atol=2e-6, what="bicubic level %d" % i)
 
 
+def test_interpolate_u8_reports_psnr_and_ssim(hip, oracle, dev, model):
+    """uint8 in -> uint8 out with PSNR and SSIM-Y against a ground truth, all on the device (main.py:885-911)."""
+    import fldr_harness as Hn
+    m, a = model
+    u = Hn.synthetic_pair(200, 328, seed=6)
+    gt = u[0:1].to(dev)                                              # any uint8 frame serves as "ground truth" here
+    img, (ps, ss) = Hn.interpolate_u8(m, a, u.unsqueeze(0).to(dev), torch.tensor([[0.5]], device=dev), target_u8=gt, want_ssim=True)
+    hwc = lambda t: np.transpose(t.cpu().numpy(), (1, 2, 0)).astype(np.float64)
+    assert ss[0] == pytest.approx(oracle.ssim_y(hwc(gt[0]), hwc(img[0])), abs=1e-10)
+    assert ps[0] == pytest.approx(oracle.psnr(hwc(gt[0]), hwc(img[0])), abs=1e-9)
+
+
 def test_gpu_metrics_and_u8_roundtrip(hip, oracle, weights, dev, model):
     import fldr_harness as Hn
     m, a = model
@@ -824,6 +836,31 @@ def test_gpu_metrics_and_u8_roundtrip(hip, oracle, weights, dev, model):
     assert (np.abs(diff) > 0).mean() < 1e-3 and np.abs(diff).max() <= 1  # rounding ties aside, identical 8-bit frames
     want = oracle.psnr(gt[0].permute(1, 2, 0).double().numpy(), img[0].permute(1, 2, 0).cpu().double().numpy())
     assert abs(ps[0] - want) < 1e-9
+
+
+@pytest.mark.parametrize("size", [(96, 128), (61, 203), (7, 9), (540, 960)])
+def test_gpu_ssim_y_matches_oracle(hip, oracle, dev, size):
+    """fldr_ssim_y_u8 (utils.ssim_bgr on the device, 8f-3) against the oracle's restatement on seeded frames, a batch of
+    two with different distortions; fp64 throughout -> 1e-10."""
+    H, W = size
+    u = oracle.synthetic_pair(H + 0, W + 0, seed=9, quadrant=True)              # [2,3,H,W] uint8, channel 0 = B
+    tgt = u[0]
+    g = _gen(3)
+    noisy = (tgt.float() + torch.randn(tgt.shape, generator=g) * 9).round().clamp(0, 255).to(torch.uint8)
+    preds = torch.stack([u[1], noisy], 0)
+    tgts = torch.stack([tgt, tgt], 0)
+    got = hip.ssim_y_u8(preds.to(dev), tgts.to(dev)).cpu().tolist()
+    hwc = lambda t: np.transpose(t.numpy(), (1, 2, 0)).astype(np.float64)
+    for b in range(2):
+        ref = oracle.ssim_y(hwc(tgts[b]), hwc(preds[b]))
+        assert got[b] == pytest.approx(ref, abs=1e-10), (b, got[b], ref)
+    same = hip.ssim_y_u8(tgts.to(dev), tgts.to(dev)).cpu().tolist()
+    assert same[0] == pytest.approx(1.0, abs=1e-13)
+    import fldr_harness as Hn
+    assert Hn.ssim_bgr(hwc(tgts[1]), hwc(preds[1])) == pytest.approx(got[1], abs=1e-13)
+    if H == 7:
+        with pytest.raises(ValueError):
+            hip.ssim_y_u8(preds[:, :, :6].contiguous().to(dev), tgts[:, :, :6].contiguous().to(dev))
 
 
 def test_odd_shape_stress_of_kernel_variants(hip, dev, capsys):

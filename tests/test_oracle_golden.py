@@ -181,3 +181,42 @@ def test_oracle_backward_restatements_match_autograd_of_the_forward():
     ga, gb = torch.autograd.grad(c, [a, b], gc)
     ra, rb = O.correlation_backward(a.detach(), b.detach(), gc)
     assert (ga - ra).abs().max() < 2e-6 and (gb - rb).abs().max() < 2e-6
+
+
+def test_ssim_y_oracle_known_answers(oracle):
+    """oracle.ssim_y restates utils.ssim_bgr (utils.py:662-669) + scikit-image 0.19.3's structural_similarity defaults.
+    The reference holds no SSIM vectors and scikit-image is not installed here, so it is pinned by known answers:
+    identical images -> 1; an INDEPENDENT direct evaluation of the definition (explicit 7x7 windows, no uniform_filter)
+    on the interior; monotone in the distortion; and committed values (tests/golden/ssim_y_known_answers.json, generated
+    by the oracle itself: a regression pin, not a reference vector)."""
+    import json
+    import os
+    rng = np.random.default_rng(7)
+    a = rng.integers(0, 256, (23, 31, 3)).astype(np.float64)
+    b = np.clip(a + rng.normal(0, 12, a.shape), 0, 255).round()
+    assert oracle.ssim_y(a, a) == pytest.approx(1.0, abs=1e-15)
+
+    def direct(x, y):                                       # the definition, window by window
+        w = np.array([0.256788235294118, 0.504129411764706, 0.097905882352941])
+        X = x[:, :, ::-1] @ w + 16.0
+        Y = y[:, :, ::-1] @ w + 16.0
+        R = Y.max() - Y.min()
+        C1, C2 = (0.01 * R) ** 2, (0.03 * R) ** 2
+        vals = []
+        for i in range(3, X.shape[0] - 3):
+            for j in range(3, X.shape[1] - 3):
+                p, q = X[i - 3:i + 4, j - 3:j + 4].ravel(), Y[i - 3:i + 4, j - 3:j + 4].ravel()
+                ux, uy = p.mean(), q.mean()
+                vx, vy = p.var(ddof=1), q.var(ddof=1)
+                vxy = ((p - ux) * (q - uy)).sum() / 48.0
+                vals.append((2 * ux * uy + C1) * (2 * vxy + C2) / ((ux * ux + uy * uy + C1) * (vx + vy + C2)))
+        return float(np.mean(vals))
+    assert oracle.ssim_y(a, b) == pytest.approx(direct(a, b), abs=1e-11)
+    worse = np.clip(a + rng.normal(0, 40, a.shape), 0, 255).round()
+    assert oracle.ssim_y(a, worse) < oracle.ssim_y(a, b) < 1.0
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ssim_y_known_answers.json")))
+    u = oracle.synthetic_pair(96, 128, seed=3, quadrant=True).numpy()
+    t, p = np.transpose(u[0], (1, 2, 0)).astype(np.float64), np.transpose(u[1], (1, 2, 0)).astype(np.float64)
+    assert oracle.ssim_y(t, p) == pytest.approx(fx["frame1_vs_frame0"], abs=1e-12)
+    assert oracle.ssim_y(t, np.clip(t + 5, 0, 255)) == pytest.approx(fx["plus5"], abs=1e-12)
+    assert oracle.ssim_y(t, np.round((t + p) / 2)) == pytest.approx(fx["blur_like_half"], abs=1e-12)
