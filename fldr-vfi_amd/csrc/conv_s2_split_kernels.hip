@@ -49,6 +49,7 @@ struct S2Args {
     int32_t relu;
     int32_t tiles_x, n_tiles, tiles_per_xcd;
     int32_t N, wgs_per_xcd;    // persistent kernel: samples (tiles are numbered over all samples), workgroups per XCD
+    int32_t x_shift;           // persistent kernel: the tile grid starts x_shift output columns left of the image (see s2_launch_pers)
 };
 
 // kernel tap (dy, dx) of k slot j (0..7) within row pair rp (0..1): dword d = j / 2 -> (parity, index offset); half j % 2 -> row
@@ -378,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         iss_n = t / a.n_tiles;
         const int tile = t - iss_n * a.n_tiles;
         const int ty = tile / a.tiles_x;
-        const int iy0 = ty * S2_TH * 2 - 1, ix0 = (tile - ty * a.tiles_x) * S2_TW * 2 - 1;
+        const int iy0 = ty * S2_TH * 2 - 1, ix0 = ((tile - ty * a.tiles_x) * S2_TW - a.x_shift) * 2 - 1;
         iss_m0 = 0; iss_m1 = 0;
 #pragma unroll
         for (int i = 0; i < S2_NI; ++i) {
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int t = t_first + cur_k * a.wgs_per_xcd;
         const int n = t / a.n_tiles, tile = t - n * a.n_tiles;
         const int ty = tile / a.tiles_x;
-        const int oy0 = ty * S2_TH, ox0 = (tile - ty * a.tiles_x) * S2_TW;
+        const int oy0 = ty * S2_TH, ox0 = (tile - ty * a.tiles_x) * S2_TW - a.x_shift;
         float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
         unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
         const int lk = lg;
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         for (int p = 0; p < PT; ++p) {
             const int oy = oy0 + wave * RPW + p / TPR;
             const int ox = ox0 + (p % TPR) * MT + lj;
-            const bool pix_ok = oy < a.Hout && ox < a.Wout;
+            const bool pix_ok = oy < a.Hout && ox >= 0 && ox < a.Wout;
             const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
 #pragma unroll
             for (int m = 0; m < NMT; ++m) {
@@ -667,6 +668,8 @@ static int s2_launch(S2Args& a, int N, hipStream_t s) {
 }
 
 // Persistent kernel: 2 workgroups per CU (LDS: all weights + two input stages), XCD-contiguous tile ranges.
+static int g_s2_xshift = -1;                     // -1: automatic (15 on wide images); >= 0: forced (0 .. 31)
+extern "C" int fldr_debug_s2_xshift(int v) { if (v >= -1 && v < S2_TW) g_s2_xshift = v; return g_s2_xshift; }
 static int g_s2_persistent = 1;
 extern "C" int fldr_debug_s2_persistent(int v) { if (v >= 0) g_s2_persistent = v; return g_s2_persistent; }
 
@@ -681,7 +684,12 @@ static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {
         if (e != hipSuccess) return (int)e;
         attr_bytes[dev & 63].store(lds_bytes, std::memory_order_release);
     }
-    a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
+    // Tile grid shifted left by 15 output columns on wide images: a tile's 66 input columns then start ONE float into a
+    // 128-byte line ([64 t - 31, 64 t + 34]) and touch 3 lines per row instead of the 4 of the unshifted span
+    // [64 t - 1, 64 t + 64] (one float each into the lines left and right).  PMC at 4K, enc1: the L2 fetched 1,629 MB for
+    // 920 MB of planes and the kernel ran at the fabric's ~6.4 TB/s; one extra, partly filled tile column pays for it.
+    a.x_shift = g_s2_xshift >= 0 ? g_s2_xshift : (a.Wout >= 256 ? 15 : 0);
+    a.tiles_x = fldr_cdiv(a.Wout + a.x_shift, S2_TW);
     a.n_tiles = a.tiles_x * fldr_cdiv(a.Hout, S2_TH);
     a.N = N;
     const int64_t total = (int64_t)N * a.n_tiles;

@@ -107,6 +107,7 @@ _SIGNATURES = {
     "fldr_conv_s2_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_s2_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_debug_s2_persistent": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_s2_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -339,14 +340,17 @@ def pca_project_stream(planes, ev, mean, meanvec, want_spk=False):
     return o32, o64, mm, spk
 
 
+_PCA_TABLES = {}
+
+
 def pca_table(ev, mean, meanvec):
-    """Prepacked projection table for pca_project_pyramid, cached on the EV tensor (keyed by the versions / addresses of
-    the three parameters)."""
-    key = (ev._version, ev.data_ptr(), mean._version, mean.data_ptr(), meanvec._version, meanvec.data_ptr(), ev.shape[0])
-    hit = getattr(ev, "_fldr_pca_table", None)
-    if hit is not None and hit[0] == key:
-        return hit[1]
+    """Prepacked projection table for pca_project_pyramid, cached per (storage address, version) of the three parameters
+    (callers pass fresh views such as EV8.detach()[:k] on every forward, so the cache cannot live on the tensor object)."""
     K = ev.shape[0]
+    key = (ev.data_ptr(), ev._version, mean.data_ptr(), mean._version, meanvec.data_ptr(), meanvec._version, K, ev.device.index)
+    hit = _PCA_TABLES.get(key)
+    if hit is not None:
+        return hit
     n = lib().fldr_pca_table_size(K)
     if n < 0:
         raise FldrError("unsupported number of PCA components %d" % K)
@@ -354,7 +358,10 @@ def pca_table(ev, mean, meanvec):
     _check(lib().fldr_pca_prepack(_dev(ev.detach().contiguous(), "EV", torch.float64), _dev(mean.detach().contiguous(), "mean", torch.float64),
                                   _dev(meanvec.detach().contiguous(), "mean_vec", torch.float64), _dev(tab, "table", torch.float64), K, _stream()),
            "fldr_pca_prepack")
-    ev._fldr_pca_table = (key, tab)
+    _prepack_done()
+    if len(_PCA_TABLES) >= 8:
+        _PCA_TABLES.clear()
+    _PCA_TABLES[key] = tab
     return tab
 
 
@@ -460,6 +467,12 @@ def zmetric(self_img, other_img, flow, alpha):
     return z
 
 
+def _prepack_done():
+    """A packed weight / table is cached and may next be consumed from a DIFFERENT stream (several pairs in flight):
+    wait for the one-time prepack kernels here rather than racing on first use."""
+    torch.cuda.current_stream().synchronize()
+
+
 def conv_prepack(weight):
     """Repack an nn.Conv2d weight for fldr_conv2d.  The packed copy is cached ON the tensor object (an
     allocator may hand the same address to a different weight, so the address alone is not a key)."""
@@ -474,6 +487,7 @@ def conv_prepack(weight):
     w = weight.detach().contiguous()
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
     _check(lib().fldr_conv_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, k, _stream()), "fldr_conv_prepack")
+    _prepack_done()
     weight._fldr_pack = ((weight._version, weight.data_ptr()), wp)
     return wp
 
@@ -517,6 +531,7 @@ def conv_split_prepack(weight):
     w = weight.detach().contiguous()
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
     _check(lib().fldr_conv_split_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, _stream()), "fldr_conv_split_prepack")
+    _prepack_done()
     weight._fldr_pack_split = ((weight._version, weight.data_ptr()), wp)
     return wp
 
@@ -532,6 +547,7 @@ def conv_s2_prepack(weight):
     w = weight.detach().contiguous()
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
     _check(lib().fldr_conv_s2_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, _stream()), "fldr_conv_s2_prepack")
+    _prepack_done()
     weight._fldr_pack_s2 = ((weight._version, weight.data_ptr()), wp)
     return wp
 
@@ -682,6 +698,7 @@ def conv_spk_prepack(weight):
     w = weight.detach().contiguous()
     wp = torch.empty(n, device=weight.device, dtype=torch.float32)
     _check(lib().fldr_conv_spk_prepack(_dev(w, "weight"), _dev(wp, "wpack"), cout, cin, _stream()), "fldr_conv_spk_prepack")
+    _prepack_done()
     weight._fldr_pack_spk = ((weight._version, weight.data_ptr()), wp)
     return wp
 
@@ -765,6 +782,7 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
     if hit is None or hit[0] != (weight._version, weight.data_ptr()):
         weff = torch.empty(1536, device=weight.device, dtype=torch.float32)
         _check(lib().fldr_dec3_prepack(_dev(weight.detach().contiguous(), "weight"), _dev(weff, "weff"), _stream()), "fldr_dec3_prepack")
+        _prepack_done()
         weight._fldr_dec3 = hit = ((weight._version, weight.data_ptr()), weff)
     weff = hit[1]
     d2 = d2.contiguous()

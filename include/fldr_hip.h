@@ -238,6 +238,7 @@ int64_t fldr_conv_s2_prepack_size(int cout, int cin);
 int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 int fldr_debug_s2_persistent(int v);                                /* tuning hook: 1 (default) persistent-workgroup kernel where the weights fit, 0 per-tile kernel; < 0 query */
+int fldr_debug_s2_xshift(int v);                                  /* tuning hook: left shift (output columns) of the persistent stride-2 kernel's tile grid; -1 (default): 15 on wide images */
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.
  * A logical [N,C,H,W] fp32 tensor is stored as [N][G=ceil(C/8)][hi,lo][H*W][8 x fp16] (x = hi + lo, 22 significant

@@ -230,7 +230,7 @@ def test_stride2_split_conv_is_fp32_equivalent(hip, dev, shape):
 
 
 @pytest.mark.parametrize("shape", [([3, 3, 2, 5], 16, 40, 72, 1), ([16], 32, 34, 70, 2), ([26], 16, 50, 38, 3), ([5], 16, 18, 66, 1),
-                                   ([4], 1, 34, 64, 1), ([1, 3], 17, 10, 66, 2), ([2, 1], 5, 130, 6, 1)])
+                                   ([4], 1, 34, 64, 1), ([1, 3], 17, 10, 66, 2), ([2, 1], 5, 130, 6, 1), ([3, 2], 16, 20, 600, 1)])
 def test_stride2_persistent_kernel_bit_identical_to_per_tile(hip, dev, shape):
     """The persistent stride-2 kernel (weights resident in LDS, inputs requested two iterations ahead) against the per-tile
     kernel it replaces for enc1 / enc2: same operand layout and MFMA order => identical fp32 and split-packed outputs;
@@ -242,13 +242,16 @@ def test_stride2_persistent_kernel_bit_identical_to_per_tile(hip, dev, shape):
     b = (torch.rand(cout, generator=g) - 0.5).to(dev)
     outs = []
     try:
-        for mode in (0, 1):
+        for mode, shift in ((0, -1), (1, -1), (1, 0), (1, 15), (1, 31)):      # per-tile kernel; persistent with the automatic / forced tile-grid shifts
             hip.lib().fldr_debug_s2_persistent(mode)
+            hip.lib().fldr_debug_s2_xshift(shift)
             o, sp = hip.conv2d(srcs, wt, b, stride=2, relu=True, precision="split", want_spk=True)
             outs.append((o.clone(), sp.buf.clone()))
     finally:
         hip.lib().fldr_debug_s2_persistent(1)
-    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        hip.lib().fldr_debug_s2_xshift(-1)
+    for k in range(1, len(outs)):
+        assert torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]), k
     # the packed twin is the split of the fp32 output, padding channels of the last group included (zeros, never
     # uninitialised memory: a later convolution multiplies them by zero weights, and NaN * 0 is NaN)
     assert torch.equal(hip.spk_pack(outs[1][0]).buf, outs[1][1])
