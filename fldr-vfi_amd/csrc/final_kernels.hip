@@ -47,11 +47,12 @@ template <typename OUT>
 __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict__ d2, const float* __restrict__ weff,
                                                          const float* __restrict__ bias, FinalArgs cd,
                                                          const float* __restrict__ tv, double T, OUT* __restrict__ out,
-                                                         float* __restrict__ refine_dbg, int H, int W) {
+                                                         float* __restrict__ refine_dbg, int H, int W, int xs) {
+    // xs: the tile grid starts xs low-resolution columns left of the image (fldr_dec3_synth_strided)
     const int h = H >> 1, w = W >> 1;
     __shared__ float tile[D3_CIN][D3_TH + 2][D3_TW + 2];
     const int tid = threadIdx.x, tx = tid % D3_TW, ty = tid / D3_TW;
-    const int i0 = blockIdx.y * D3_TH, j0 = blockIdx.x * D3_TW, n = blockIdx.z;
+    const int i0 = blockIdx.y * D3_TH, j0 = blockIdx.x * D3_TW - xs, n = blockIdx.z;
     const float* src = d2 + (int64_t)n * D3_CIN * h * w;
     constexpr int TILE_E = (D3_TH + 2) * (D3_TW + 2);
     // Staging: this thread's (up to two) slots of a channel's (TH+2) x (TW+2) tile are the same for all 16 channels, so the
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     // a partial tile; they return before using them).
     const int li = i0 + ty, lj = j0 + tx;
     const int64_t HW = (int64_t)H * W;
-    const int lic = min(li, h - 1), ljc = min(lj, w - 1);
+    const int lic = min(li, h - 1), ljc = min(max(lj, 0), w - 1);
     float2 cv[2][6][3];
     auto load_cands = [&](int a) __attribute__((always_inline)) {
         const uint32_t pob = (__umul24((uint32_t)(2 * lic + a), (uint32_t)W) + (uint32_t)(2 * ljc)) * 4u;     // byte offset inside a plane (< 4 GB, host-checked)
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) { if (a == 0) { fldr_pin(cv[0][k][ch].x); fldr_pin(cv[0][k][ch].y); } }
     load_cands(1);
-    if (li >= h || lj >= w) return;
+    if (li >= h || lj >= w || lj < 0) return;
     const float t = tv[n];
     const double w1 = (double)t, w0 = (double)(1.0f - t);
     const double inv_T = 1.0 / T;
@@ -195,6 +196,9 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     }
 }
 
+static int g_d3_xshift = -1;                     // -1: automatic (16 on wide frames); 0 .. 31: forced
+extern "C" int fldr_debug_dec3_xshift(int v) { if (v >= -1 && v < D3_TW) g_d3_xshift = v; return g_d3_xshift; }
+
 extern "C" int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream) {
     FLDR_CHECK_ARG(weight && weff);
     hipLaunchKernelGGL(dec3_prepack_kernel, dim3(fldr_cdiv(D3_CIN * 4 * D3_COUT * 4, 256)), dim3(256), 0, fldr_s(stream), weight, weff);
@@ -215,9 +219,14 @@ extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const
         FLDR_CHECK_ARG(cand[k] && (((uintptr_t)cand[k]) & 7) == 0 && (cand_bstride[k] & 1) == 0 && (cand_cstride[k] & 1) == 0);
         a.cand[k] = cand[k]; a.bstride[k] = cand_bstride[k]; a.cstride[k] = cand_cstride[k];
     }
-    dim3 grid(fldr_cdiv(W / 2, D3_TW), fldr_cdiv(H / 2, D3_TH), N);
-    if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W);
-    else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W);
+    // Tile grid shifted 16 low-resolution columns left on wide frames: a tile's 34 staged columns of dec2's output then
+    // start 15 floats into a 128-byte line and touch 2 lines per row instead of 3 ([32 t - 1, 32 t + 32]: one float each
+    // into the lines left and right; PMC at 4K: 526 MB fetched for the 141 MB of dec2's output), while the full-resolution
+    // candidate loads and the frame stores (64 t - 32 ...) stay line-aligned.  One extra half-filled tile column.
+    const int xs = g_d3_xshift >= 0 ? g_d3_xshift : (W >= 1024 ? 16 : 0);
+    dim3 grid(fldr_cdiv(W / 2 + xs, D3_TW), fldr_cdiv(H / 2, D3_TH), N);
+    if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs);
+    else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs);
     FLDR_LAUNCH_RET();
 }
 

@@ -238,7 +238,10 @@ class DCTVFInet(nn.Module):
         else:
             up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])             # :384-385
             f1 = self.conv_flow1
-            if spk:                                                    # the warped features only feed conv_flow1: split-packed
+            if spk and C // 2 <= 48 and fldr_hip.SPLAT_FEATURES == "gather":
+                # both warped feature maps in one deterministic gather launch; they only feed conv_flow1: split-packed
+                w1, w0 = fldr_hip.softsplat_gather([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax")   # :386-387
+            elif spk:
                 w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True)        # :386
                 w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True)        # :387
             else:

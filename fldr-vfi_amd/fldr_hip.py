@@ -56,6 +56,14 @@ class PcaLevel(ctypes.Structure):
                 ("P", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
+class SplatGatherDesc(ctypes.Structure):
+    _fields_ = [("img", ctypes.c_void_p * 2), ("img_bstride", ctypes.c_int64 * 2), ("flow", ctypes.c_void_p * 2),
+                ("flow_bstride", ctypes.c_int64 * 2), ("metric", ctypes.c_void_p * 2), ("out_f32", ctypes.c_void_p * 2),
+                ("out_spk", ctypes.c_void_p * 2), ("ws", ctypes.c_void_p),
+                ("ndir", ctypes.c_int32), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("mode", ctypes.c_int32)]
+
+
 class SpkConvDesc(ctypes.Structure):
     _fields_ = [
         ("src", ctypes.c_void_p * MAX_SRC),
@@ -79,6 +87,8 @@ _SIGNATURES = {
     "fldr_softsplat_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_softsplat_fused": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_fused_spk": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_softsplat_gather_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 4),
+    "fldr_softsplat_gather": (ctypes.c_int, [ctypes.POINTER(SplatGatherDesc), ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile_strided": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64] + [_c_float_p] * 4 + [ctypes.c_int] * 5
@@ -108,6 +118,7 @@ _SIGNATURES = {
     "fldr_conv2d_s2_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_debug_s2_persistent": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_s2_xshift": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_dec3_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -249,6 +260,11 @@ _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 #   "auto" (default): tile for <= 3 channels (the level-0 image splats: 360 -> 190 us each incl. memset/normalisation),
 #            strip for feature maps (the 12-channel band variant needs > 256 VGPRs and is slower).
 SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
+# Warped feature maps of the flow estimator (fLDRnet.py:386-387): "strip" (default) = the global-atomic scatter kernel +
+# normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
+# splat_gather_kernels.hip (bitwise run-to-run reproducible output frames; measured 531 us per forward: every match costs a
+# 48-load body whose latency the few waves of a feature map cannot hide).
+SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "strip")
 
 
 def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False):
@@ -291,6 +307,49 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
                                       _dev(out, "out"), _dev(scratch, "scratch"), N, C, H, W, _MODES[mode], _stream()),
            "fldr_softsplat_fused")
     return out
+
+
+def softsplat_gather(imgs, flows, metrics=None, mode="softmax", want_f32=False, want_spk=True):
+    """FunctionSoftsplat of one or two (img [N,C,H,W], flow [N,2,H,W]) problems of the same shape as a deterministic gather
+    (feature maps: C <= 48, at most 4096 tiles of 16x16).  img / flow may be batch-strided channel slices of larger tensors
+    (feat[:, 48:], up[:, :2]): each sample's [C,H,W] / [2,H,W] block must be contiguous.  -> list of fp32 tensors, list of
+    Spk tensors, or list of (fp32, Spk)."""
+    nd = len(imgs)
+    assert 1 <= nd <= 2 and len(flows) == nd
+    N, C, H, W = imgs[0].shape
+    d = SplatGatherDesc()
+    keep, outs = [], []
+    for k in range(nd):
+        im, fl = imgs[k], flows[k]
+        assert im.shape == (N, C, H, W) and fl.shape == (N, 2, H, W)
+        if not im.is_cuda:
+            raise NotImplementedError("fldr softsplat has no CPU path (the reference has none either, softSplat.py:251-252)")
+        if im.dtype != torch.float32 or fl.dtype != torch.float32:
+            raise TypeError("softsplat_gather takes float32 tensors")
+        if not im[0].is_contiguous():
+            im = im.contiguous()
+        if not fl[0].is_contiguous():
+            fl = fl.contiguous()
+        keep += [im, fl]
+        d.img[k], d.img_bstride[k] = im.data_ptr(), (im.stride(0) if N > 1 else 0)
+        d.flow[k], d.flow_bstride[k] = fl.data_ptr(), (fl.stride(0) if N > 1 else 0)
+        mt = metrics[k] if metrics is not None else None
+        if mt is not None:
+            mt = mt.contiguous()
+            assert mt.shape == (N, 1, H, W)
+            keep.append(mt)
+        d.metric[k] = mt.data_ptr() if mt is not None else None
+        o32 = torch.empty(N, C, H, W, device=im.device, dtype=torch.float32) if want_f32 else None
+        osp = _spk_alloc(N, C, H, W, im.device) if want_spk else None
+        d.out_f32[k] = o32.data_ptr() if o32 is not None else None
+        d.out_spk[k] = osp.buf.data_ptr() if osp is not None else None
+        outs.append((o32, osp) if (want_f32 and want_spk) else (osp if want_spk else o32))
+    n = lib().fldr_softsplat_gather_ws_floats(nd, N, H, W)
+    ws = torch.empty(max(int(n), 4), device=imgs[0].device, dtype=torch.float32)
+    d.ws = ws.data_ptr()
+    d.ndir, d.N, d.C, d.H, d.W, d.mode = nd, N, C, H, W, _MODES[mode]
+    _check(lib().fldr_softsplat_gather(ctypes.byref(d), _stream()), "fldr_softsplat_gather")
+    return outs
 
 
 def correlation_fwd(a, b):

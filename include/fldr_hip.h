@@ -52,6 +52,26 @@ int fldr_softsplat_fused(const float* img, const float* flow, const float* metri
                          float* out, float* scratch, int N, int C, int H, int W, int mode,
                          fldr_stream_t stream);
 
+/* FunctionSoftsplat of FEATURE MAPS as a deterministic gather (no atomics, no accumulator, no memset, no separate
+ * normalisation pass; run-to-run identical results): every destination pixel collects the sources whose bilinear footprint
+ * covers it, found through flow bounds per 16x16 source tile — exact for any flow, fast for the smooth flows of video.  Up
+ * to two (image, flow) problems of the same shape per call (the two directions of fLDRnet.py:386-387).  C <= 48; meant
+ * for maps of at most 4096 tiles of 16x16 (FLDR_E_SHAPE beyond: use fldr_softsplat_fused / _tile for frames).
+ * mode: 0 summation, 1 average, 2 linear, 3 softmax (metric may be NULL: weight 1).  ws: fldr_softsplat_gather_ws_floats. */
+typedef struct fldr_splat_gather_desc {
+    const float* img[2];        /* [N,C,H,W] fp32, channel planes contiguous */
+    int64_t      img_bstride[2];/* floats between samples */
+    const float* flow[2];       /* [N,2,H,W] */
+    int64_t      flow_bstride[2];
+    const float* metric[2];     /* [N,1,H,W] contiguous, or NULL */
+    float*       out_f32[2];    /* [N,C,H,W] or NULL */
+    void*        out_spk[2];    /* packed [N,C,H,W] (fldr_spk_bytes per sample) or NULL */
+    float*       ws;
+    int32_t      ndir, N, C, H, W, mode;
+} fldr_splat_gather_desc;
+int64_t fldr_softsplat_gather_ws_floats(int ndir, int N, int H, int W);
+int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stream);
+
 /* fldr_softsplat_fused with the result in the split-packed layout of the convolution section (fldr_spk_bytes(C,H,W) bytes
  * per sample) instead of fp32 NCHW: the warped feature maps of fLDRnet.py:386-387 are read by conv_flow1 only. */
 int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric_or_null, void* out_spk,
@@ -239,6 +259,7 @@ int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, f
 int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 int fldr_debug_s2_persistent(int v);                                /* tuning hook: 1 (default) persistent-workgroup kernel where the weights fit, 0 per-tile kernel; < 0 query */
 int fldr_debug_s2_xshift(int v);                                  /* tuning hook: left shift (output columns) of the persistent stride-2 kernel's tile grid; -1 (default): 15 on wide images */
+int fldr_debug_dec3_xshift(int v);                                /* tuning hook: left shift (low-resolution columns) of fldr_dec3_synth's tile grid; -1 (default): 16 on wide frames */
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.
  * A logical [N,C,H,W] fp32 tensor is stored as [N][G=ceil(C/8)][hi,lo][H*W][8 x fp16] (x = hi + lo, 22 significant

@@ -99,3 +99,24 @@ def test_xiph_geometry_fp16_conv_mode(hip, dev, model, xtest):
     mx, mean, p = _errs(out, refs[0.5])
     print("4096x2160 fp16-input convs: max|err| %.2e mean %.2e PSNR(8-bit vs oracle) %.1f dB" % (mx, mean, p))
     assert torch.isfinite(out).all() and p >= 65.0 and mean <= 2e-4
+
+
+def test_deterministic_mode_is_bitwise_reproducible(hip, dev, model, xtest):
+    """FLDR_SPLAT_FEATURES=gather replaces the only order-dependent kernel of the forward (the fp32-atomic feature splat:
+    SURVEY F9; two default runs differ by ~1e-5) with the deterministic gather: two forwards are bit-identical and within
+    the usual bounds of the oracle."""
+    import fldr_harness as Hn
+    m, a = model
+    frames, refs = xtest
+    prev = hip.SPLAT_FEATURES
+    try:
+        hip.SPLAT_FEATURES = "gather"
+        t = torch.tensor([[0.5]], device=dev)
+        o1 = Hn.interpolate(m, a, frames, t)
+        o2 = Hn.interpolate(m, a, frames, t)
+    finally:
+        hip.SPLAT_FEATURES = prev
+    assert torch.equal(o1, o2)
+    mx, mean, p = _errs(o1, refs[0.5])
+    print("4096x2160 deterministic mode: max|err| %.2e mean %.2e PSNR(8-bit) %.1f dB" % (mx, mean, p))
+    assert mx <= 1e-4 and mean <= 1e-6 and p >= 90.0

@@ -311,6 +311,43 @@ def test_tile_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
     _cmp(out, oracle.function_softsplat(x, flow, z, mode), atol=3e-5, rtol=1e-5, what="tile " + mode)
 
 
+@pytest.mark.parametrize("mode", ["summation", "average", "linear", "softmax"])
+@pytest.mark.parametrize("shape", [(2, 48, 33, 70, 3.0, "smooth"), (1, 48, 36, 60, 9.0, "random"), (1, 13, 40, 130, 80.0, "random"),
+                                   (1, 3, 17, 16, 600.0, "random"), (1, 48, 72, 120, 30.0, "smooth")])
+def test_gather_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
+    """fldr_softsplat_gather (deterministic gather formulation used for the warped features, fLDRnet.py:386-387) against
+    the oracle: two (image, flow) problems per call, sources as channel slices of a larger tensor, smooth flows of
+    several pixels (the video case), random flows up to far beyond the map (every tile reaches every tile), all four
+    modes with and without a metric; fp32 and split-packed outputs; bitwise run-to-run determinism."""
+    N, C, H, W, amp, kind = shape
+    g = _gen(17)
+    feat = torch.rand(N, 2 * C, H, W, generator=g) * 2 - 1
+    if kind == "smooth":
+        lo = (torch.rand(N, 4, max(H // 8, 2), max(W // 8, 2), generator=g) - 0.5) * amp + torch.tensor([amp, -amp / 2, -amp, amp / 3]).view(1, 4, 1, 1)
+        up = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+    else:
+        up = (torch.rand(N, 4, H, W, generator=g) - 0.5) * amp
+    z = None
+    if mode in ("linear", "softmax"):
+        z = [torch.randn(N, 1, H, W, generator=g) for _ in range(2)]
+        if mode == "linear":
+            z = [t.abs() + 0.1 for t in z]
+    fd, ud = feat.to(dev), up.to(dev)
+    imgs, flows = [fd[:, C:], fd[:, :C]], [ud[:, :2], ud[:, 2:]]
+    zs = None if z is None else [t.to(dev) for t in z]
+    res = hip.softsplat_gather(imgs, flows, zs, mode, want_f32=True, want_spk=True)
+    res2 = hip.softsplat_gather(imgs, flows, zs, mode, want_f32=True, want_spk=True)
+    for k in range(2):
+        ref = oracle.function_softsplat(feat[:, C:] if k == 0 else feat[:, :C], up[:, :2] if k == 0 else up[:, 2:],
+                                        None if z is None else z[k], mode)
+        _cmp(res[k][0], ref, atol=3e-5, rtol=1e-5, what="gather %s dir %d" % (mode, k))
+        assert torch.equal(res[k][0], res2[k][0]) and torch.equal(res[k][1].buf, res2[k][1].buf)      # deterministic
+        assert torch.equal(hip.spk_pack(res[k][0]).buf, res[k][1].buf)                                 # packed twin
+    if mode == "softmax" and z is not None:                      # metric None = weight 1 (the feature splats of the model)
+        one = hip.softsplat_gather(imgs[:1], flows[:1], None, mode, want_f32=True, want_spk=False)[0]
+        _cmp(one, oracle.function_softsplat(feat[:, C:], up[:, :2], None, mode), atol=3e-5, rtol=1e-5, what="gather softmax, no metric")
+
+
 def test_tile_softsplat_extreme_and_smooth_flows(hip, oracle, dev):
     """Band splat corner cases: a smooth flow field (trimmed candidate walk) with 1 % of the vectors thrown out to
     +-3e9 px (bounds far beyond int range: the block walk takes over where they occur) and a pure sub-pixel shift."""
@@ -676,6 +713,14 @@ def test_fused_dec3_synth_matches_unfused(hip, dev):
     num = sum(wk[k] * occ[:, k:k + 1] * cands[k] for k in range(6))
     den = sum(wk[k] * occ[:, k:k + 1] for k in range(6))
     _cmp(out, num / den, atol=2e-6, what="fused tail vs torch")
+    # the tile-grid shift (wide frames) only moves tile boundaries: same bits
+    try:
+        for xs in (16, 5, 31):
+            hip.lib().fldr_debug_dec3_xshift(xs)
+            o2 = hip.dec3_synth(d2.to(dev), wt.to(dev), bs.to(dev), [c.to(dev) for c in cands], t.to(dev), 1.5616)
+            assert torch.equal(o2, out), xs
+    finally:
+        hip.lib().fldr_debug_dec3_xshift(-1)
 
 
 def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):

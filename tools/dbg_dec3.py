@@ -1,22 +1,19 @@
-"""dec3_synth at the 4K shape: us per launch (LIB=path selects an experimental build)."""
+"""dec3 + softmax/T + blend at the 4K shape: tile-grid shift 0 / 16 (us per launch, rotating inputs)."""
 import os, sys, torch
-R = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.join(R, "..", "fldr-vfi_amd"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
-if os.environ.get("LIB"): hip.LIB_PATH = os.environ["LIB"]
-dev = torch.device("cuda:0")
-torch.manual_seed(0)
-H, W = 2304, 3840
-d2 = torch.randn(1, 16, H // 2, W // 2, device=dev)
-w3 = torch.randn(6, 16, 3, 3, device=dev) / 12
-b3 = torch.randn(6, device=dev)
-x = torch.rand(1, 3, 2, H, W, device=dev)
-cands = [torch.rand(1, 3, H, W, device=dev) for _ in range(4)] + [x[:, :, 0], x[:, :, 1]]
-t = torch.tensor([[0.5]], device=dev)
-def run(): return hip.dec3_synth(d2, w3, b3, cands, t, 1.56)
-for _ in range(3): o = run()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-torch.cuda.synchronize(); e0.record()
-for _ in range(20): o = run()
-e1.record(); torch.cuda.synchronize()
-print(os.environ.get("LIB", "product"), "dec3_synth %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3), "checksum %.9f" % o.double().mean().item(), flush=True)
+dev = torch.device("cuda:0"); torch.manual_seed(0); L = hip.lib()
+H, W = 2304, int(os.environ.get("FW", 3840))
+sets = [(torch.rand(1, 16, H // 2, W // 2, device=dev), [torch.rand(1, 3, H, W, device=dev) * 2 - 1 for _ in range(6)]) for _ in range(2)]
+wt = torch.randn(6, 16, 3, 3, device=dev) / 6; bs = torch.randn(6, device=dev) * 0.3; t = torch.tensor([[0.5]], device=dev)
+def timeit(fn, n=16):
+    for i in range(3): fn(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for i in range(n): fn(i)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+for xs in (0, 16, 0, 16, 8):
+    L.fldr_debug_dec3_xshift(xs)
+    print("x shift %2d: %.1f us" % (xs, timeit(lambda i: hip.dec3_synth(sets[i % 2][0], wt, bs, sets[i % 2][1], t, 1.5616))), flush=True)
+L.fldr_debug_dec3_xshift(-1)
