@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Per-kernel timings at the shapes of a 4K forward (GPU box; FLDR_LIB=<path> selects an experimental library built with
+tools/build_lib_variant.sh or tools/stamps/build_variant.sh).  One script instead of the per-kernel dbg_*.py of round 1.
+
+    python tools/kernel_bench.py conv      # fldr_conv2d_spk: barrier pipeline / ring with 8 / 4 consumer waves, per layer shape
+    python tools/kernel_bench.py s2        # stride-2 encoders: tile-grid shift 0 / 15 / 31 of the persistent kernel
+    python tools/kernel_bench.py dec3      # dec3 + softmax/T + blend: tile-grid shift 0 / 16
+    python tools/kernel_bench.py pca       # PCA of a whole pyramid: per-level one-pass kernels vs the two pyramid launches
+    python tools/kernel_bench.py band      # image band splat (bounds + band)
+    python tools/kernel_bench.py gather    # feature splats of one level: deterministic gather vs atomic scatter + finish
+"""
+import os, sys, torch, torch.nn.functional as F
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
+import fldr_hip as hip
+dev = torch.device("cuda:0"); torch.manual_seed(0); L = hip.lib()
+
+
+def timeit(fn, n=20):
+    for i in range(3): fn(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for i in range(n): fn(i)
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def conv():
+    for (cin, cout, h, w) in [(96, 96, 288, 480), (96, 96, 288, 512), (96, 96, 144, 240), (96, 96, 72, 120), (96, 96, 9, 15), (96, 48, 288, 480),
+                              (48, 48, 288, 480), (48, 16, 1152, 1920), (96, 32, 576, 960), (64, 64, 288, 480), (48, 4, 288, 480)]:
+        x = torch.rand(1, cin, h, w, device=dev); xp = hip.spk_pack(x); w2 = torch.randn(cout, cin, 3, 3, device=dev) / 30
+        t = []
+        for var in (0, 1, 2):
+            L.fldr_debug_spk_variant(min(var, 1)); L.fldr_debug_ring_consumers(8 if var == 1 else 4)
+            t.append(timeit(lambda i: hip.conv2d_spk([xp], w2, None, relu=True, want_f32=False, want_spk=True), 40))
+        print("%3d->%2d @%4dx%4d: barrier %.1f us, ring8 %.1f us, ring4 %.1f us" % (cin, cout, h, w, t[0], t[1], t[2]), flush=True)
+    L.fldr_debug_spk_variant(1); L.fldr_debug_ring_consumers(8)
+    print("ring timeouts:", L.fldr_debug_ring_timeouts())
+
+
+def s2():
+    for (cin, cout, h, w) in [(26, 16, 2304, 3840), (16, 32, 1152, 1920), (26, 16, 2304, 4096)]:
+        xs = [torch.rand(1, cin, h, w, device=dev) * 2 - 1 for _ in range(3)]      # rotated: 3 x 0.9 GB > Infinity Cache
+        wt = torch.randn(cout, cin, 4, 4, device=dev) / 20; b = torch.randn(cout, device=dev)
+        row = []
+        for sh in (0, 15, 31):
+            L.fldr_debug_s2_xshift(sh)
+            row.append("shift %2d: %.1f us" % (sh, timeit(lambda i: hip.conv2d([xs[i % 3]], wt, b, stride=2, relu=True, precision="split", want_f32=True, want_spk=True))))
+        print("%d->%d @%dx%d  " % (cin, cout, h, w) + " | ".join(row), flush=True)
+    L.fldr_debug_s2_xshift(-1)
+
+
+def dec3():
+    H, W = 2304, 3840
+    sets = [(torch.rand(1, 16, H // 2, W // 2, device=dev), [torch.rand(1, 3, H, W, device=dev) * 2 - 1 for _ in range(6)]) for _ in range(2)]
+    wt = torch.randn(6, 16, 3, 3, device=dev) / 6; bs = torch.randn(6, device=dev) * 0.3; t = torch.tensor([[0.5]], device=dev)
+    for xs in (0, 16, 0, 16):
+        L.fldr_debug_dec3_xshift(xs)
+        print("x shift %2d: %.1f us" % (xs, timeit(lambda i: hip.dec3_synth(sets[i % 2][0], wt, bs, sets[i % 2][1], t, 1.5616), 16)), flush=True)
+    L.fldr_debug_dec3_xshift(-1)
+
+
+def pca():
+    import fldr_harness as Hn
+    model, _, args = Hn.prepare_model(dev)
+    ev, mean, mv = model.EV8.detach(), model.Mean8.detach(), model.meanVec8.detach()
+    pyrs = [[(torch.rand(6, 2304 >> l, 3840 >> l, device=dev) * 2 - 1) for l in range(6)] for _ in range(3)]
+    print("pyramid, rotating inputs: per-level %.1f us, pyramid kernels %.1f us" % (
+        timeit(lambda i: [hip.pca_project_stream(p, ev, mean, mv, want_spk=True) for p in pyrs[i % 3]]),
+        timeit(lambda i: hip.pca_project_pyramid(pyrs[i % 3], ev, mean, mv, want_f32=True, want_spk=True))))
+    print("level 0 only            : per-level %.1f us, pyramid kernels %.1f us" % (
+        timeit(lambda i: hip.pca_project_stream(pyrs[i % 3][0], ev, mean, mv, want_spk=True)),
+        timeit(lambda i: hip.pca_project_pyramid(pyrs[i % 3][:1], ev, mean, mv, want_f32=True, want_spk=True))))
+
+
+def band():
+    H, W = 2304, 3840
+    sets = []
+    for k in range(3):
+        lo = (torch.rand(1, 2, H // 8, W // 8, device=dev) - 0.5) * 4 + torch.tensor([6.0, 4.0], device=dev).view(1, 2, 1, 1)
+        flow = hip.resize_bilinear(hip.resize_bilinear(lo, H // 2, W // 2), H, W)
+        sets.append((torch.rand(1, 3, H, W, device=dev) * 2 - 1, flow, torch.rand(1, 1, H, W, device=dev) * -2))
+    print("band splat (bounds + band): %.1f us" % timeit(lambda i: hip.softsplat_fused(*sets[i % 3], "softmax", kernel="tile"), 16), flush=True)
+
+
+def gather():
+    for (h, w) in [(288, 480), (144, 240), (72, 120), (18, 30)]:
+        feat = torch.rand(1, 96, h, w, device=dev) * 2 - 1
+        for amp in (1.0, 4.0):
+            lo = (torch.rand(1, 4, max(h // 8, 2), max(w // 8, 2), device=dev) - 0.5) * amp + torch.tensor([amp, -amp / 2, -amp, amp / 3], device=dev).view(1, 4, 1, 1)
+            up = F.interpolate(lo, size=(h, w), mode="bilinear", align_corners=False)
+            f1, f0 = feat[:, 48:], feat[:, :48]
+            tg = timeit(lambda i: hip.softsplat_gather([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax"))
+            ts = timeit(lambda i: (hip.softsplat_fused(f1, up[:, :2], None, "softmax", want_spk=True), hip.softsplat_fused(f0, up[:, 2:], None, "softmax", want_spk=True)))
+            print("%3dx%3d flow ~%4.1f px: gather %.1f us, scatter+finish %.1f us" % (h, w, amp, tg, ts), flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["conv", "s2", "dec3", "pca", "band", "gather"]
+    for name in which:
+        print("----", name, "(%s)" % os.environ.get("FLDR_LIB", "product library").split("/")[-1], flush=True)
+        globals()[name]()
