@@ -242,12 +242,20 @@ class DCTVFInet(nn.Module):
                 # both warped feature maps in one deterministic gather launch; they only feed conv_flow1: split-packed
                 w1, w0 = fldr_hip.softsplat_gather([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax")   # :386-387
             elif spk:
-                w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True)        # :386
-                w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True)        # :387
+                wpair = fldr_hip._spk_alloc(2, half, H, W, feat_x.device) if (B == 1 and half % 8 == 0) else None
+                w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True,
+                                              out_spk=wpair.sample(0) if wpair else None)             # :386
+                w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True,
+                                              out_spk=wpair.sample(1) if wpair else None)             # :387
             else:
                 w1 = self.softsplat(feat1, up[:, :2])                                                  # :386
                 w0 = self.softsplat(feat0, up[:, 2:])                                                  # :387
-            if spk:
+            if spk and B == 1 and half % 8 == 0 and fldr_hip.SPLAT_FEATURES != "gather":
+                # conv_flow1(cat(feat0, w1)) and conv_flow1(cat(feat1, w0)) share their weights: ONE launch over a batch of two
+                # (feat seen as its two channel halves, the warped maps written side by side above) — twice the units per launch
+                pair = fldr_hip.conv2d_spk([feat_p.channel_halves(), wpair], f1.weight, f1.bias, want_f32=False, want_spk=True)
+                ca, cb = pair.sample(0), pair.sample(1)
+            elif spk:
                 ca = fldr_hip.conv2d_spk([feat_p.narrow(0, half), w1], f1.weight, f1.bias, want_f32=False, want_spk=True)
                 cb = fldr_hip.conv2d_spk([feat_p.narrow(half, half), w0], f1.weight, f1.bias, want_f32=False, want_spk=True)
             else:

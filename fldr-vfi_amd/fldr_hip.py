@@ -267,8 +267,9 @@ SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "strip")
 
 
-def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False):
-    """FunctionSoftsplat (softSplat.py:320-352).  want_spk: return the result split-packed (Spk) instead of fp32 NCHW."""
+def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False, out_spk=None):
+    """FunctionSoftsplat (softSplat.py:320-352).  want_spk: return the result split-packed (Spk) instead of fp32 NCHW
+    (written into `out_spk`, a Spk of the same shape, when given)."""
     N, C, H, W = img.shape
     assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W
     flow = flow.contiguous()
@@ -291,10 +292,11 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
     if want_spk:
         ca = C + (0 if mode == "summation" else 1)
         scratch = torch.empty(N * ca * H * W, device=img.device, dtype=torch.float32)
-        outp = _spk_alloc(N, C, H, W, img.device)
+        outp = _spk_alloc(N, C, H, W, img.device) if out_spk is None else out_spk
+        assert outp.shape == (N, C, H, W) and (N == 1 or outp.bstride == ((C + 7) // 8) * 2 * H * W * 16)
         _check(lib().fldr_softsplat_fused_spk(_dev(img, "img"), _dev(flow, "flow"),
                                               _dev(metric, "metric") if metric is not None else None,
-                                              ctypes.c_void_p(outp.buf.data_ptr()), _dev(scratch, "scratch"), N, C, H, W,
+                                              ctypes.c_void_p(outp.ptr), _dev(scratch, "scratch"), N, C, H, W,
                                               _MODES[mode], _stream()), "fldr_softsplat_fused_spk")
         return outp
     ca = C + (0 if mode == "summation" else 1)
@@ -714,6 +716,19 @@ class Spk:
         N, C, H, W = self.shape
         assert c0 % 8 == 0 and c > 0 and c0 + c <= C and (c % 8 == 0 or c0 + c == C)
         return Spk(self.buf, (N, c, H, W), self.offset + (c0 // 8) * 2 * H * W * 16, self.bstride)
+
+    def sample(self, n):
+        """Sample n as a one-sample view."""
+        N, C, H, W = self.shape
+        assert 0 <= n < N
+        return Spk(self.buf, (1, C, H, W), self.offset + n * self.bstride, self.bstride)
+
+    def channel_halves(self):
+        """A one-sample tensor of 2c channels seen as TWO samples of c channels (sample 0 = the first half): lets the two
+        convolutions of fLDRnet.py:389 that share their weights run as one batch-of-2 launch."""
+        N, C, H, W = self.shape
+        assert N == 1 and C % 16 == 0
+        return Spk(self.buf, (2, C // 2, H, W), self.offset, (C // 16) * 2 * H * W * 16)
 
     def float(self):
         """hi + lo as an fp32 NCHW tensor (22 significant bits; tests and debugging)."""
