@@ -24,6 +24,7 @@ struct PrepArgs {
     int h, w, H, W;
     float sy, sx, mul, inv_wm1, inv_hm1, r_wm1, r_hm1, za0, za1;     // inv_*: the grid normalisation divisors max(S-1,1); r_*: their reciprocals
     int withmask;
+    int phase;                     // bit 0: z0 / z1 + flow_t0 / flow_t1; bit 1: flowback_0 / _1 + im0_tot / im1_tot (3 = everything)
 };
 
 // Uniform base pointer + 32-bit byte offset: one global_load / global_store with an SGPR base and a VGPR offset, no 64-bit
@@ -144,10 +145,13 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
     const float tv = a.t[n], omt = 1.0f - tv;
 
-    // the frames at this pixel (direct reads, issued first)
-    float c0[3], c1[3];
+    const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;        // uniform
+    // the frames at this pixel (direct reads, issued first; only the splat metrics use them)
+    float c0[3] = {0.0f, 0.0f, 0.0f}, c1[3] = {0.0f, 0.0f, 0.0f};
+    if (ph1 && a.z0) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { c0[c] = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb); }
+        for (int c = 0; c < 3; ++c) { c0[c] = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb); }
+    }
 
     // upsampled flows at this pixel (fLDRnet.py:419-422)
     const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
@@ -156,7 +160,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     const float f01x = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f), f01y = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
 
     // splat metrics (fLDRnet.py:442-446 = zmetric_kernel): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10)
-    if (a.z0) {
+    if (ph1 && a.z0) {
         const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
         const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
         const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
@@ -174,10 +178,13 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 
     // t-scaled forward flows (fLDRnet.py:404-405,419-422): upsampling of (t * flow_01_lo) and ((1-t) * flow_10_lo)
     const int64_t o2 = (int64_t)n * 2 * HW;                     // (uniform: plane bases below are scalar)
-    prep_stf(a.flow_t0 + o2, pixb, prep_up(q, 2, lx, ly, a.mul, 1, tv));
-    prep_stf(a.flow_t0 + o2 + HW, pixb, prep_up(q, 3, lx, ly, a.mul, 1, tv));
-    prep_stf(a.flow_t1 + o2, pixb, prep_up(q, 0, lx, ly, a.mul, 1, omt));
-    prep_stf(a.flow_t1 + o2 + HW, pixb, prep_up(q, 1, lx, ly, a.mul, 1, omt));
+    if (ph1) {
+        prep_stf(a.flow_t0 + o2, pixb, prep_up(q, 2, lx, ly, a.mul, 1, tv));
+        prep_stf(a.flow_t0 + o2 + HW, pixb, prep_up(q, 3, lx, ly, a.mul, 1, tv));
+        prep_stf(a.flow_t1 + o2, pixb, prep_up(q, 0, lx, ly, a.mul, 1, omt));
+        prep_stf(a.flow_t1 + o2 + HW, pixb, prep_up(q, 1, lx, ly, a.mul, 1, omt));
+    }
+    if (!ph2) return;
 
     // backward flows (fLDRnet.py:474-475 = bwarp_kernel with scales): flowback_0 = bwarp(t * flow_10, (1-t) * flow_01),
     // flowback_1 = bwarp((1-t) * flow_01, t * flow_10)
@@ -218,9 +225,11 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     a.inv_wm1 = (float)(d->W - 1 > 1 ? d->W - 1 : 1); a.inv_hm1 = (float)(d->H - 1 > 1 ? d->H - 1 : 1);
     a.r_wm1 = 1.0f / a.inv_wm1; a.r_hm1 = 1.0f / a.inv_hm1;
     a.za0 = d->z_alpha0; a.za1 = d->z_alpha1; a.withmask = d->withmask;
+    a.phase = (d->phase & 3) ? (d->phase & 3) : 3;
     const int64_t hw = (int64_t)d->h * d->w;
-    hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
-                       reinterpret_cast<float2*>(d->ws), hw);
+    if (!(d->phase & 4))                                          // bit 2: d->ws already holds the interleaved flow (second phase of a split call)
+        hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
+                           reinterpret_cast<float2*>(d->ws), hw);
     dim3 grid(fldr_cdiv(d->W, 64), fldr_cdiv(d->H, 4), d->N);
     hipLaunchKernelGGL(level0_prep_kernel, grid, dim3(256), 0, fldr_s(stream), a);
     FLDR_LAUNCH_RET();

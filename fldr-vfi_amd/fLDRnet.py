@@ -289,17 +289,20 @@ class DCTVFInet(nn.Module):
         I1 = x_l[:, :, 1]
         if inv is not None:
             z0, z1 = inv
+        split = fldr_hip.PREP_SPLIT
         r = fldr_hip.level0_prep(flow_l, I0, I1, t4, H, W, za0, za1, withmask=mask,
-                                 want_z=bool(a.impmasksoftsplat) and inv is None)
+                                 want_z=bool(a.impmasksoftsplat) and inv is None, phase=1 if split else 3)
         if inv is None:
             z0, z1 = r["z0"], r["z1"]                                                                   # :442-446
             if cache is not None:
                 cache["level0"] = (z0, z1)
         flow_t0, flow_t1 = r["flow_t0"], r["flow_t1"]                                                   # :404-405,419-422
-        flowback_0, flowback_1 = r["flowback_0"], r["flowback_1"]                                       # :474-475
-        im0_tot, im1_tot = r["im0_tot"], r["im1_tot"]                                                   # :478-479
         warped0 = self.softsplat(I0, flow_t0, z=z0)                                                    # :449
         warped1 = self.softsplat(I1, flow_t1, z=z1)                                                    # :450
+        if split:                     # the second half of the prep kernel, right in front of its consumer (enc1)
+            fldr_hip.level0_prep(None, None, None, None, H, W, za0, za1, state=r)
+        flowback_0, flowback_1 = r["flowback_0"], r["flowback_1"]                                       # :474-475
+        im0_tot, im1_tot = r["im0_tot"], r["im1_tot"]                                                   # :478-479
         srcs = [I0, I1, warped0, warped1, flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot]  # :480 (no cat)
         cands = [warped0, warped1, im0_tot, im1_tot, I0, I1]
         unet = self.refine_unet

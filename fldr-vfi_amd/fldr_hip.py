@@ -48,6 +48,7 @@ class PrepDesc(ctypes.Structure):
         ("mul", ctypes.c_float), ("z_alpha0", ctypes.c_float), ("z_alpha1", ctypes.c_float), ("withmask", ctypes.c_int32),
         ("ws", ctypes.c_void_p),
         ("i0_cstride", ctypes.c_int64), ("i1_cstride", ctypes.c_int64),
+        ("phase", ctypes.c_int32), ("reserved", ctypes.c_int32),
     ]
 
 
@@ -265,6 +266,10 @@ SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 # splat_gather_kernels.hip (bitwise run-to-run reproducible output frames; measured 531 us per forward: every match costs a
 # 48-load body whose latency the few waves of a feature map cannot hide).
 SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "strip")
+# Level-0 prep kernel in one launch (0, default) or in two around the image splats (1: enc1 then reads flowback_* / im*_tot
+# right behind their producer; measured 408 vs 419 pairs/s: the second launch's repeated flow evaluation costs more than the
+# Infinity-Cache hits give)
+PREP_SPLIT = os.environ.get("FLDR_PREP_SPLIT", "0") == "1"
 
 
 def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False, out_spk=None):
@@ -489,10 +494,18 @@ def resize_bilinear(x, H, W, mul=1.0):
     return out
 
 
-def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True):
+def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True, phase=3, state=None):
     """fLDRnet.py:400-479 minus the splats in one kernel.  flow_lo [N,4,h,w]; I0 / I1 [N,3,H,W] (batch-strided views of
     the [N,3,2,H,W] level-0 tensor, e.g. x[:, :, 0], are read in place: batch and channel strides are passed down).
-    -> dict(z0, z1 (None unless want_z), flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot)."""
+    -> dict(z0, z1 (None unless want_z), flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot).
+    phase=1 only fills z0 / z1 / flow_t0 / flow_t1 (what the splats need); a second call with phase=2 and state=<the dict
+    returned by the first> fills flowback_* / im*_tot: the model runs the splats in between, so that enc1 reads those planes
+    right behind their producer (Infinity-Cache resident) instead of after 1.3 GB of splat traffic."""
+    if state is not None:
+        d, out = state["_desc"], state
+        d.phase = 2 | 4
+        _check(lib().fldr_level0_prep(ctypes.byref(d), _stream()), "fldr_level0_prep")
+        return out
     N, four, h, w = flow_lo.shape
     assert four == 4 and I0.shape == (N, 3, H, W) and I1.shape == (N, 3, H, W)
     flow_lo = flow_lo.contiguous()
@@ -514,8 +527,10 @@ def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True):
     d.mul, d.z_alpha0, d.z_alpha1, d.withmask = float(H / h), float(za0), float(za1), int(bool(withmask))
     ws = torch.empty(N * h * w * 4, device=dev, dtype=torch.float32)
     d.ws = ws.data_ptr()
+    d.phase = phase
     _check(lib().fldr_level0_prep(ctypes.byref(d), _stream()), "fldr_level0_prep")
-    out["_keep"] = (I0, I1, t, ws)
+    out["_keep"] = (I0, I1, t, ws, flow_lo)
+    out["_desc"] = d
     return out
 
 

@@ -200,6 +200,10 @@ typedef struct fldr_prep_desc {
     int32_t withmask;                /* not args.outMaskLess */
     float* ws;                       /* workspace: N*h*w*4 floats (the low-resolution flow, channel-interleaved), 16-B aligned */
     int64_t i0_cstride, i1_cstride;  /* floats between the channel planes of I0 / I1; 0 = H*W (contiguous [3,H,W]) */
+    int32_t phase;                   /* 0 or 3: everything in one launch; 1: only z0 / z1 + flow_t0 / flow_t1 (what the splats need);
+                                        2 | 4 = 6: only flowback_* + im*_tot, reusing the workspace filled by a phase-1 call — so that
+                                        the consumer of those planes (enc1) can run right behind their producer */
+    int32_t reserved;
 } fldr_prep_desc;
 int fldr_level0_prep(const fldr_prep_desc* desc, fldr_stream_t stream);
 
