@@ -206,6 +206,9 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             if (free_target) ring_wait_ge(ctr + 16 + 4 * st, free_target, lane);
             RSTAMP(l2)
             unsigned char* stage = smem + st * Cfg::STAGE;
+#if defined(RING_ABLATE) && RING_ABLATE == 3                          // diagnostic: no DMA traffic after the prologue fills
+            if (k >= RING_SLOTS) { wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR); for (int i = 0; i < RING_NXI; ++i) dptr[i] = zero_blk; }
+#endif
 #pragma unroll
             for (int i = 0; i < Cfg::NWL; ++i)
                 __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_voff[i]), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
@@ -432,12 +435,21 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
         };
         constexpr int N_MFMA = NQ * TERMS * NMT, N_DS = TERMS > 1 ? 2 * NQ + 2 * NMT : NQ + NMT;
+#ifdef RING_NTAIL
+        constexpr int N_TAIL = N_MFMA >= 12 ? RING_NTAIL : (N_MFMA >= 6 ? 2 : 0);
+#else
         constexpr int N_TAIL = N_MFMA >= 12 ? 4 : (N_MFMA >= 6 ? 2 : 0);
+#endif
         ld(0, 0);
         __builtin_amdgcn_sched_barrier(0);                               // keep step 0's reads out of the interleave pattern below
 #pragma unroll
         for (int s = 0; s < SPK_STEPS; ++s) {
+#if defined(RING_ABLATE) && RING_ABLATE == 1                          // diagnostic: operands read once per iteration
+            if (s + 1 < SPK_STEPS) { for (int q = 0; q < NQ; ++q) { bh[(s + 1) & 1][q] = bh[s & 1][q]; bl[(s + 1) & 1][q] = bl[s & 1][q]; }
+                                    for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; al[(s + 1) & 1][m] = al[s & 1][m]; } }
+#else
             if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);               // lands while this step's MFMAs run
+#endif
 #if RING_EARLY_FREE
             if (s + 2 == SPK_STEPS) { if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(ctr + 16 + 4 * st_cur), "v"(1u) : "memory"); }
 #endif
@@ -449,7 +461,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     for (int q = 0; q < NQ; ++q) {
                         const h8 av = term == 2 ? al[s & 1][m] : ah[s & 1][m];
                         const h8 bv = term == 1 ? bl[s & 1][q] : bh[s & 1][q];
+#if defined(RING_ABLATE) && RING_ABLATE == 2                          // diagnostic: no MFMAs
+                        asm volatile("" :: "v"(av), "v"(bv));
+#else
                         acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][q], 0, 0, 0);
+#endif
                     }
             // spread the next step's LDS reads evenly between this step's MFMAs
             spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);

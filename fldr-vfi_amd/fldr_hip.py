@@ -166,6 +166,10 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        for env, hook in (("FLDR_RING_CONSUMERS", "fldr_debug_ring_consumers"), ("FLDR_SPK_VARIANT", "fldr_debug_spk_variant"),
+                          ("FLDR_PCA_WORKGROUPS", "fldr_debug_pca_workgroups")):       # tuning hooks from the environment (A/B runs)
+            if os.environ.get(env):
+                getattr(l, hook)(int(os.environ[env]))
         _lib = l
     return _lib
 
