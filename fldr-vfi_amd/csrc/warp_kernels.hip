@@ -303,6 +303,34 @@ extern "C" int fldr_softsplat_fused_spk(const float* img, const float* flow, con
     FLDR_LAUNCH_RET();
 }
 
+// The two feature splats of a pyramid level (fLDRnet.py:386-387: feat1 by flow_10, feat0 by flow_01; one sample each) with
+// ONE memset and ONE normalisation launch: scratch holds both accumulators back to back, out_spk both packed results as a
+// batch of two (sample 0 = the first problem) — what the batched conv_flow1 launch consumes.  Same kernels, same results as two
+// fldr_softsplat_fused_spk calls; 4 launches instead of 6.
+extern "C" int fldr_softsplat_pair_spk(const float* img_a, const float* flow_a, const float* img_b, const float* flow_b,
+                                       void* out_spk, float* scratch, int C, int H, int W, int mode, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(img_a && flow_a && img_b && flow_b && out_spk && scratch && C > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 3 && mode != 2);
+    const int64_t HW = (int64_t)H * W;
+    const int CA = mode >= 1 ? C + 1 : C;
+    hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)2 * CA * HW, fldr_s(stream));
+    if (e != hipSuccess) return (int)e;
+    for (int k = 0; k < 2; ++k) {
+        const float* img = k ? img_b : img_a;
+        const float* flow = k ? flow_b : flow_a;
+        float* acc = scratch + (int64_t)k * CA * HW;
+        switch (mode) {
+            case 0: splat_launch<0>(img, flow, nullptr, acc, 1, C, H, W, fldr_s(stream)); break;
+            case 1: splat_launch<1>(img, flow, nullptr, acc, 1, C, H, W, fldr_s(stream)); break;
+            default: splat_launch<3>(img, flow, nullptr, acc, 1, C, H, W, fldr_s(stream)); break;
+        }
+    }
+    dim3 g2(fldr_cdiv(HW, 256), (C + 7) / 8, 2);
+    unsigned char* o = reinterpret_cast<unsigned char*>(out_spk);
+    if (mode == 0) hipLaunchKernelGGL(splat_finish_spk_kernel<false>, g2, dim3(256), 0, fldr_s(stream), scratch, o, C, HW);
+    else           hipLaunchKernelGGL(splat_finish_spk_kernel<true>, g2, dim3(256), 0, fldr_s(stream), scratch, o, C, HW);
+    FLDR_LAUNCH_RET();
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward warp (fLDRnet.py:546-581) and the splat metric built on it (fLDRnet.py:442-446)
 // ------------------------------------------------------------------------------------------------
@@ -422,6 +450,53 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
     float top = wx0 * p[(int64_t)y0 * w + x0] + lx * p[(int64_t)y0 * w + x1];
     float bot = wx0 * p[(int64_t)y1 * w + x0] + lx * p[(int64_t)y1 * w + x1];
     out[((int64_t)c * H + Y) * W + X] = (wy0 * top + ly * bot) * mul;
+}
+
+// The same resize for a tensor of C <= 8 channels that also emits its split-packed twin (one group): the upsampled flow of
+// fLDRnet.py:384-385 is consumed as fp32 (splats, residual) AND as the third packed source of conv_flow2.0.
+__global__ __launch_bounds__(256) void resize_bilinear_spk_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                  unsigned char* __restrict__ spk, int C, int h, int w,
+                                                                  int H, int W, float sy, float sx, float mul) {
+#pragma clang fp contract(off)
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (X >= W || Y >= H) return;
+    int x0, x1, y0, y1; float lx, ly;
+    fldr_lin_src(X, sx, w, x0, x1, lx);
+    fldr_lin_src(Y, sy, h, y0, y1, ly);
+    const float wx0 = 1.0f - lx, wy0 = 1.0f - ly;
+    const int64_t HW = (int64_t)H * W, pix = (int64_t)Y * W + X;
+    h8 hi, lo;
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        float v = 0.0f;
+        if (c < C) {
+            const float* p = in + ((int64_t)n * C + c) * h * w;
+            const float top = wx0 * p[(int64_t)y0 * w + x0] + lx * p[(int64_t)y0 * w + x1];
+            const float bot = wx0 * p[(int64_t)y1 * w + x0] + lx * p[(int64_t)y1 * w + x1];
+            v = (wy0 * top + ly * bot) * mul;
+            out[((int64_t)n * C + c) * HW + pix] = v;
+        }
+        _Float16 h_, l_;
+        fldr_split_hl(v, h_, l_, bad);
+        hi[c] = h_; lo[c] = l_;
+    }
+    fldr_note_range(bad);
+    unsigned char* d = spk + ((int64_t)n * 2 * HW + pix) * 16;
+    *reinterpret_cast<h8*>(d) = hi;
+    *reinterpret_cast<h8*>(d + HW * 16) = lo;
+}
+
+extern "C" int fldr_resize_bilinear_spk(const float* in, float* out, void* out_spk, int N, int C, int h, int w, int H, int W,
+                                        float mul, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(in && out && out_spk && N > 0 && C > 0 && C <= 8 && h > 0 && w > 0 && H > 0 && W > 0);
+    dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4), N);
+    hipLaunchKernelGGL(resize_bilinear_spk_kernel, grid, dim3(256), 0, fldr_s(stream), in, out, reinterpret_cast<unsigned char*>(out_spk),
+                       C, h, w, H, W, (float)h / (float)H, (float)w / (float)W, mul);
+    FLDR_LAUNCH_RET();
 }
 
 extern "C" int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int H, int W, float mul,

@@ -236,17 +236,22 @@ class DCTVFInet(nn.Module):
         if flow_l_prev is None:
             flow_l = self._chain([feat_p if spk else feat_x], self.conv_flow_bottom, (0, 2, 4, 6, 8), final_store=4)   # :379-380
         else:
-            up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])             # :384-385
+            up_p = None
+            if spk:       # the upsampled flow is consumed as fp32 (splats, residual) and packed (conv_flow2.0): one kernel writes both
+                up, up_p = fldr_hip.resize_bilinear_spk(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])   # :384-385
+            else:
+                up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])         # :384-385
             f1 = self.conv_flow1
             if spk and C // 2 <= 48 and fldr_hip.SPLAT_FEATURES == "gather":
                 # both warped feature maps in one deterministic gather launch; they only feed conv_flow1: split-packed
                 w1, w0 = fldr_hip.softsplat_gather([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax")   # :386-387
+            elif spk and B == 1 and half % 8 == 0:
+                wpair = fldr_hip.softsplat_pair_spk(feat1, up[:, :2], feat0, up[:, 2:], "softmax")     # :386-387, one memset / finish
+                w1, w0 = wpair.sample(0), wpair.sample(1)
             elif spk:
-                wpair = fldr_hip._spk_alloc(2, half, H, W, feat_x.device) if (B == 1 and half % 8 == 0) else None
-                w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True,
-                                              out_spk=wpair.sample(0) if wpair else None)             # :386
-                w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True,
-                                              out_spk=wpair.sample(1) if wpair else None)             # :387
+                wpair = None
+                w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True)        # :386
+                w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True)        # :387
             else:
                 w1 = self.softsplat(feat1, up[:, :2])                                                  # :386
                 w0 = self.softsplat(feat0, up[:, 2:])                                                  # :387
@@ -261,7 +266,7 @@ class DCTVFInet(nn.Module):
             else:
                 ca = fldr_hip.conv2d([feat0, w1], f1.weight, f1.bias)
                 cb = fldr_hip.conv2d([feat1, w0], f1.weight, f1.bias)
-            flow_l = self._chain([ca, cb, up], self.conv_flow2, (0, 2, 4, 6, 8), final_residual=up)    # :389-391
+            flow_l = self._chain([ca, cb, up_p if up_p is not None else up], self.conv_flow2, (0, 2, 4, 6, 8), final_residual=up)    # :389-391
         return flow_l
 
     # ---- level 0 (fLDRnet.py:400-535) ------------------------------------------------------------

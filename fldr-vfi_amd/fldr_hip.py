@@ -88,6 +88,8 @@ _SIGNATURES = {
     "fldr_softsplat_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_softsplat_fused": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_fused_spk": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
+    "fldr_softsplat_pair_spk": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_resize_bilinear_spk": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_void_p]),
     "fldr_softsplat_gather_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 4),
     "fldr_softsplat_gather": (ctypes.c_int, [ctypes.POINTER(SplatGatherDesc), ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
@@ -363,6 +365,20 @@ def softsplat_gather(imgs, flows, metrics=None, mode="softmax", want_f32=False, 
     return outs
 
 
+def softsplat_pair_spk(img_a, flow_a, img_b, flow_b, mode="softmax"):
+    """The two feature splats of a level (one sample each, no metric) -> ONE packed batch of two (sample 0 = problem a); one
+    memset + one normalisation launch for both (fldr_softsplat_pair_spk)."""
+    N, C, H, W = img_a.shape
+    assert N == 1 and img_b.shape == img_a.shape and flow_a.shape == (1, 2, H, W) and flow_b.shape == (1, 2, H, W)
+    ia, ib, fa, fb = img_a.contiguous(), img_b.contiguous(), flow_a.contiguous(), flow_b.contiguous()
+    ca = C + (0 if mode == "summation" else 1)
+    scratch = torch.empty(2 * ca * H * W, device=ia.device, dtype=torch.float32)
+    out = _spk_alloc(2, C, H, W, ia.device)
+    _check(lib().fldr_softsplat_pair_spk(_dev(ia, "img"), _dev(fa, "flow"), _dev(ib, "img"), _dev(fb, "flow"), ctypes.c_void_p(out.ptr),
+                                         _dev(scratch, "scratch"), C, H, W, _MODES[mode], _stream()), "fldr_softsplat_pair_spk")
+    return out
+
+
 def correlation_fwd(a, b):
     N, C, H, W = a.shape
     assert b.shape == a.shape
@@ -496,6 +512,18 @@ def resize_bilinear(x, H, W, mul=1.0):
     _check(lib().fldr_resize_bilinear(_dev(x, "in"), _dev(out, "out"), N * C, h, w, H, W, float(mul), _stream()),
            "fldr_resize_bilinear")
     return out
+
+
+def resize_bilinear_spk(x, H, W, mul=1.0):
+    """resize_bilinear for C <= 8 channels that also returns the split-packed twin: -> (fp32 [N,C,H,W], Spk)."""
+    N, C, h, w = x.shape
+    assert C <= 8
+    x = x.contiguous()
+    out = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
+    sp = _spk_alloc(N, C, H, W, x.device)
+    _check(lib().fldr_resize_bilinear_spk(_dev(x, "in"), _dev(out, "out"), ctypes.c_void_p(sp.ptr), N, C, h, w, H, W, float(mul), _stream()),
+           "fldr_resize_bilinear_spk")
+    return out, sp
 
 
 def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True, phase=3, state=None):

@@ -52,6 +52,12 @@ int fldr_softsplat_fused(const float* img, const float* flow, const float* metri
                          float* out, float* scratch, int N, int C, int H, int W, int mode,
                          fldr_stream_t stream);
 
+/* The two feature splats of a pyramid level (fLDRnet.py:386-387; one sample each, no metric; mode 0, 1 or 3) with one memset
+ * and one normalisation launch: scratch = 2 * (C + 1) * H * W floats, out_spk = packed batch of two (sample 0 = problem a).
+ * Identical results to two fldr_softsplat_fused_spk calls. */
+int fldr_softsplat_pair_spk(const float* img_a, const float* flow_a, const float* img_b, const float* flow_b, void* out_spk,
+                            float* scratch, int C, int H, int W, int mode, fldr_stream_t stream);
+
 /* FunctionSoftsplat of FEATURE MAPS as a deterministic gather (no atomics, no accumulator, no memset, no separate
  * normalisation pass; run-to-run identical results): every destination pixel collects the sources whose bilinear footprint
  * covers it, found through flow bounds per 16x16 source tile — exact for any flow, fast for the smooth flows of video.  Up
@@ -173,6 +179,9 @@ int fldr_bwarp_tscaled(const float* x, const float* flo, float* out, const float
 
 /* F.interpolate(mode='bilinear', align_corners=False) from [NC,h,w] to [NC,H,W], result multiplied
  * by `mul` (fLDRnet.py:384-385 with mul = W/w; :419-422 with mul = upscale). */
+/* fldr_resize_bilinear for [N,C,h,w] with C <= 8 that also writes the split-packed twin of the result (one group). */
+int fldr_resize_bilinear_spk(const float* in, float* out, void* out_spk, int N, int C, int h, int w, int H, int W, float mul,
+                             fldr_stream_t stream);
 int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int H, int W, float mul,
                          fldr_stream_t stream);
 
