@@ -114,6 +114,45 @@ __global__ __launch_bounds__(256) void splat_bounds_kernel(const float* __restri
     }
 }
 
+// The same table for a flow that is the bilinear upsampling of a low-resolution field — flow = up(scale * lo) * mul, what
+// fldr_level0_prep writes as flow_t0 / flow_t1 (fLDRnet.py:404-405,419-422) — computed from the low-resolution field alone:
+// bilinear weights are a convex combination, so every value of a 64x4 block lies between the extremes of the low-resolution
+// pixels its rows and columns interpolate between (fldr_lin_src is monotone: the footprint is the index range of the block's
+// first and last pixel), widened by 2e-6 of the magnitude for the roundings of the three interpolation steps.  The bounds
+// only select candidate sources (st_match / the trimmed walk): a superset is exact.  One wave per super-block, lane = block;
+// 2 MB read instead of the two full-resolution flow planes (4K: 23 -> 3 us).
+__global__ __launch_bounds__(64) void splat_bounds_up_kernel(const float* __restrict__ lo, int64_t lo_bstride, const float* __restrict__ tv,
+                                                             int smode, float mul, float* __restrict__ blk, float* __restrict__ sbt,
+                                                             int h, int w, int H, int W, float sy, float sx, int nsb_x, int nsb) {
+#pragma clang fp contract(off)
+    const int sb = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+    const int X0 = ((sb % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
+    const float INF = __builtin_inff();
+    float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
+    if (X0 < W && Y0 < H) {
+        const float scale = smode == 0 ? 1.0f : (smode == 1 ? tv[n] : 1.0f - tv[n]);
+        int c0, c1, r0, r1, d0, d1; float l;
+        fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
+        fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
+        const float* px = lo + (int64_t)n * lo_bstride;
+        const float* py = px + (int64_t)h * w;
+        for (int r = r0; r <= r1; ++r)
+            for (int c = c0; c <= c1; ++c) {
+                const float vx = (scale * px[(int64_t)r * w + c]) * mul, vy = (scale * py[(int64_t)r * w + c]) * mul;
+                xmin = fminf(xmin, vx); xmax = fmaxf(xmax, vx); ymin = fminf(ymin, vy); ymax = fmaxf(ymax, vy);
+            }
+        const float ex = fmaxf(fabsf(xmin), fabsf(xmax)) * 2.0e-6f, ey = fmaxf(fabsf(ymin), fabsf(ymax)) * 2.0e-6f;
+        xmin -= ex; xmax += ex; ymin -= ey; ymax += ey;
+    }
+    *reinterpret_cast<float4*>(blk + (((int64_t)n * nsb + sb) * ST_SB_BLOCKS + lane) * 4) = make_float4(xmin, xmax, ymin, ymax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    }
+    if (lane == 0) *reinterpret_cast<float4*>(sbt + ((int64_t)n * nsb + sb) * 4) = make_float4(xmin, xmax, ymin, ymax);
+}
+
 // Can a source region [rx0, rx1] x [ry0, ry1] (inclusive pixel coordinates) with flow bounds b touch the tile?
 // Target corner columns of a source: floor(x + fx) and floor(x + fx) + 1.  Conservative by one cell.
 __device__ __forceinline__ bool st_match(const float4 b, float rx0, float rx1, float ry0, float ry1, float tx0, float tx1,
@@ -713,9 +752,10 @@ extern "C" int fldr_softsplat_tile(const float* img, const float* flow, const fl
 }
 
 // img: sample n, channel c at img + n*img_bstride + c*img_cstride (floats), each [H,W] plane contiguous.
-extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
-                                           const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
-                                           fldr_stream_t stream) {
+// mode_flags bit 0: ws already holds the bounds table (fldr_splat_bounds_upsampled)
+static int splat_tile_run(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                          const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode, int mode_flags,
+                          fldr_stream_t stream) {
     FLDR_CHECK_ARG(img && flow && out && ws && N > 0 && C > 0 && H > 0 && W > 0 && mode >= 0 && mode <= 3);
     FLDR_CHECK_ARG(mode != 2 || metric != nullptr);
     if (W > 65535 * ST_BW || H > 32767 * ST_BH) return FLDR_E_SHAPE;
@@ -724,7 +764,7 @@ extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride
     float* blk = ws;
     float* sbt = ws + (int64_t)N * nsb * ST_SB_BLOCKS * 4;
     hipStream_t s = fldr_s(stream);
-    hipLaunchKernelGGL(splat_bounds_kernel, dim3(nsb, N), dim3(256), 0, s, flow, blk, sbt, H, W, nsb_x, nsb);
+    if (!(mode_flags & 1)) hipLaunchKernelGGL(splat_bounds_kernel, dim3(nsb, N), dim3(256), 0, s, flow, blk, sbt, H, W, nsb_x, nsb);
     if (g_splat_tile_variant == 1) {
         switch (mode) {
             case 0: splat_band_launch<0>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
@@ -741,4 +781,35 @@ extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride
         default: splat_tile_launch<3>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
     }
     FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                           const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                           fldr_stream_t stream) {
+    return splat_tile_run(img, img_bstride, img_cstride, flow, metric, out, ws, N, C, H, W, mode, 0, stream);
+}
+
+// The bounds table of `ws` for flow = F.interpolate(scale * flow_lo, (H, W), bilinear) * mul, from flow_lo alone (conservative:
+// see splat_bounds_up_kernel).  flow_lo: sample n at flow_lo + n*lo_bstride, [2,h,w] contiguous; scale_mode 0: 1, 1: t[n],
+// 2: 1 - t[n] (t may be null for mode 0).
+extern "C" int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstride, const float* t, int scale_mode, float mul,
+                                           float* ws, int N, int h, int w, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(flow_lo && ws && N > 0 && h > 0 && w > 0 && H >= h && W >= w && scale_mode >= 0 && scale_mode <= 2 && mul > 0.0f);
+    FLDR_CHECK_ARG(scale_mode == 0 || t != nullptr);
+    if (W > 65535 * ST_BW || H > 32767 * ST_BH) return FLDR_E_SHAPE;
+    if ((int64_t)fldr_cdiv(W, ST_SBX * ST_BW) * fldr_cdiv(H, ST_SBY * ST_BH) > 65535) return FLDR_E_SHAPE;
+    const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
+    float* blk = ws;
+    float* sbt = ws + (int64_t)N * nsb * ST_SB_BLOCKS * 4;
+    hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, N), dim3(64), 0, fldr_s(stream), flow_lo, lo_bstride, t, scale_mode, mul, blk, sbt,
+                       h, w, H, W, (float)h / (float)H, (float)w / (float)W, nsb_x, nsb);
+    FLDR_LAUNCH_RET();
+}
+
+// fldr_softsplat_tile_strided with the bounds table already in `ws` (any table whose block / super-block intervals CONTAIN the
+// flow values of their pixels gives the exact result: the table only selects candidate sources).
+extern "C" int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                              const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                              fldr_stream_t stream) {
+    return splat_tile_run(img, img_bstride, img_cstride, flow, metric, out, ws, N, C, H, W, mode, 1, stream);
 }

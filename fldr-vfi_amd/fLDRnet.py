@@ -302,8 +302,15 @@ class DCTVFInet(nn.Module):
             if cache is not None:
                 cache["level0"] = (z0, z1)
         flow_t0, flow_t1 = r["flow_t0"], r["flow_t1"]                                                   # :404-405,419-422
-        warped0 = self.softsplat(I0, flow_t0, z=z0)                                                    # :449
-        warped1 = self.softsplat(I1, flow_t1, z=z1)                                                    # :450
+        if fldr_hip.SPLAT_BOUNDS == "lowres" and fldr_hip.SPLAT_KERNEL in ("auto", "tile"):
+            # candidate-source bounds of the two splats from the low-resolution flow their flow_t is the upsampling of
+            b0 = fldr_hip.splat_bounds_upsampled(flow_01_lo, t4, 1, up, H, W)
+            b1 = fldr_hip.splat_bounds_upsampled(flow_10_lo, t4, 2, up, H, W)
+            warped0 = fldr_hip.softsplat_fused(I0, flow_t0, z0, self.softsplat.strType, bounds_ws=b0)   # :449
+            warped1 = fldr_hip.softsplat_fused(I1, flow_t1, z1, self.softsplat.strType, bounds_ws=b1)   # :450
+        else:
+            warped0 = self.softsplat(I0, flow_t0, z=z0)                                                # :449
+            warped1 = self.softsplat(I1, flow_t1, z=z1)                                                # :450
         if split:                     # the second half of the prep kernel, right in front of its consumer (enc1)
             fldr_hip.level0_prep(None, None, None, None, H, W, za0, za1, state=r)
         flowback_0, flowback_1 = r["flowback_0"], r["flowback_1"]                                       # :474-475

@@ -96,6 +96,10 @@ _SIGNATURES = {
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile_strided": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64] + [_c_float_p] * 4 + [ctypes.c_int] * 5
                                     + [ctypes.c_void_p]),
+    "fldr_softsplat_tile_prebounded": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64] + [_c_float_p] * 4 + [ctypes.c_int] * 5
+                                       + [ctypes.c_void_p]),
+    "fldr_splat_bounds_upsampled": (ctypes.c_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int, ctypes.c_float, _c_float_p]
+                                    + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_softsplat_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -278,9 +282,30 @@ SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "strip")
 PREP_SPLIT = os.environ.get("FLDR_PREP_SPLIT", "0") == "1"
 
 
-def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False, out_spk=None):
+# Bounds table of the level-0 image splats: "lowres" (default) = from the low-resolution flow the upsampled flow_t is made of
+# (fldr_splat_bounds_upsampled: conservative intervals, 3 us instead of a 23 us pass over the full-resolution planes);
+# "exact" = the pre-pass over the full-resolution flow.  Same results up to fp32 summation order.
+SPLAT_BOUNDS = os.environ.get("FLDR_SPLAT_BOUNDS", "lowres")
+
+
+def splat_bounds_upsampled(flow_lo, t, scale_mode, mul, H, W):
+    """Bounds workspace for softsplat_fused(..., bounds_ws=...) of flow = interpolate(scale * flow_lo, (H, W)) * mul.
+    flow_lo [N,2,h,w] (may be a channel slice of the [N,4,h,w] level flow); scale_mode 0: 1, 1: t[n], 2: 1 - t[n]."""
+    N, two, h, w = flow_lo.shape
+    assert two == 2 and flow_lo.stride(3) == 1 and flow_lo.stride(2) == w and flow_lo.stride(1) == h * w
+    ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=flow_lo.device, dtype=torch.float32)
+    if t is not None:
+        t = t.reshape(N).contiguous().float()
+    _check(lib().fldr_splat_bounds_upsampled(ctypes.c_void_p(flow_lo.data_ptr()), flow_lo.stride(0) if N > 1 else 2 * h * w,
+                                             _dev(t, "t") if t is not None else None, int(scale_mode), float(mul), _dev(ws, "ws"),
+                                             N, h, w, H, W, _stream()), "fldr_splat_bounds_upsampled")
+    return ws
+
+
+def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False, out_spk=None, bounds_ws=None):
     """FunctionSoftsplat (softSplat.py:320-352).  want_spk: return the result split-packed (Spk) instead of fp32 NCHW
-    (written into `out_spk`, a Spk of the same shape, when given)."""
+    (written into `out_spk`, a Spk of the same shape, when given).  bounds_ws: a bounds table from splat_bounds_upsampled
+    (tile kernel only) instead of the exact pre-pass over `flow`."""
     N, C, H, W = img.shape
     assert flow.shape[1] == 2 and flow.shape[2] == H and flow.shape[3] == W
     flow = flow.contiguous()
@@ -291,13 +316,12 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
         kern = "tile" if C <= 3 else "strip"
     if kern == "tile" and not want_spk:
         img, ibs, ics = _planes(img, "img")
-        ws = torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
+        ws = bounds_ws if bounds_ws is not None else torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
         if out is None:
             out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
-        _check(lib().fldr_softsplat_tile_strided(ctypes.c_void_p(img.data_ptr()), ibs, ics, _dev(flow, "flow"),
-                                                 _dev(metric, "metric") if metric is not None else None,
-                                                 _dev(out, "out"), _dev(ws, "ws"), N, C, H, W, _MODES[mode], _stream()),
-               "fldr_softsplat_tile_strided")
+        fn = lib().fldr_softsplat_tile_prebounded if bounds_ws is not None else lib().fldr_softsplat_tile_strided
+        _check(fn(ctypes.c_void_p(img.data_ptr()), ibs, ics, _dev(flow, "flow"), _dev(metric, "metric") if metric is not None else None,
+                  _dev(out, "out"), _dev(ws, "ws"), N, C, H, W, _MODES[mode], _stream()), "fldr_softsplat_tile")
         return out
     img = img.contiguous()
     if want_spk:

@@ -99,6 +99,22 @@ int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t i
                                 const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
                                 fldr_stream_t stream);
 
+/* The level-0 image splats (fLDRnet.py:449-450) take flows that are bilinear upsamplings of a low-resolution field
+ * (flow_t = F.interpolate(scale * flow_lo, (H, W)) * mul, fLDRnet.py:404-405,419-422).  Their bounds table follows from the
+ * low-resolution field alone (interpolation is a convex combination; the intervals are widened by 2e-6 of their magnitude for
+ * its roundings), so the pre-pass over the two full-resolution flow planes is not needed:
+ *   fldr_splat_bounds_upsampled  fills ws (fldr_softsplat_tile_ws_floats(N,H,W) floats) from flow_lo — sample n at
+ *                                flow_lo + n*lo_bstride, [2,h,w] contiguous; scale_mode 0: 1, 1: t[n], 2: 1 - t[n];
+ *   fldr_softsplat_tile_prebounded = fldr_softsplat_tile_strided that takes the table in ws as given.  Any table whose block /
+ *                                super-block intervals contain the flow values of their pixels gives the exact result (the
+ *                                table only selects candidate sources); summation order, and with it the last bits, may
+ *                                differ from the exact-bounds call. */
+int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstride, const float* t_or_null, int scale_mode, float mul,
+                                float* ws, int N, int h, int w, int H, int W, fldr_stream_t stream);
+int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                   const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                   fldr_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * PWC cost volume — replaces OpticalFlow/correlation.py (forward only).
  * ------------------------------------------------------------------------------------------ */

@@ -104,6 +104,43 @@ def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
     assert torch.equal(r["im0_tot"], hip.bwarp(I0, fb0, True)) and torch.equal(r["im1_tot"], hip.bwarp(I1, fb1, True))
 
 
+@pytest.mark.parametrize("shape", [(1, 27, 60, 8, 0.5, 6.0), (2, 13, 21, 8, 0.25, 40.0), (1, 9, 15, 4, 1.0, 2.0), (1, 34, 40, 8, 0.0, 10.0)])
+def test_splat_bounds_from_low_resolution_flow(hip, oracle, dev, shape):
+    """fldr_splat_bounds_upsampled (the bounds table of the level-0 image splats from the LOW-resolution flow): every block /
+    super-block interval must contain the exact interval of the full-resolution flow_t that fldr_level0_prep writes, and the
+    splat run on that table must equal the exact-bounds splat up to summation order and the oracle."""
+    import ctypes
+    N, h, w, up, tv, amp = shape
+    H, W = h * up, w * up
+    g = _gen(101)
+    flow_lo = ((torch.rand(N, 4, h, w, generator=g) - 0.5) * amp).to(dev)
+    x = (torch.rand(N, 3, 2, H, W, generator=g) * 2 - 1).to(dev)
+    I0, I1 = x[:, :, 0], x[:, :, 1]
+    t4 = torch.full((N, 1, 1, 1), tv).to(dev)
+    r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+    L = hip.lib()
+    for img, flow, z, lo, smode in ((I0, r["flow_t0"], r["z0"], flow_lo[:, 2:], 1), (I1, r["flow_t1"], r["z1"], flow_lo[:, :2], 2)):
+        ws_lo = hip.splat_bounds_upsampled(lo, t4, smode, float(up), H, W)
+        exact = hip.softsplat_fused(img, flow, z, "softmax", kernel="tile")
+        # the exact table: run the exact-bounds entry on a workspace of our own and read it back
+        ws_ex = torch.empty_like(ws_lo)
+        imgc = img.contiguous()
+        out = torch.empty(N, 3, H, W, device=dev)
+        assert L.fldr_softsplat_tile(ctypes.c_void_p(imgc.data_ptr()), ctypes.c_void_p(flow.data_ptr()), ctypes.c_void_p(z.data_ptr()),
+                                     ctypes.c_void_p(out.data_ptr()), ctypes.c_void_p(ws_ex.data_ptr()), N, 3, H, W, 3, None) == 0
+        torch.cuda.synchronize()
+        a, b = ws_lo.view(-1, 4).cpu(), ws_ex.view(-1, 4).cpu()
+        live = torch.isfinite(b[:, 0])
+        assert torch.equal(live, torch.isfinite(a[:, 0]))                      # the same blocks are inside the image
+        a, b = a[live], b[live]
+        assert bool((a[:, 0] <= b[:, 0]).all() and (a[:, 1] >= b[:, 1]).all() and (a[:, 2] <= b[:, 2]).all() and (a[:, 3] >= b[:, 3]).all())
+        slack = torch.max((b[:, 0] - a[:, 0]).max(), (a[:, 1] - b[:, 1]).max())
+        assert float(slack) <= amp * up * max(tv, 1 - tv) + 1e-3                # never wider than the value range of the field
+        got = hip.softsplat_fused(img, flow, z, "softmax", bounds_ws=ws_lo)
+        assert (got - exact).abs().max().item() <= 2e-6
+        _cmp(got, oracle.function_softsplat(img.contiguous().cpu(), flow.cpu(), z.cpu(), "softmax"), atol=3e-5, what="splat on low-res bounds")
+
+
 def test_channel_strided_frames_read_in_place(hip, dev):
     """I0 / I1 are the views x[:, :, 0] / x[:, :, 1] of the [B,3,2,H,W] input (fLDRnet.py:130-131): level0_prep, the tile
     splat, the stride-2 encoder and dec3_synth read them through batch + channel strides and must give exactly what
