@@ -21,6 +21,7 @@
 //     therefore run up to two iterations apart instead of meeting at a barrier 6 times per unit.
 //   * Every spin is bounded (RING_SPIN_LIMIT polls, then the wave gives up, counts the event in fldr_ring_timeouts and
 //     runs on): the grid always drains.
+#include <type_traits>
 #include "spk_common.h"
 
 #define RING_SLOTS 3
@@ -32,6 +33,20 @@
 #endif
 #ifndef RING_FIN_PRIO
 #define RING_FIN_PRIO 0                         // wave priority of a consumer during its epilogue (0 = unchanged)
+#endif
+#ifndef RING_DEFER
+#define RING_DEFER 0                            // 1: a unit's epilogue runs between the MFMAs of the NEXT unit's first iteration (see the consumer
+                                                // loop).  Measured: 96->96 @272x480 59.9 vs 62.8 us alone, but 414 vs 418 pairs/s in the
+                                                // three-stream bench (the interleaved stores cost what the hidden VALU work saves): off.
+#endif
+#ifndef RING_LEAN
+#define RING_LEAN 0                             // 1: single-buffered hi weights / lo pixels in the iteration that carries a parked epilogue
+#endif
+#ifndef RING_FAIR
+#define RING_FAIR 0                             // 1: the two consumer waves of a SIMD trade issue priority by progress (see the consumer loop)
+#endif
+#ifndef RING_FAIR_SKEW
+#define RING_FAIR_SKEW 1
 #endif
 #ifndef RING_EARLY_FREE
 #define RING_EARLY_FREE 0                       // 1: FREE is signalled right after the last operand read is ISSUED (step 3)
@@ -68,8 +83,9 @@ struct RingCfg {
     static constexpr int NWL = (NBLK + RING_NLOAD - 1) / RING_NLOAD;    // weight blocks per loader wave
     static constexpr int K_DMA = NWL + RING_NXI;                        // DMA instructions per loader wave and fill
     static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
-    static constexpr int CTR_OFF = RING_SLOTS * STAGE;                  // FULL[3] at +0, FREE[3] at +16
-    static constexpr int LDS_BYTES = CTR_OFF + 64;
+    static constexpr int CTR_OFF = RING_SLOTS * STAGE;                  // FULL[3] at +0, FREE[3] at +16, PROGRESS[8] (consumer iteration counters) at +32
+    static constexpr int BIAS_OFF = CTR_OFF + 64;                       // bias of the workgroup's 16 * NMT output channels (fp32)
+    static constexpr int LDS_BYTES = BIAS_OFF + 64 * NMT;
     static_assert(K_DMA <= 15, "counted vmcnt wait uses the 4 low bits");
     static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
 };
@@ -114,7 +130,13 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     const int n_chunks = a.n_chunks;
     const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);   // LDS byte address of FULL[0]; FREE[s] at +16 + 4 s
 
-    if (tid < 8) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
+    if (tid >= 64 && tid < 64 + 16 * NMT) {                               // (unit -> output group as below: constant over the workgroup)
+        const int u0 = (blockIdx.x & 7) * a.units_per_xcd + (blockIdx.x >> 3);
+        int co = (u0 % a.groups) * 16 * NMT + (tid - 64);
+        co = co < a.cout ? co : a.cout - 1;
+        reinterpret_cast<float*>(smem + Cfg::BIAS_OFF)[tid - 64] = a.bias ? a.bias[co] : 0.0f;
+    }
     __syncthreads();                                                      // the only workgroup barrier of the kernel
 
     // Units of this workgroup: as in conv_spk_kernels.hip (XCD x owns the contiguous range [x*upx, (x+1)*upx)).
@@ -263,15 +285,22 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     const uint32_t HW32 = (uint32_t)HW;                                   // byte offsets below fit 32 bits (host-checked)
     const int gout = (a.cout_store + 7) >> 3;
     const int cbase = grp0 * MTOT;
-    float bias_r[NMT][4];
+    // bias of this lane's 4 channels per 16-channel block: in registers, or (kernels with the deferred epilogue, which need
+    // the 4 * NMT registers) fetched from the LDS table block by block
+    constexpr bool CAN_DEFER = RING_DEFER && !HAS_RES && NC == 8;
+    float bias_r[CAN_DEFER ? 1 : NMT][4];
+    if constexpr (!CAN_DEFER) {
 #pragma unroll
-    for (int m = 0; m < NMT; ++m)
+        for (int m = 0; m < NMT; ++m) {
+            const f4 bv = *reinterpret_cast<const f4*>(smem + Cfg::BIAS_OFF + (m * 16 + lg * 4) * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            int co = cbase + m * 16 + lg * 4 + r;
-            co = co < a.cout ? co : a.cout - 1;
-            bias_r[m][r] = a.bias ? a.bias[co] : 0.0f;
+            for (int r = 0; r < 4; ++r) bias_r[m][r] = bv[r];
         }
+    }
+    auto bias_of = [&](int m) __attribute__((always_inline)) -> f4 {
+        if constexpr (CAN_DEFER) return *reinterpret_cast<const f4*>(smem + Cfg::BIAS_OFF + (m * 16 + lg * 4) * 4);
+        else return f4{bias_r[m][0], bias_r[m][1], bias_r[m][2], bias_r[m][3]};
+    };
     auto unit_pixels = [&](int u, uint32_t (&po)[NQ], int& n) {
         const int t = spk_div(u, a.m_groups, a.groups);
         n = spk_div(t, a.m_tiles, a.n_tiles);
@@ -311,6 +340,10 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     bool range_bad = false;
     const bool grp_full = cbase + MTOT <= a.cout_store && !(a.cout_store & 7);      // wave-uniform, constant over the kernel
     auto finish_store = [&]() {
+        // (opaque copies of the lane coordinates: without them the compiler hoists this path's per-block offsets and
+        // predicates out of the iteration loop and keeps ~20 VGPRs live across the MFMA steps, or spills them)
+        int lj = lane & 15, lg = lane >> 4;
+        asm volatile("" : "+v"(lj), "+v"(lg));
         const int t = spk_div(cur_u, a.m_groups, a.groups);
         const int n = spk_div(t, a.m_tiles, a.n_tiles);
         const int tile = t - n * a.n_tiles;
@@ -329,9 +362,10 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     const int co0 = cbase + m * 16 + lg * 4;
                     float ov[4];
                     h4 ohi, olo;
+                    const f4 bsv = bias_of(m);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float v = fmaxf(acc[m][q][r] * inv_scale + bias_r[m][r], relu_floor);
+                        float v = fmaxf(acc[m][q][r] * inv_scale + bsv[r], relu_floor);
                         if constexpr (HAS_RES) v += res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r];
                         ov[r] = v;
                         acc[m][q][r] = 0.0f;
@@ -367,9 +401,10 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 const int co0 = cbase + m * 16 + lg * 4;
                 float ov[4];
                 h4 ohi, olo;
+                const f4 bsv = bias_of(m);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    float v = fmaxf(acc[m][q][r] * inv_scale + bias_r[m][r], relu_floor);
+                    float v = fmaxf(acc[m][q][r] * inv_scale + bsv[r], relu_floor);
                     if constexpr (HAS_RES) v += res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r];
                     ov[r] = v;
                     acc[m][q][r] = 0.0f;
@@ -402,38 +437,91 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
     };
 
+    // Deferred epilogue (RING_DEFER; launches without residual whose only output is the packed tensor, units on the fast
+    // path): a unit's accumulators move to `tmp` when its last chunk is done and are scaled / split / stored BETWEEN the MFMAs
+    // of the next unit's first iteration, two blocks' worth of VALU work and stores per MFMA step.  Stand-alone, the epilogue
+    // stops its wave's matrix instructions for ~3,300 cycles per unit (the SIMD partner then issues alone, one MFMA per 20
+    // cycles with its own polls and bookkeeping exposed): 15 % of the 96->96 launch (ablation: 64.2 -> 54.7 us without it;
+    // 58.5 with the deferred VALU work but no stores, 59.9-61.5 with everything: the stores are most of the cost).
+    constexpr int NBLK_E = NMT * NQ;                                     // (pixel block, 16-channel block) pairs of a wave
+    f4 tmp[CAN_DEFER ? NMT : 1][CAN_DEFER ? NQ : 1];
+    uint32_t pend_voff = 0;
+    char* pend_spkn = nullptr;
+    const bool defer_launch = CAN_DEFER && a.out_spk != nullptr && a.out_f32 == nullptr && grp_full;     // kernel-uniform
+    // block b = q * NMT + m of the pending unit, branch-free (fast path of finish_store, packed output only)
+    // (addresses: one lane-dependent 32-bit offset `pend_voff`, fixed when the unit is parked; everything that depends on the
+    // block is wave-uniform and stays in scalar registers — nothing per block for the compiler to hoist into VGPRs)
+    auto epi_block = [&](int b) __attribute__((always_inline)) {
+        if constexpr (CAN_DEFER) {
+            const int q = b / NMT, m = b - q * NMT;
+            const uint32_t s_pix = (uint32_t)((q >> 1) * a.W + (q & 1) * 16);
+            const uint32_t s_off = ((uint32_t)(((cbase >> 3) + 2 * m) * 2) * HW32 + s_pix) * 16u;     // wave-uniform
+            char* pb = pend_spkn + s_off;
+            h4 ohi, olo;
+            const f4 bsv = bias_of(m);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(tmp[m][q][r] * inv_scale + bsv[r], relu_floor);
+                _Float16 h, l;
+                spk_split(v, h, l, range_bad);
+                ohi[r] = h; olo[r] = l;
+            }
+#if defined(RING_ABLATE) && RING_ABLATE == 6                          // diagnostic: deferred epilogue without its stores
+            asm volatile("" :: "v"(ohi), "v"(olo), "s"(pb));
+#else
+            *reinterpret_cast<h4*>(pb + pend_voff) = ohi;
+            *reinterpret_cast<h4*>(pb + HW32 * 16u + pend_voff) = olo;
+#endif
+        }
+    };
+
     int st_cur = 0;
     uint32_t full_target = RING_NLOAD;                                    // RING_NLOAD * (use index of the slot + 1)
 #ifdef RING_STAMPS
     unsigned long long cs_wait = 0, cs_steps = 0, cs_fin = 0;
     RSTAMP(c_begin)
 #endif
-    for (int g = 0; g < total; ++g) {
-        const bool last = cur_c == n_chunks - 1;                          // workgroup-uniform
-        if constexpr (HAS_RES) { if (last) residual_prefetch(); }
-        RSTAMP(c0)
-        ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
-        RSTAMP(c1)
+    // the MFMA steps of one iteration on slot st_cur; EPI: with the pending unit's epilogue blocks spread over the steps
+    auto steps = [&](auto epi_tag) __attribute__((always_inline)) {
+        constexpr bool EPI = decltype(epi_tag)::value;
         const unsigned char* sb = smem + st_cur * Cfg::STAGE;
         const unsigned char* win = sb + lane * 16;
-        h8 bh[2][NQ], bl[2][NQ], ah[2][NMT], al[2][NMT];
-        auto ld = [&](int buf, int s) {
-            // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values);
-            // issue order = consumption order of the term-major MFMA sequence (hi x hi, hi x lo, lo x hi)
+        // Operand registers.  The lo weights are single-buffered (they feed only the last third of a step's MFMAs and are
+        // fetched at its start).  In the iteration that carries a parked epilogue (EPI) the hi weights and the lo pixels
+        // are single-buffered too — refilled for the next step right after their last use, behind the second third of
+        // the step's MFMAs — which frees the 20 registers the parked accumulators need.
+        constexpr bool LEAN = RING_LEAN && EPI && TERMS > 1;
+        h8 bh[2][NQ], bl[LEAN ? 1 : 2][NQ], ah[LEAN ? 1 : 2][NMT], al[NMT];
+        auto tap_off = [&](int s) {
+            // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values)
             const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
             const int offA = ((tA / 3) * SPK_IW + tA % 3) * 16, offB = ((tB / 3) * SPK_IW + tB % 3) * 16;
-            const int toff = tap_sel ? offB : offA;
+            return tap_sel ? offB : offA;
+        };
+        auto ld_bh = [&](int buf, int s) {
+            const int toff = tap_off(s);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) bh[buf][q] = *reinterpret_cast<const h8*>(sb + boff[q] + toff);
+        };
+        auto ld_ah = [&](int buf, int s) {
 #pragma unroll
             for (int m = 0; m < NMT; ++m) ah[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+        };
+        auto ld_bl = [&](int buf, int s) {
             if constexpr (TERMS > 1) {
+                const int toff = tap_off(s);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) bl[buf][q] = *reinterpret_cast<const h8*>(sb + 2 * SPK_PLANE + boff[q] + toff);
-#pragma unroll
-                for (int m = 0; m < NMT; ++m) al[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
             }
         };
+        auto ld_al = [&](int s) {
+            if constexpr (TERMS > 1) {
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) al[m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            }
+        };
+        // issue order = consumption order of the term-major MFMA sequence (hi x hi, hi x lo, lo x hi)
+        auto ld = [&](int buf, int s) { ld_bh(buf, s); ld_ah(LEAN ? 0 : buf, s); ld_bl(LEAN ? 0 : buf, s); };
         constexpr int N_MFMA = NQ * TERMS * NMT, N_DS = TERMS > 1 ? 2 * NQ + 2 * NMT : NQ + NMT;
 #ifdef RING_NTAIL
         constexpr int N_TAIL = N_MFMA >= 12 ? RING_NTAIL : (N_MFMA >= 6 ? 2 : 0);
@@ -441,50 +529,108 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         constexpr int N_TAIL = N_MFMA >= 12 ? 4 : (N_MFMA >= 6 ? 2 : 0);
 #endif
         ld(0, 0);
+        ld_al(0);
         __builtin_amdgcn_sched_barrier(0);                               // keep step 0's reads out of the interleave pattern below
 #pragma unroll
         for (int s = 0; s < SPK_STEPS; ++s) {
 #if defined(RING_ABLATE) && RING_ABLATE == 1                          // diagnostic: operands read once per iteration
-            if (s + 1 < SPK_STEPS) { for (int q = 0; q < NQ; ++q) { bh[(s + 1) & 1][q] = bh[s & 1][q]; bl[(s + 1) & 1][q] = bl[s & 1][q]; }
-                                    for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; al[(s + 1) & 1][m] = al[s & 1][m]; } }
+            if (s + 1 < SPK_STEPS && !LEAN) { for (int q = 0; q < NQ; ++q) { bh[(s + 1) & 1][q] = bh[s & 1][q]; bl[(s + 1) & 1][q] = bl[s & 1][q]; }
+                                              for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; } }
 #else
-            if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);               // lands while this step's MFMAs run
+            if (s > 0) ld_al(s);                                         // (after the previous step's last lo-weight MFMA in program order)
+            if (s + 1 < SPK_STEPS) { if constexpr (LEAN) ld_bh((s + 1) & 1, s + 1); else ld((s + 1) & 1, s + 1); }   // lands while this step's MFMAs run
 #endif
 #if RING_EARLY_FREE
             if (s + 2 == SPK_STEPS) { if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(ctr + 16 + 4 * st_cur), "v"(1u) : "memory"); }
 #endif
 #pragma unroll
-            for (int term = 0; term < TERMS; ++term)
+            for (int term = 0; term < TERMS; ++term) {
+                if constexpr (LEAN) {                                     // hi weights / lo pixels of the next step, behind their last readers
+                    if (term == 2 && s + 1 < SPK_STEPS) { ld_ah(0, s + 1); ld_bl(0, s + 1); }
+                }
 #pragma unroll
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const h8 av = term == 2 ? al[s & 1][m] : ah[s & 1][m];
-                        const h8 bv = term == 1 ? bl[s & 1][q] : bh[s & 1][q];
+                        const h8 av = term == 2 ? al[m] : ah[LEAN ? 0 : (s & 1)][m];
+                        const h8 bv = term == 1 ? bl[LEAN ? 0 : (s & 1)][q] : bh[s & 1][q];
 #if defined(RING_ABLATE) && RING_ABLATE == 2                          // diagnostic: no MFMAs
                         asm volatile("" :: "v"(av), "v"(bv));
 #else
                         acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][q], 0, 0, 0);
 #endif
                     }
-            // spread the next step's LDS reads evenly between this step's MFMAs
-            spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);
+            }
+            if constexpr (EPI) {
+                // blocks [b0, b1) of the pending unit ride on this step: ~24 VALU instructions and 2 stores each
+                constexpr int per = (NBLK_E + SPK_STEPS - 1) / SPK_STEPS;
+                const int b0 = s * per < NBLK_E ? s * per : NBLK_E, b1 = (s + 1) * per < NBLK_E ? (s + 1) * per : NBLK_E;
+#pragma unroll
+                for (int b = b0; b < b1; ++b) epi_block(b);
+                // {1 MFMA, 1 LDS read while there are reads, 3 VALU} per matrix instruction; the stores go wherever they fit
+                // (LEAN: the reads come in two groups — lo weights + next hi pixels from the step's start, next hi weights + lo
+                // pixels from its last third)
+                constexpr int third = N_MFMA / (TERMS > 1 ? 3 : 1);
+#pragma unroll
+                for (int i = 0; i < N_MFMA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    const bool rd = LEAN ? (i < NMT + NQ || (i >= 2 * third && i < 2 * third + NMT + NQ)) : i < N_DS;
+                    if ((s + 1 < SPK_STEPS || (LEAN && s > 0 && i < NMT)) && rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    if (b1 > b0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+                }
+            } else {
+                // spread the next step's LDS reads evenly between this step's MFMAs
+                spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);
+            }
         }
+    };
+    // one iteration's hand-shake around `steps`: wait for the slot, run, release it, step to the next slot
+    int g = 0;
+#ifdef RING_STAMPS
+    unsigned long long c0 = 0, c1 = 0, c2 = 0;
+#endif
+    auto iter_begin = [&]() __attribute__((always_inline)) {
+#ifdef RING_STAMPS
+        { RSTAMP(t) c0 = t; }
+#endif
+#if RING_FAIR
+        if constexpr (NC == 8) {
+            // The SIMD's arbiter serves its OLDER wave first when both consumer waves have an MFMA ready; with RING_FAIR each
+            // consumer publishes its iteration count and takes the LOWER issue priority while it is further ahead of its
+            // SIMD partner than RING_FAIR_SKEW iterations, the higher one while behind.  Measured: the waves then interleave
+            // (wait-FULL 1,500 -> 550 cycles per iteration) but the launch time does not change (64 us either way): off.
+            uint32_t pg, fl;
+            if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ctr + 32 + 4 * cw), "v"((uint32_t)g) : "memory");
+            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(pg), "=&v"(fl) : "v"(ctr + 32 + 4 * (cw ^ 4)), "v"(ctr + 4 * st_cur) : "memory");
+            pg = (uint32_t)__builtin_amdgcn_readfirstlane((int)pg);
+            fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)fl);
+            const int d = g - (int)pg - (cw < 4 ? RING_FAIR_SKEW : -RING_FAIR_SKEW);      // > 0: further ahead than wanted
+            if (d > 0) __builtin_amdgcn_s_setprio(0);
+            else if (d < 0) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(1);
+            if (fl < full_target) ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
+        } else
+#endif
+#if defined(RING_ABLATE) && RING_ABLATE == 5                          // diagnostic: consumers never look at FULL after the first fills (timing only: stale operands)
+        if (g < RING_SLOTS)
+#endif
+        ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
+#ifdef RING_STAMPS
+        { RSTAMP(t) c1 = t; }
+#endif
+    };
+    auto iter_end = [&]() __attribute__((always_inline)) {
 #if !RING_EARLY_FREE
         ring_signal(ctr + 16 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
 #endif
-        RSTAMP(c2)
-        if (last) {
-            if constexpr (HAS_RES) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the residual prefetched at the top
-            if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(RING_FIN_PRIO);
-            finish_store();
-            if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(0);
-            cur_c = 0; cur_u += a.wgs_per_xcd;
-        } else {
-            ++cur_c;
-        }
-        RSTAMP(c3)
 #ifdef RING_STAMPS
+        { RSTAMP(t) c2 = t; }
+#endif
+    };
+    auto iter_close = [&]() __attribute__((always_inline)) {
+#ifdef RING_STAMPS
+        RSTAMP(c3)
         cs_wait += c1 - c0; cs_steps += c2 - c1; cs_fin += c3 - c2;
         if (blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0 && g < 24) {
             unsigned long long* tr = fldr_ring_trace + ((wave == 0 ? 0 : 1) * 24 + g) * 4;
@@ -492,6 +638,69 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         }
 #endif
         if (++st_cur == RING_SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
+        ++g;
+    };
+    // The parked epilogue runs in the iteration that FOLLOWS the park in straight-line code (the first chunk of the next
+    // unit), not behind a flag tested at the loop head: `tmp` is then live from the park to the end of that one iteration
+    // only (with a flag, it counts as live through every plain iteration and is spilled to scratch, whose reloads share
+    // vmcnt with the epilogue's stores).
+    const bool can_park = defer_launch && n_chunks > 1;                   // kernel-uniform
+    while (g < total) {
+        const bool last = cur_c == n_chunks - 1;                          // workgroup-uniform
+        if constexpr (HAS_RES) { if (last) residual_prefetch(); }
+        iter_begin();
+        steps(std::false_type{});
+        iter_end();
+        if (last) {
+            if constexpr (HAS_RES) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the residual prefetched at the top
+            if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(RING_FIN_PRIO);
+#if defined(RING_ABLATE) && RING_ABLATE == 4                          // diagnostic: no epilogue (accumulators cleared, nothing stored)
+            for (int m = 0; m < NMT; ++m) for (int q = 0; q < NQ; ++q) { asm volatile("" :: "v"(acc[m][q])); acc[m][q] = f4{0.0f, 0.0f, 0.0f, 0.0f}; }
+            cur_c = 0; cur_u += a.wgs_per_xcd;
+            iter_close();
+#else
+            bool parked = false;
+            if constexpr (CAN_DEFER) {
+                if (can_park) {
+                    const int t = spk_div(cur_u, a.m_groups, a.groups);
+                    const int n = spk_div(t, a.m_tiles, a.n_tiles);
+                    const int tile = t - n * a.n_tiles;
+                    const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+                    const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+                    if (oy0 + ROWS <= a.H && ox0 + SPK_TW <= a.W) {       // wave-uniform: the fast path of finish_store
+                        pend_voff = ((uint32_t)(oy0 * a.W + ox0 + lj) + (uint32_t)(lg >> 1) * 2u * HW32) * 16u + (uint32_t)(lg & 1) * 8u;
+                        pend_spkn = reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride;
+#pragma unroll
+                        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                            for (int q = 0; q < NQ; ++q) { tmp[m][q] = acc[m][q]; acc[m][q] = f4{0.0f, 0.0f, 0.0f, 0.0f}; }
+                        parked = true;
+                        cur_c = 0; cur_u += a.wgs_per_xcd;
+                        iter_close();
+                        if (g < total) {                                  // first chunk of the next unit, carrying the epilogue (n_chunks > 1: not its last)
+                            iter_begin();
+                            steps(std::true_type{});
+                            iter_end();
+                            cur_c = 1;
+                            iter_close();
+                        } else {                                          // the workgroup's last unit
+#pragma unroll
+                            for (int b = 0; b < NBLK_E; ++b) epi_block(b);
+                        }
+                    }
+                }
+            }
+            if (!parked) {
+                finish_store();
+                cur_c = 0; cur_u += a.wgs_per_xcd;
+                iter_close();
+            }
+#endif
+            if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(0);
+        } else {
+            ++cur_c;
+            iter_close();
+        }
     }
     if (a.out_spk) fldr_note_range(range_bad);
 #ifdef RING_STAMPS

@@ -3,6 +3,7 @@
 tools/build_lib_variant.sh or tools/stamps/build_variant.sh).  One script instead of the per-kernel dbg_*.py of round 1.
 
     python tools/kernel_bench.py conv      # fldr_conv2d_spk: barrier pipeline / ring with 8 / 4 consumer waves, per layer shape
+    python tools/kernel_bench.py conv_cold # the dominant conv with cache-resident vs rotating inputs
     python tools/kernel_bench.py s2        # stride-2 encoders: tile-grid shift 0 / 15 / 31 of the persistent kernel
     python tools/kernel_bench.py dec3      # dec3 + softmax/T + blend: tile-grid shift 0 / 16
     python tools/kernel_bench.py pca       # PCA of a whole pyramid: per-level one-pass kernels vs the two pyramid launches
@@ -35,6 +36,18 @@ def conv():
         print("%3d->%2d @%4dx%4d: barrier %.1f us, ring8 %.1f us, ring4 %.1f us" % (cin, cout, h, w, t[0], t[1], t[2]), flush=True)
     L.fldr_debug_spk_variant(1); L.fldr_debug_ring_consumers(8)
     print("ring timeouts:", L.fldr_debug_ring_timeouts())
+
+
+def conv_cold():
+    """The 96->96 convolution at the level-0 geometries of the bench (272x480) and of X-Test (288x512): the same input every
+    launch (Infinity-Cache resident) against 6 rotating inputs / outputs (600 MB: every launch streams from HBM)."""
+    for (h, w) in [(272, 480), (288, 480), (288, 512)]:
+        xs = [hip.spk_pack(torch.rand(1, 96, h, w, device=dev)) for _ in range(6)]
+        w2 = torch.randn(96, 96, 3, 3, device=dev) / 30
+        hot = timeit(lambda i: hip.conv2d_spk([xs[0]], w2, None, relu=True, want_f32=False, want_spk=True), 40)
+        cold = timeit(lambda i: hip.conv2d_spk([xs[i % 6]], w2, None, relu=True, want_f32=False, want_spk=True), 42)
+        tiles = -(-h // 8) * -(-w // 32)
+        print("96->96 @%dx%d (%d units, %.2f rounds of 256): same input %.1f us, rotating inputs %.1f us" % (h, w, 2 * tiles, 2 * tiles / 256, hot, cold), flush=True)
 
 
 def s2():

@@ -5,16 +5,17 @@ import fldr_hip as hip
 hip.LIB_PATH = os.path.join(R, "libfldr_rstamp.so")
 dev = torch.device("cuda:0")
 wt = torch.randn(96, 96, 3, 3, device=dev) / 30; b = torch.randn(96, device=dev)
-for (h, w) in [(36, 60), (288, 480)]:
-    x = torch.rand(1, 96, h, w, device=dev); xp = hip.spk_pack(x)
-    for _ in range(3): hip.conv2d_spk([xp], wt, b, relu=True, want_f32=False, want_spk=True)
+for (h, w, cold) in [(36, 60, 0), (272, 480, 0), (272, 480, 1)]:
+    xs = [hip.spk_pack(torch.rand(1, 96, h, w, device=dev)) for _ in range(6 if cold else 1)]     # cold: 6 rotating inputs (600 MB > Infinity Cache)
+    for i in range(12): hip.conv2d_spk([xs[i % len(xs)]], wt, b, relu=True, want_f32=False, want_spk=True)
     torch.cuda.synchronize()
+    xp = xs[0]
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); hip.conv2d_spk([xp], wt, b, relu=True, want_f32=False, want_spk=True); e1.record(); torch.cuda.synchronize()
     buf = (ctypes.c_uint64 * 32)()
     hip.lib().fldr_debug_read_ring_stamps.argtypes = [ctypes.c_void_p]
     hip.lib().fldr_debug_read_ring_stamps(buf)
-    print((h, w), "launch %.1f us" % (e0.elapsed_time(e1) * 1e3))
+    print((h, w), "cold" if cold else "hot", "launch %.1f us" % (e0.elapsed_time(e1) * 1e3))
     for k, name in enumerate(("wg0 consumer0", "wg0 loader4", "wg101 consumer0", "wg101 loader4")):
         v = buf[k * 8: k * 8 + 7]; n = max(1, v[5])
         if k % 2 == 0:
