@@ -72,7 +72,7 @@ def self_launch(a):
 # ---------------------------------------------------------------------------------------------------------
 def dominant_conv_roofline(model, h, w, device, steps):
     """Roofline of the dominant kernel: the 96->96 3x3 convolution at the level-0 feature map (rec_ctx_ds.0/.2,
-    conv_flow2.0/.2 launch this instance of conv3x3_spk_kernel; the 3x3 convolutions are ~30 % of the GPU time).
+    conv_flow2.0/.2 launch this instance of conv3x3_ring_kernel<3,3,false,8>; the 3x3 convolutions are ~30 % of the GPU time).
     algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels (165 888 MAC/px for the two
     rec_ctx_ds convolutions); `achieved` = algorithmic FLOPs / average launch time, `frac` = that over the dense
     fp16 MFMA peak (= frac_algorithmic).  The kernel forms every product from THREE fp16 MFMAs (hi*hi + hi*lo + lo*hi,
@@ -104,7 +104,7 @@ def dominant_conv_roofline(model, h, w, device, steps):
     flops = 2.0 * 96 * 96 * 9 * h * w
     alg = flops / (ms * 1e-3) / 1e12
     tr = _measured_traffic()
-    return {"bound": "mfma", "kernel": "conv3x3_spk_kernel<3,3> (3x3 96->96 @%dx%d, persistent workgroups, split-packed operands, "
+    return {"bound": "mfma", "kernel": "conv3x3_ring_kernel<3,3,false,8> (3x3 96->96 @%dx%d, persistent loader/consumer ring, split-packed operands, "
                                        "3 x fp16-split v_mfma_f32_16x16x32_f16)" % (h, w),
             "achieved": round(alg, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(alg / PEAK_FP16_MFMA_TFLOPS, 4),
             "frac_algorithmic": round(alg / PEAK_FP16_MFMA_TFLOPS, 4), "frac_issued": round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
