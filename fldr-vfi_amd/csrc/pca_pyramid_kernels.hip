@@ -24,6 +24,8 @@
 #include "common.h"
 
 #define PCAP_MAX_LEVELS 8
+#define PCAP_MM 16                      // doubles between the per-level bounds in the workspace: every bound on a 128-byte line of its own (all
+                                        // 12 on one line serialised the ~25,000 atomics of the matrix-core pass A at one L2 channel: 139 vs 96 us)
 #ifndef PCAP_H
 #define PCAP_H 16                       // coefficients per scalar request (16: whole rows for K = 16, 64 cycles of FMAs per request)
 #endif
@@ -35,11 +37,12 @@ struct PcapLevel {
     int32_t P, H, W;
     int32_t wg_start;                 // first workgroup of the level in the launch
     int64_t nblocks;                  // P * (H/8) * (W/8)
+    int32_t item_start;               // matrix-core kernel: first 32-block item of the level
 };
 struct PcapArgs {
     PcapLevel lv[PCAP_MAX_LEVELS];
     const double* table;              // 64 rows {K coefficients, mean, 0}, meanvec[K], RN(1 / meanvec)[K] (fldr_pca_prepack)
-    double* mm;                       // [n_levels][2] {min, max}
+    double* mm;                       // min of level l at [32 l], max at [32 l + 16]
     int32_t n_levels;
 };
 
@@ -63,7 +66,7 @@ __device__ __forceinline__ double pcap_div(double x, double c, double r) {
 }
 
 __global__ void pcap_init_kernel(double* mm, int n) {
-    if ((int)threadIdx.x < n) { mm[2 * threadIdx.x] = 1.0e300; mm[2 * threadIdx.x + 1] = -1.0e300; }
+    if ((int)threadIdx.x < n) { mm[PCAP_MM * 2 * threadIdx.x] = 1.0e300; mm[PCAP_MM * (2 * threadIdx.x + 1)] = -1.0e300; }
 }
 
 // table from the module's parameters (EV8 [K,64] k-major, Mean8 [64], meanVec8 [K]); one block of 64 x K threads
@@ -79,6 +82,10 @@ __global__ void pcap_prepack_kernel(const double* __restrict__ ev, const double*
 
 // Pixels of one 8x8 block: 16 x dwordx4, all issued back to back (the consumer runs a whole block later).
 __device__ __forceinline__ void pcap_load(const float* __restrict__ p, int W, float (&x)[64]) {
+#if defined(PCAP_ABLATE) && PCAP_ABLATE == 1                           // diagnostic: no pixel traffic
+    for (int i = 0; i < 64; ++i) asm volatile("v_mov_b32 %0, 1.0" : "=v"(x[i]));
+    return;
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)i * W);
@@ -225,8 +232,8 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
         __syncthreads();
         if (threadIdx.x == 0) {
             for (int i = 1; i < 4; ++i) { lo = slo[i] < lo ? slo[i] : lo; hi = shi[i] > hi ? shi[i] : hi; }
-            pcap_atomic_min(a.mm + 2 * cur_level, lo);
-            pcap_atomic_max(a.mm + 2 * cur_level + 1, hi);
+            pcap_atomic_min(a.mm + PCAP_MM * 2 * cur_level, lo);
+            pcap_atomic_max(a.mm + PCAP_MM * (2 * cur_level + 1), hi);
         }
         lo = 1.0e300; hi = -1.0e300;
     };
@@ -235,7 +242,11 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
         double y[K];
         // The table pointer is laundered once per block: its 1,100 scalar loads are loop-invariant, and hoisted out of the
         // item loop they would need ~2,200 SGPRs (observed: thousands of spills).
+#if defined(PCAP_ABLATE) && PCAP_ABLATE == 2                           // diagnostic: no projection arithmetic
+        for (int k = 0; k < K; ++k) y[k] = (double)(x[k] + x[k + 16] + x[k + 32] + x[k + 48]);
+#else
         pcap_project<K>(x, table, y);
+#endif
         if constexpr (!EMIT) {
             if (w.level != cur_level) { flush(); cur_level = w.level; }
             if (w.live) {
@@ -245,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
         } else {
             if (!w.live) return;
             const PcapLevel& L = a.lv[w.level];
-            const double mi = a.mm[2 * w.level], range = a.mm[2 * w.level + 1] - mi;
+            const double mi = a.mm[PCAP_MM * 2 * w.level], range = a.mm[PCAP_MM * (2 * w.level + 1)] - mi;
             const double rr = 1.0 / range;                               // one true division per block; K Markstein quotients
             float f[K];
 #pragma unroll
@@ -320,6 +331,199 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
     if constexpr (!EMIT) flush();
 }
 
+// ------------------------------------------------------------------------------------------------
+// K = 16 on the fp64 matrix cores (opt-in: fldr_debug_pca_variant(1); the scalar-fed kernel above stays the default because it
+// is bit-identical to the per-level kernels and this one is no faster — 196 vs 202 us per 4K pyramid, both passes within
+// ~10 % of what their 267 + 400 MB cost at the 4.2-4.5 TB/s this access pattern streams at; pass A / B with the pixel loads
+// compiled out: 65 / 62 us, without the matrix instructions: 75 / 80 us, without pass B's stores: 65 us).
+//
+// What the ablations of the kernel above say (4K pyramid, two passes = 200 us): 141 us with the pixel loads compiled out —
+// the 1,100 scalar loads per block bound the fp64 pipe at half its rate — and 152 us with the arithmetic compiled out:
+// one block per lane means 16-byte loads at a 32-byte lane stride, two instructions over the same lines (3.5 TB/s).
+// Here the projection is the GEMM it is:  Y[16 components][16 blocks] += EV[16][4 pixels] * (X - mean)[4 pixels][16 blocks]
+// as v_mfma_f64_16x16x4_f64, 16 steps per 8x8 block:
+//   * A (coefficients, 16 steps x 1 double per lane) and the pixel means live in registers for the whole kernel — no scalar
+//     stream; matrix row i' holds component 4 (i' % 4) + i' / 4, so that a lane's four results (rows q + 4 r,
+//     MI355X_MICROARCH.md) are the components 4 q .. 4 q + 3: one 8-byte piece of the split-packed record;
+//   * B: lane (block j = lane % 16, quarter q = lane / 16) supplies, for every pair of rows, the four pixels 4 (q & 1) .. + 3 of
+//     row 2 r' + (q >> 1) (steps 4 r' .. 4 r' + 3): ONE 16-byte load per row pair and lane, and the 64 lanes of a load read
+//     two runs of 512 contiguous bytes (16 adjacent blocks, two image rows) — the access width this chip streams
+//     fastest (tools/ubench/plane_bw_bench: 5.5-5.9 TB/s against 3.9-4.1 for 4-byte lanes);
+//   * a wave owns 32 consecutive blocks per item = two independent accumulation chains; the next item's 16 loads are in
+//     flight while the 32 matrix instructions of the current one run.
+// The summation order over the 64 pixels differs from the scalar kernels (and the matrix instruction's internal order is
+// the hardware's): results agree with them to fp64 rounding (~1e-15 relative; the fp32 casts the model consumes are
+// equal except where that moves a value across a rounding boundary) — tests/test_gpu_parity.py bounds both.
+// ------------------------------------------------------------------------------------------------
+typedef double pcam_d4 __attribute__((ext_vector_type(4)));
+
+struct PcamWhere { int level; int p[2]; int64_t pix[2]; bool live[2]; const float* src[2]; };
+
+__device__ __forceinline__ void pcam_locate(const PcapArgs& a, int item, int j, int q, PcamWhere& w) {
+    w.level = 0;
+#pragma unroll
+    for (int l = 1; l < PCAP_MAX_LEVELS; ++l)
+        if (l < a.n_levels && item >= a.lv[l].item_start) w.level = l;          // wave-uniform
+    const PcapLevel& L = a.lv[w.level];
+    const int BW = L.W >> 3;
+    const int BHW = (L.H >> 3) * BW;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int64_t b = (int64_t)(item - L.item_start) * 32 + c * 16 + j;
+        w.live[c] = b < L.nblocks;
+        const uint32_t bb = w.live[c] ? (uint32_t)b : 0u;                        // dead lanes read block 0 of the level
+        // (floor of a correctly rounded fp64 quotient of two integers < 2^31 is the integer quotient: twice per 32 matrix instructions)
+#if defined(PCAM_ABLATE) && PCAM_ABLATE == 3                           // diagnostic: cheap (inexact) block decode
+        const uint32_t p = (uint32_t)((float)bb * (1.0f / (float)BHW));
+        const uint32_t pix = bb - p * (uint32_t)BHW;
+        const uint32_t by = (uint32_t)((float)pix * (1.0f / (float)BW)), bx = pix - by * (uint32_t)BW;
+#else
+        const uint32_t p = (uint32_t)((double)bb / (double)BHW);
+        const uint32_t pix = bb - p * (uint32_t)BHW;
+        const uint32_t by = (uint32_t)((double)pix / (double)BW), bx = pix - by * (uint32_t)BW;
+#endif
+        w.p[c] = (int)p; w.pix[c] = pix;
+        w.src[c] = L.planes + (int64_t)p * L.H * L.W + ((int64_t)by * 8 + (q >> 1)) * L.W + (int64_t)bx * 8 + 4 * (q & 1);
+    }
+}
+
+__device__ __forceinline__ void pcam_load(const PcamWhere& w, int W, float4 (&x)[2][4]) {
+#if defined(PCAM_ABLATE) && PCAM_ABLATE == 1                           // diagnostic: no pixel traffic
+    for (int c = 0; c < 2; ++c) for (int r = 0; r < 4; ++r) { asm volatile("v_mov_b32 %0, 1.0" : "=v"(x[c][r].x)); x[c][r].y = x[c][r].z = x[c][r].w = x[c][r].x; }
+    return;
+#endif
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[c][r] = *reinterpret_cast<const float4*>(w.src[c] + (int64_t)(2 * r) * W);
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(256, 2) void pcam_kernel(PcapArgs a, const double* __restrict__ table, int total_items) {
+#pragma clang fp contract(off)
+    constexpr int K = 16;
+    const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+    const int n_waves = gridDim.x * 4;
+    int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= total_items) return;                                            // wave-uniform; the kernel has no workgroup barrier
+
+    // A operand and means: step s = 4 r' + t  <->  pixel (row 2 r' + (q >> 1), column 4 (q & 1) + t); matrix row i' = lane % 16 <-> component 4 (i' % 4) + i' / 4
+    const int comp_a = 4 * (j & 3) + (j >> 2);
+    double aev[16], bm[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int pix = 8 * (2 * (s >> 2) + (q >> 1)) + 4 * (q & 1) + (s & 3);
+        aev[s] = table[pix * (K + 2) + comp_a];
+        bm[s] = table[pix * (K + 2) + K];
+    }
+    double mvr[4], rmvr[4];                                                     // this lane's components 4 q + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { mvr[r] = table[64 * (K + 2) + 4 * q + r]; rmvr[r] = table[64 * (K + 2) + K + 4 * q + r]; }
+
+    double lo = 1.0e300, hi = -1.0e300;
+    int cur_level = -1;
+    auto flush = [&]() {                                                        // wave-uniform call sites only
+        if (cur_level < 0) return;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+            lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+        }
+        if (lane == 0) { pcap_atomic_min(a.mm + PCAP_MM * 2 * cur_level, lo); pcap_atomic_max(a.mm + PCAP_MM * (2 * cur_level + 1), hi); }
+        lo = 1.0e300; hi = -1.0e300;
+    };
+
+    auto process = [&](const PcamWhere& w, const float4 (&x)[2][4]) {
+        pcam_d4 acc[2] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float4 xq = x[c][s >> 2];
+                const float xv = (s & 3) == 0 ? xq.x : ((s & 3) == 1 ? xq.y : ((s & 3) == 2 ? xq.z : xq.w));
+                const double d = (double)xv - bm[s];                            // pca_comp.py:502
+#if defined(PCAM_ABLATE) && PCAM_ABLATE == 2                           // diagnostic: no matrix instructions
+                acc[c][s & 3] += d * aev[s];
+#else
+                acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(aev[s], d, acc[c], 0, 0, 0);   // :507
+#endif
+            }
+        if constexpr (!EMIT) {
+            if (w.level != cur_level) { flush(); cur_level = w.level; }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                if (w.live[c]) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double y = pcap_div(acc[c][r], mvr[r], rmvr[r]);  // :511
+                        lo = y < lo ? y : lo; hi = y > hi ? y : hi;
+                    }
+                }
+        } else {
+            const PcapLevel& L = a.lv[w.level];
+            const int64_t BHW = (int64_t)(L.H >> 3) * (L.W >> 3);
+            const double mi = a.mm[PCAP_MM * 2 * w.level], range = a.mm[PCAP_MM * (2 * w.level + 1)] - mi;
+            const double rr = 1.0 / range;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                if (!w.live[c]) continue;
+                float f[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double y = pcap_div(acc[c][r], mvr[r], rmvr[r]);
+                    f[r] = (float)(pcap_div(y - mi, range, rr) * 2.0 - 1.0);    // :523-526, fLDRnet.py:146 .float()
+                }
+#if defined(PCAM_ABLATE) && PCAM_ABLATE == 4                           // diagnostic: pass B stores nothing
+                asm volatile("" :: "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]));
+                continue;
+#endif
+                if (L.out32) {
+                    float* o = L.out32 + ((int64_t)w.p[c] * K + 4 * q) * BHW + w.pix[c];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[(int64_t)r * BHW] = f[r];
+                }
+                if (L.spk) {
+                    // channel p*16 + 4q + r: group 2p + (q >> 1), halves 4 (q & 1) .. + 3 of the pixel's 16-byte record
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    h4 vh, vl;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float t = __uint_as_float(__float_as_uint(f[r]) & 0xFFFFE000u);   // the split of conv_spk_kernels.hip
+                        vh[r] = (_Float16)t;
+                        vl[r] = (_Float16)(f[r] - t);
+                    }
+                    unsigned char* d = L.spk + (((int64_t)w.p[c] * 2 + (q >> 1)) * 2 * BHW + w.pix[c]) * 16 + (q & 1) * 8;
+                    *reinterpret_cast<h4*>(d) = vh;
+                    *reinterpret_cast<h4*>(d + BHW * 16) = vl;
+                }
+            }
+        }
+    };
+
+    PcamWhere wa, wb;
+    float4 xa[2][4], xb[2][4];
+    pcam_locate(a, item, j, q, wa);
+    pcam_load(wa, a.lv[wa.level].W, xa);
+    while (true) {
+        int next = item + n_waves;                                              // wave-uniform control flow throughout
+        if (next < total_items) { pcam_locate(a, next, j, q, wb); pcam_load(wb, a.lv[wb.level].W, xb); }
+        __builtin_amdgcn_sched_barrier(0);                                       // the prefetch is issued before the arithmetic below
+        process(wa, xa);
+        if (next >= total_items) break;
+        item = next;
+        next = item + n_waves;
+        if (next < total_items) { pcam_locate(a, next, j, q, wa); pcam_load(wa, a.lv[wa.level].W, xa); }
+        __builtin_amdgcn_sched_barrier(0);
+        process(wb, xb);
+        if (next >= total_items) break;
+        item = next;
+    }
+    if constexpr (!EMIT) flush();
+}
+
+static int g_pcap_variant = 0;                    // 1: fp64 matrix cores (K = 16), 0 (default): scalar-fed vector kernel
+extern "C" int fldr_debug_pca_variant(int v) { if (v == 0 || v == 1) g_pcap_variant = v; return g_pcap_variant; }
+
 extern "C" int64_t fldr_pca_table_size(int K) {
     if (K != 4 && K != 8 && K != 16) return FLDR_E_ARG;
     return 64 * (K + 2) + 2 * K;
@@ -353,7 +557,8 @@ extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_leve
                                         double* minmax_ws, fldr_stream_t stream) {
     FLDR_CHECK_ARG(levels && table && minmax_ws && n_levels >= 1 && n_levels <= PCAP_MAX_LEVELS);
     PcapArgs a;
-    int64_t wg = 0;
+    int64_t wg = 0, items = 0;
+    bool mfma_ok = true;
     for (int l = 0; l < n_levels; ++l) {
         const fldr_pca_level& in = levels[l];
         FLDR_CHECK_ARG(in.planes && (in.out_f32 || in.out_spk) && in.P > 0 && in.H > 0 && in.W > 0);
@@ -366,10 +571,21 @@ extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_leve
         L.wg_start = (int)wg;
         wg += (L.nblocks + 255) / 256;
         if (wg >= (1ll << 30)) return FLDR_E_SHAPE;
+        L.item_start = (int)items;
+        items += (L.nblocks + 31) / 32;
+        if (L.nblocks + 32 >= (1ll << 31) || items >= (1ll << 30)) mfma_ok = false;
     }
-    for (int l = n_levels; l < PCAP_MAX_LEVELS; ++l) { a.lv[l] = a.lv[0]; a.lv[l].wg_start = 0x7fffffff; a.lv[l].nblocks = 0; }
+    for (int l = n_levels; l < PCAP_MAX_LEVELS; ++l) { a.lv[l] = a.lv[0]; a.lv[l].wg_start = 0x7fffffff; a.lv[l].item_start = 0x7fffffff; a.lv[l].nblocks = 0; }
     a.table = table; a.mm = minmax_ws; a.n_levels = n_levels;
     hipStream_t s = fldr_s(stream);
+    if (K == 16 && g_pcap_variant == 1 && mfma_ok) {
+        const int waves = (int)items, wgs = (waves + 3) / 4;
+        const int grid = wgs < g_pcap_wgs ? wgs : g_pcap_wgs;
+        hipLaunchKernelGGL(pcap_init_kernel, dim3(1), dim3(64), 0, s, a.mm, a.n_levels);
+        hipLaunchKernelGGL((pcam_kernel<false>), dim3(grid), dim3(256), 0, s, a, a.table, (int)items);
+        hipLaunchKernelGGL((pcam_kernel<true>), dim3(grid), dim3(256), 0, s, a, a.table, (int)items);
+        FLDR_LAUNCH_RET();
+    }
     switch (K) {
         case 16: pcap_launch<16>(a, (int)wg, s); break;
         case 8:  pcap_launch<8>(a, (int)wg, s); break;

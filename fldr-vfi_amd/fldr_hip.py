@@ -109,6 +109,7 @@ _SIGNATURES = {
     "fldr_pca_prepack": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int, ctypes.c_void_p]),
     "fldr_pca_project_pyramid": (ctypes.c_int, [ctypes.POINTER(PcaLevel), ctypes.c_int, _c_float_p, ctypes.c_int, _c_float_p, ctypes.c_void_p]),
     "fldr_debug_pca_workgroups": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_pca_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "fldr_resize_bilinear": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
@@ -173,7 +174,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         for env, hook in (("FLDR_RING_CONSUMERS", "fldr_debug_ring_consumers"), ("FLDR_SPK_VARIANT", "fldr_debug_spk_variant"),
-                          ("FLDR_PCA_WORKGROUPS", "fldr_debug_pca_workgroups")):       # tuning hooks from the environment (A/B runs)
+                          ("FLDR_PCA_WORKGROUPS", "fldr_debug_pca_workgroups"), ("FLDR_PCA_VARIANT", "fldr_debug_pca_variant")):   # tuning hooks from the environment (A/B runs)
             if os.environ.get(env):
                 getattr(l, hook)(int(os.environ[env]))
         _lib = l
@@ -498,10 +499,10 @@ def pca_project_pyramid(planes_list, ev, mean, meanvec, want_f32=True, want_spk=
         arr[i].out_f32 = o32.data_ptr() if o32 is not None else None
         arr[i].out_spk = osp.buf.data_ptr() if osp is not None else None
         arr[i].P, arr[i].H, arr[i].W = P, H, W
-    mm = torch.empty(n, 2, device=planes_list[0].device, dtype=torch.float64)
+    mm = torch.empty(n, 32, device=planes_list[0].device, dtype=torch.float64)      # each bound on a 128-byte line of its own
     _check(lib().fldr_pca_project_pyramid(arr, n, _dev(tab, "table", torch.float64), K, _dev(mm, "minmax", torch.float64), _stream()),
            "fldr_pca_project_pyramid")
-    return (outs32 if want_f32 else None), (outsp if want_spk else None), mm
+    return (outs32 if want_f32 else None), (outsp if want_spk else None), mm[:, ::16]
 
 
 def bwarp(x, flo, withmask=True):

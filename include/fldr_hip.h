@@ -163,9 +163,12 @@ int fldr_pca_project_stream(const float* planes, const double* ev, const double*
 
 /* All pyramid levels of a forward in two launches (the six to_pca_diff calls of fLDRnet.py:133-146): pass A reduces the
  * per-level min / max, pass B recomputes the projection and emits the fp32 cast and / or its split-packed twin — no fp64
- * intermediate in memory.  Same arithmetic and bit-identical results to fldr_pca_project per level.  `table` comes from
+ * intermediate in memory.  Same arithmetic as fldr_pca_project per level (bit-identical for the vector kernel).  `table` comes from
  * fldr_pca_prepack (fldr_pca_table_size(K) doubles: coefficients pixel-major, mean, meanvec and its reciprocals);
- * minmax_ws: 2 * n_levels doubles, on completion {min, max} per level.  n_levels <= 8; K in {4, 8, 16}. */
+ * minmax_ws: 32 * n_levels doubles (every bound on a 128-byte line of its own: the reduction is hardware fp64 atomics at the
+ * L2), on completion min of level l at [32 l], max at [32 l + 16].  n_levels <= 8; K in {4, 8, 16}.  K = 16 can run on the
+ * fp64 matrix cores instead (fldr_debug_pca_variant(1)): same arithmetic, pixels summed in another order — equal to the
+ * per-level kernels to fp64 rounding, not bit for bit; measured no faster, so not the default. */
 typedef struct fldr_pca_level {
     const float* planes;       /* [P, H, W] fp32, 16-byte aligned; H, W multiples of 8 */
     float*       out_f32;      /* [P*K, H/8, W/8] or NULL */
@@ -176,6 +179,7 @@ int64_t fldr_pca_table_size(int K);
 int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K, fldr_stream_t stream);
 int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K, double* minmax_ws,
                              fldr_stream_t stream);
+int fldr_debug_pca_variant(int v);                                /* K = 16: 0 (default) the scalar-fed vector kernel (bit-identical to the per-level kernels), 1 fp64 matrix cores; other: query */
 int fldr_debug_pca_workgroups(int v);                             /* tuning hook: persistent workgroups of the two pyramid passes (default 512); 0: query */
 
 /* ------------------------------------------------------------------------------------------

@@ -189,15 +189,16 @@ def test_pca_stream_equals_two_pass(hip, dev, model):
 
 @pytest.mark.parametrize("K", [16, 8, 4])
 def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K):
-    """fldr_pca_project_pyramid (all levels in two launches, pixel-major table, Markstein quotients, no fp64 intermediate)
-    against the per-level one-pass kernels of fldr_pca_project_stream: fp32 output, split-packed twin and min / max are
-    the same bits at every level, including levels of a few blocks and an odd number of planes."""
+    """fldr_pca_project_pyramid, vector kernel (all levels in two launches, pixel-major table, Markstein quotients, no fp64
+    intermediate) against the per-level one-pass kernels of fldr_pca_project_stream: fp32 output, split-packed twin and
+    min / max are the same bits at every level, including levels of a few blocks and an odd number of planes."""
     m, _ = model
     g = _gen(31)
     ev, mean, mv = m.EV8.detach()[:K].contiguous(), m.Mean8.detach(), m.meanVec8.detach()[:K].contiguous()
     P = 6 if K != 4 else 5
     levels = [(64, 96), (32, 48), (16, 24), (8, 8), (40, 520)]
     planes = [(torch.rand(P, h, w, generator=g) * 2 - 1).to(dev) for (h, w) in levels]
+    assert hip.lib().fldr_debug_pca_variant(-1) == 0
     o32, osp, mm = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=True, want_spk=True)
     for i, pl in enumerate(planes):
         s32, s64, smm, spk = hip.pca_project_stream(pl, ev, mean, mv, want_spk=True)
@@ -206,6 +207,36 @@ def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K):
         assert torch.equal(spk.buf, osp[i].buf), i
     only_spk = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=False, want_spk=True)[1]
     assert all(torch.equal(a.buf, b.buf) for a, b in zip(only_spk, osp))
+
+
+def test_pca_pyramid_matrix_core_kernel(hip, oracle, dev, model):
+    """The opt-in K = 16 pyramid kernel on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; pixels summed in the matrix instruction's order) against the
+    per-level vector kernels and the oracle: min / max to 1e-13 relative, the fp32 casts equal except where an fp64 rounding
+    difference crosses an fp32 rounding boundary (<= 1 ulp of 1.0, < 0.1 % of the elements), the packed twin = the pack of
+    its own fp32 output.  Levels: many rows of 16-block tiles, rows that are no multiple of 16 blocks (tiles wrap), fewer
+    than 32 blocks (dead lanes), a level of one block per plane."""
+    m, _ = model
+    g = _gen(33)
+    ev, mean, mv = m.EV8.detach(), m.Mean8.detach(), m.meanVec8.detach()
+    levels = [(64, 1024), (72, 136), (32, 48), (16, 24), (8, 8), (40, 520)]
+    planes = [(torch.rand(6, h, w, generator=g) * 2 - 1).to(dev) for (h, w) in levels]
+    L = hip.lib()
+    try:
+        assert L.fldr_debug_pca_variant(1) == 1
+        o32, osp, mm = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=True, want_spk=True)
+        for i, pl in enumerate(planes):
+            s32, s64, smm, spk = hip.pca_project_stream(pl, ev, mean, mv, want_spk=True)
+            assert torch.allclose(smm, mm[i], rtol=1e-13, atol=0.0), (i, smm, mm[i])
+            d = (s32 - o32[i]).abs()
+            assert d.max().item() <= 1.2e-7 and (d > 0).float().mean().item() < 1e-3, (i, d.max().item(), (d > 0).float().mean().item())
+            P, H, W = pl.shape
+            assert torch.equal(hip.spk_pack(o32[i].reshape(1, P * 16, H // 8, W // 8)).buf, osp[i].buf), i
+            ref = oracle.to_pca_diff(pl.double().cpu(), mean.cpu(), ev.cpu(), mv.cpu())
+            _cmp(o32[i].reshape(ref.shape), ref, atol=2e-7, what="matrix-core PCA vs oracle, level %d" % i)
+        only_spk = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=False, want_spk=True)[1]
+        assert all(torch.equal(a.buf, b.buf) for a, b in zip(only_spk, osp))
+    finally:
+        L.fldr_debug_pca_variant(0)
 
 
 @pytest.mark.parametrize("shape", [(1, [96], [0], 96, None, 9, 15, True, True), (2, [96], [0], 48, None, 20, 37, True, False),
