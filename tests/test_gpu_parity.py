@@ -803,11 +803,26 @@ def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
     for tv, c in zip(ts, cached):
         t = torch.tensor([[tv]])
         plain = Hn.interpolate(m, a, frames, t.to(dev))
-        _cmp(c, plain, atol=2e-5, what="cached vs uncached t=%g" % tv)
+        # Two runs of the SAME forward differ in the last bits of the flows (the feature splat sums with fp32 atomics, as the
+        # reference's does), and the backward warp's validity mask is a hard threshold (mask < 0.999 -> 0, fLDRnet.py:573-574):
+        # on this pair at t = 0.875 one pixel sits on it and about one run in eight flips it, moving ~190 output pixels by up
+        # to 1.3e-3 (tools/multit_probe.py: plain vs plain shows the same two outcomes).  So: a bounded fraction of bounded
+        # outliers here, and exact equality in the deterministic mode below.
+        err = _cmp(c, plain, atol=2e-5, max_outlier_frac=5e-3, what="cached vs uncached t=%g" % tv)
+        assert err < 5e-3, err
         if tv in (0.125, 0.5):
             with torch.no_grad():
                 ref = oracle.forward(weights, pyr, t)[:, :, :256, :384]
             _cmp(c, ref, atol=1e-4, what="cached vs oracle t=%g" % tv)
+    # deterministic mode (gather splat for the feature maps): cached and uncached outputs are the same bits
+    prev = hip.SPLAT_FEATURES
+    try:
+        hip.SPLAT_FEATURES = "gather"
+        det = Hn.interpolate_multi(m, a, frames, [0.5, 0.875])
+        for tv, c in zip([0.5, 0.875], det):
+            assert torch.equal(c, Hn.interpolate(m, a, frames, torch.tensor([[tv]], device=dev))), tv
+    finally:
+        hip.SPLAT_FEATURES = prev
     # a different pair must not hit the cache
     m.pair_cache = True
     try:
