@@ -26,7 +26,6 @@
 
 #define RING_SLOTS 3
 #define RING_NLOAD 4
-#define RING_NXI 6                              // 64-pixel DMA pieces per input plane (352 slots, the last two overlap)
 #define RING_SPIN_LIMIT (1 << 21)
 #ifndef RING_LOADER_PRIO
 #define RING_LOADER_PRIO 0                      // wave priority of the loaders (0 / 1 / 3 measured equal within noise)
@@ -76,16 +75,25 @@ extern "C" int fldr_debug_ring_timeouts(void) {
 
 int fldr_range_read_ring(int reset) { return fldr_tu_range_read(reset); }
 
-template <int NMT>
+// TW: tile width in pixels (32, or 16 for launches whose 8 x 32 tiles fill the last round of persistent workgroups badly:
+// see ring_pick_tile_width).  The LDS input plane is (8 + 2) x (TW + 2) pixels of 16 bytes, padded to a multiple of 256 bytes.
+template <int NMT, int TW = SPK_TW>
 struct RingCfg {
     static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;
     static constexpr int NBLK = SPK_STEPS * NMT * 2;                    // 1-KB weight blocks per chunk: (step, m, kind)
     static constexpr int NWL = (NBLK + RING_NLOAD - 1) / RING_NLOAD;    // weight blocks per loader wave
-    static constexpr int K_DMA = NWL + RING_NXI;                        // DMA instructions per loader wave and fill
-    static constexpr int STAGE = W_BYTES + SPK_IN_BYTES;
+    static constexpr int IW = TW + 2;                                   // input tile width (pixels)
+    static constexpr int CB = TW / 16;                                  // 16-pixel column blocks per tile row
+    static constexpr int PLANE = (SPK_IH * IW * 16 + 255) / 256 * 256;  // bytes per LDS plane (TW = 32: 5632 = SPK_PLANE)
+    static constexpr int NXI = (SPK_IH * IW + 63) / 64;                 // 64-pixel DMA pieces per input plane (the last ones overlap)
+    static constexpr int K_DMA = NWL + NXI;                             // DMA instructions per loader wave and fill
+    static constexpr int STAGE = W_BYTES + 4 * PLANE;
     static constexpr int CTR_OFF = RING_SLOTS * STAGE;                  // FULL[3] at +0, FREE[3] at +16, PROGRESS[8] (consumer iteration counters) at +32
     static constexpr int BIAS_OFF = CTR_OFF + 64;                       // bias of the workgroup's 16 * NMT output channels (fp32)
     static constexpr int LDS_BYTES = BIAS_OFF + 64 * NMT;
+    static_assert(TW == 16 || TW == 32, "tile width");
+    static_assert(TW != SPK_TW || PLANE == SPK_PLANE, "the 32-pixel plane is the barrier pipeline's");
+    static_assert(PLANE / 16 >= 64 && NXI * 64 >= SPK_IH * IW, "DMA pieces cover the plane");
     static_assert(K_DMA <= 15, "counted vmcnt wait uses the 4 low bits");
     static_assert(LDS_BYTES <= 160 * 1024, "ring does not fit the LDS");
 };
@@ -118,10 +126,11 @@ __device__ __forceinline__ void ring_signal(uint32_t lds_addr, int lane) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NMT, int TERMS, bool HAS_RES, int NC>
+template <int NMT, int TERMS, bool HAS_RES, int NC, int TW>
 __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(SpkArgs a) {
     // NC consumer waves (4: two tile rows each, one consumer per SIMD; 8: one row each, two per SIMD)
-    using Cfg = RingCfg<NMT>;
+    using Cfg = RingCfg<NMT, TW>;
+    constexpr int CB = Cfg::CB;
     constexpr int RING_NCONS = NC;
     constexpr int MTOT = 16 * NMT;
     extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
@@ -157,7 +166,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         const int sub = a.pack_nmt / NMT;
         const int pgrp = grp0 / sub, msel = (grp0 - pgrp * sub) * NMT;
         const int pack_w_bytes = SPK_STEPS * a.pack_nmt * 2 * 1024;
-        int w_blk[Cfg::NWL], x_piece[RING_NXI];
+        int w_blk[Cfg::NWL], x_piece[Cfg::NXI];
         uint32_t w_voff[Cfg::NWL];
 #pragma unroll
         for (int i = 0; i < Cfg::NWL; ++i) {
@@ -166,7 +175,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             w_voff[i] = (uint32_t)((step * a.pack_nmt + msel) * 2 + mk) * 1024u + (uint32_t)lane * 16u;
         }
 #pragma unroll
-        for (int i = 0; i < RING_NXI; ++i) x_piece[i] = min(i * 64, SPK_PLANE / 16 - 64);
+        for (int i = 0; i < Cfg::NXI; ++i) x_piece[i] = min(i * 64, Cfg::PLANE / 16 - 64);
         // input-group table in VGPR lanes (lane l = group l, advanced to this wave's hi or lo plane)
         unsigned long long tab_ptr;
         long long tab_bs;
@@ -181,19 +190,19 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             tab_ptr = e;
         }
         int iss_u = u_first, iss_c = 0, iss_n = 0;
-        uint32_t g_full[RING_NXI], g_half[RING_NXI];                      // byte offsets in a plane; ~0u = outside the image
+        uint32_t g_full[Cfg::NXI], g_half[Cfg::NXI];                      // byte offsets in a plane; ~0u = outside the image
         auto issue_geometry = [&]() {
             const int t = spk_div(iss_u, a.m_groups, a.groups);
             iss_n = spk_div(t, a.m_tiles, a.n_tiles);
             const int tile = t - iss_n * a.n_tiles;
             const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * TW;
 #pragma unroll
-            for (int i = 0; i < RING_NXI; ++i) {
+            for (int i = 0; i < Cfg::NXI; ++i) {
                 const int e = x_piece[i] + lane;
-                const int y = e / SPK_IW, x = e % SPK_IW;
+                const int y = e / Cfg::IW, x = e % Cfg::IW;
                 const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
-                const bool ok = e < SPK_IH * SPK_IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const bool ok = e < SPK_IH * Cfg::IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
                 g_full[i] = ok ? (uint32_t)(gy * a.W + gx) * 16u : ~0u;
                 g_half[i] = ok ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : ~0u;
             }
@@ -217,9 +226,9 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             const long long bs = (long long)(((unsigned long long)b_hi << 32) | b_lo);
             const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
             const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * bs;
-            const char* dptr[RING_NXI];
+            const char* dptr[Cfg::NXI];
 #pragma unroll
-            for (int i = 0; i < RING_NXI; ++i) {
+            for (int i = 0; i < Cfg::NXI; ++i) {
                 const uint32_t off = up2 ? g_half[i] : g_full[i];
                 dptr[i] = (off != ~0u && !nul) ? base + off : zero_blk;
             }
@@ -229,14 +238,14 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             RSTAMP(l2)
             unsigned char* stage = smem + st * Cfg::STAGE;
 #if defined(RING_ABLATE) && RING_ABLATE == 3                          // diagnostic: no DMA traffic after the prologue fills
-            if (k >= RING_SLOTS) { wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR); for (int i = 0; i < RING_NXI; ++i) dptr[i] = zero_blk; }
+            if (k >= RING_SLOTS) { wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR); for (int i = 0; i < Cfg::NXI; ++i) dptr[i] = zero_blk; }
 #endif
 #pragma unroll
             for (int i = 0; i < Cfg::NWL; ++i)
                 __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_voff[i]), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
 #pragma unroll
-            for (int i = 0; i < RING_NXI; ++i)
-                __builtin_amdgcn_global_load_lds((kgptr_t)dptr[i], (klptr_t)(stage + Cfg::W_BYTES + ip * SPK_PLANE + x_piece[i] * 16), 16, 0, 0);
+            for (int i = 0; i < Cfg::NXI; ++i)
+                __builtin_amdgcn_global_load_lds((kgptr_t)dptr[i], (klptr_t)(stage + Cfg::W_BYTES + ip * Cfg::PLANE + x_piece[i] * 16), 16, 0, 0);
             RSTAMP(l3)
             if (k > 0) {                                                  // fill k-1 has landed once at most K_DMA of my loads are outstanding
                 __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_DMA);
@@ -268,11 +277,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     constexpr int ROWS = SPK_TH / NC;                                     // tile rows per consumer wave
     const int cw = wave;                                                  // rows ROWS * cw ... of the 8 x 32 tile
     const int lj = lane & 15, lg = lane >> 4;
-    constexpr int NQ = 2 * ROWS;                                          // pixel blocks: q = row_in_wave * 2 + column block
+    constexpr int NQ = CB * ROWS;                                         // pixel blocks: q = row_in_wave * CB + column block
     int boff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-        boff[q] = Cfg::W_BYTES + (lg & 1) * SPK_PLANE + ((ROWS * cw + (q >> 1)) * SPK_IW + (q & 1) * 16 + lj) * 16;
+        boff[q] = Cfg::W_BYTES + (lg & 1) * Cfg::PLANE + ((ROWS * cw + q / CB) * Cfg::IW + (q % CB) * 16 + lj) * 16;
     const int tap_sel = lg >> 1;
     f4 acc[NMT][NQ];
 #pragma unroll
@@ -306,11 +315,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         n = spk_div(t, a.m_tiles, a.n_tiles);
         const int tile = t - n * a.n_tiles;
         const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-        const int ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+        const int ox0 = (tile - ty * a.tiles_x) * TW;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int oy = ty * SPK_TH + ROWS * cw + (q >> 1);
-            const int ox = ox0 + (q & 1) * 16 + lj;
+            const int oy = ty * SPK_TH + ROWS * cw + q / CB;
+            const int ox = ox0 + (q % CB) * 16 + lj;
             po[q] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
         }
     };
@@ -348,15 +357,15 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         const int n = spk_div(t, a.m_tiles, a.n_tiles);
         const int tile = t - n * a.n_tiles;
         const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-        const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+        const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * TW;
         char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) : nullptr;
         char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride : nullptr;
-        const bool inside = oy0 + ROWS <= a.H && ox0 + SPK_TW <= a.W;    // wave-uniform
+        const bool inside = oy0 + ROWS <= a.H && ox0 + TW <= a.W;    // wave-uniform
         if (grp_full && inside) {
             const uint32_t p0 = (uint32_t)(oy0 * a.W + ox0 + lj);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const uint32_t pq = p0 + (uint32_t)((q >> 1) * a.W + (q & 1) * 16);
+                const uint32_t pq = p0 + (uint32_t)((q / CB) * a.W + (q % CB) * 16);
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) {
                     const int co0 = cbase + m * 16 + lg * 4;
@@ -390,7 +399,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         uint32_t po[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            const int oy = oy0 + (q >> 1), ox = ox0 + (q & 1) * 16 + lj;
+            const int oy = oy0 + q / CB, ox = ox0 + (q % CB) * 16 + lj;
             po[q] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
         }
         const bool quads = !(a.cout_store & 3);                          // whole quads of channels: one predicate per 4 stores
@@ -454,7 +463,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     auto epi_block = [&](int b) __attribute__((always_inline)) {
         if constexpr (CAN_DEFER) {
             const int q = b / NMT, m = b - q * NMT;
-            const uint32_t s_pix = (uint32_t)((q >> 1) * a.W + (q & 1) * 16);
+            const uint32_t s_pix = (uint32_t)((q / CB) * a.W + (q % CB) * 16);
             const uint32_t s_off = ((uint32_t)(((cbase >> 3) + 2 * m) * 2) * HW32 + s_pix) * 16u;     // wave-uniform
             char* pb = pend_spkn + s_off;
             h4 ohi, olo;
@@ -495,7 +504,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         auto tap_off = [&](int s) {
             // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values)
             const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
-            const int offA = ((tA / 3) * SPK_IW + tA % 3) * 16, offB = ((tB / 3) * SPK_IW + tB % 3) * 16;
+            const int offA = ((tA / 3) * Cfg::IW + tA % 3) * 16, offB = ((tB / 3) * Cfg::IW + tB % 3) * 16;
             return tap_sel ? offB : offA;
         };
         auto ld_bh = [&](int buf, int s) {
@@ -511,7 +520,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             if constexpr (TERMS > 1) {
                 const int toff = tap_off(s);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) bl[buf][q] = *reinterpret_cast<const h8*>(sb + 2 * SPK_PLANE + boff[q] + toff);
+                for (int q = 0; q < NQ; ++q) bl[buf][q] = *reinterpret_cast<const h8*>(sb + 2 * Cfg::PLANE + boff[q] + toff);
             }
         };
         auto ld_al = [&](int s) {
@@ -666,8 +675,8 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     const int n = spk_div(t, a.m_tiles, a.n_tiles);
                     const int tile = t - n * a.n_tiles;
                     const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-                    const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
-                    if (oy0 + ROWS <= a.H && ox0 + SPK_TW <= a.W) {       // wave-uniform: the fast path of finish_store
+                    const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * TW;
+                    if (oy0 + ROWS <= a.H && ox0 + TW <= a.W) {       // wave-uniform: the fast path of finish_store
                         pend_voff = ((uint32_t)(oy0 * a.W + ox0 + lj) + (uint32_t)(lg >> 1) * 2u * HW32) * 16u + (uint32_t)(lg & 1) * 8u;
                         pend_spkn = reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride;
 #pragma unroll
@@ -715,19 +724,43 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 static int g_ring_consumers = 8;
 extern "C" int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
 
-template <int NMT, int TERMS, bool HAS_RES, int NC>
+template <int NMT, int TERMS, bool HAS_RES, int NC, int TW>
 static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
-    using Cfg = RingCfg<NMT>;
+    using Cfg = RingCfg<NMT, TW>;
     static std::atomic<uint64_t> attr_done{0};
-    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC>), Cfg::LDS_BYTES, attr_done)) return e;
-    if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max)) return e;
-    hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC>), dim3(8 * a.wgs_per_xcd), dim3((NC + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW>), Cfg::LDS_BYTES, attr_done)) return e;
+    if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, TW)) return e;
+    hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW>), dim3(8 * a.wgs_per_xcd), dim3((NC + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
+}
+
+// Tile width of a launch.  Persistent workgroups (one per CU) walk the units in rounds; a launch whose 8 x 32 tiles leave the
+// last round nearly empty (the second pyramid level of a 4K pair: 272 units on 256 workgroups = two rounds for 1.06 rounds
+// of work) runs 8 x 16 tiles instead when that is cheaper: twice the units, each costing RING_NARROW_COST of a wide one (half
+// the matrix work under the same weight stream).  Same arithmetic per output pixel: bit-identical results.
+#ifndef RING_NARROW_COST
+#define RING_NARROW_COST 0.65                  // measured: 9.5 vs 14.7 us per round of 256 units (96 -> 96)
+#endif
+static int g_ring_tile_width = 0;                // 0: automatic; 16 / 32: forced
+extern "C" int fldr_debug_ring_tile_width(int v) { if (v == 0 || v == 16 || v == 32) g_ring_tile_width = v; return g_ring_tile_width; }
+
+static int ring_pick_tile_width(const SpkArgs& a, int N, int wgs_per_xcd_max) {
+    if (g_ring_tile_width) return g_ring_tile_width;
+    const int64_t wgs = 8ll * wgs_per_xcd_max;
+    const int64_t ty = fldr_cdiv(a.H, SPK_TH);
+    const int64_t u32 = (int64_t)N * fldr_cdiv(a.W, 32) * ty * a.groups, u16 = (int64_t)N * fldr_cdiv(a.W, 16) * ty * a.groups;
+    if (u32 <= wgs / 2) return 32;                                       // launches that do not fill the chip either way
+    const double c32 = (double)((u32 + wgs - 1) / wgs), c16 = (double)((u16 + wgs - 1) / wgs) * RING_NARROW_COST;
+    return c16 < 0.97 * c32 ? 16 : 32;
 }
 
 template <int NMT, int TERMS, bool HAS_RES>
 static int ring_launch2(SpkArgs& a, int N, int wpx, hipStream_t s) {
-    return g_ring_consumers == 4 ? ring_launch3<NMT, TERMS, HAS_RES, 4>(a, N, wpx, s) : ring_launch3<NMT, TERMS, HAS_RES, 8>(a, N, wpx, s);
+    if (g_ring_consumers == 4) return ring_launch3<NMT, TERMS, HAS_RES, 4, 32>(a, N, wpx, s);
+    if constexpr (TERMS == 3) {
+        if (ring_pick_tile_width(a, N, wpx) == 16) return ring_launch3<NMT, TERMS, HAS_RES, 8, 16>(a, N, wpx, s);
+    }
+    return ring_launch3<NMT, TERMS, HAS_RES, 8, 32>(a, N, wpx, s);
 }
 
 template <int NMT, int TERMS>

@@ -109,8 +109,8 @@ __device__ __forceinline__ void spk_step_pattern(int s) {            // s is a c
 
 // Launch geometry shared by both pipelines: tiles, (sample, tile, group) units, XCD-contiguous unit ranges, persistent
 // workgroups per XCD (a multiple of `groups`: one output group per workgroup) and the magic numbers of spk_div.
-static inline int spk_fill_geometry(SpkArgs& a, int N, int wgs_per_xcd_max) {
-    a.tiles_x = fldr_cdiv(a.W, SPK_TW);
+static inline int spk_fill_geometry(SpkArgs& a, int N, int wgs_per_xcd_max, int tile_w = SPK_TW) {
+    a.tiles_x = fldr_cdiv(a.W, tile_w);
     a.n_tiles = a.tiles_x * fldr_cdiv(a.H, SPK_TH);
     a.n_units = N * a.n_tiles * a.groups;
     a.units_per_xcd = (a.n_units + 7) / 8;

@@ -333,6 +333,7 @@ int fldr_debug_spk_small_units(int v);                              /* tuning ho
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */
 int fldr_debug_ring_consumers(int v);                              /* tuning hook of the ring pipeline: 8 (default; two consumer waves per SIMD) or 4 consumer waves; other: query */
+int fldr_debug_ring_tile_width(int v);                             /* tuning hook of the ring pipeline: 0 (default) automatic per launch, 16 / 32 forced; other: query.  Bit-identical results */
 int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */
 
 /* ------------------------------------------------------------------------------------------

@@ -4,6 +4,7 @@ tools/build_lib_variant.sh or tools/stamps/build_variant.sh).  One script instea
 
     python tools/kernel_bench.py conv      # fldr_conv2d_spk: barrier pipeline / ring with 8 / 4 consumer waves, per layer shape
     python tools/kernel_bench.py conv_cold # the dominant conv with cache-resident vs rotating inputs
+    python tools/kernel_bench.py conv_tw   # ring pipeline on 8x32 vs 8x16 tiles
     python tools/kernel_bench.py s2        # stride-2 encoders: tile-grid shift 0 / 15 / 31 of the persistent kernel
     python tools/kernel_bench.py dec3      # dec3 + softmax/T + blend: tile-grid shift 0 / 16
     python tools/kernel_bench.py pca       # PCA of a whole pyramid: per-level one-pass kernels vs the two pyramid launches
@@ -48,6 +49,21 @@ def conv_cold():
         cold = timeit(lambda i: hip.conv2d_spk([xs[i % 6]], w2, None, relu=True, want_f32=False, want_spk=True), 42)
         tiles = -(-h // 8) * -(-w // 32)
         print("96->96 @%dx%d (%d units, %.2f rounds of 256): same input %.1f us, rotating inputs %.1f us" % (h, w, 2 * tiles, 2 * tiles / 256, hot, cold), flush=True)
+
+
+def conv_tw():
+    """8x32 against 8x16 tiles of the ring pipeline at the second pyramid level of a 4K pair (136x240: 272 wide units on 256
+    persistent workgroups) and at level 0."""
+    for (n, cin, cout, h, w) in [(1, 96, 96, 136, 240), (2, 96, 48, 136, 240), (1, 96, 48, 136, 240), (1, 48, 48, 136, 240), (1, 96, 96, 272, 480),
+                                 (1, 96, 96, 68, 120), (1, 96, 32, 544, 960), (1, 48, 16, 1088, 1920), (1, 96, 96, 144, 256), (1, 96, 96, 288, 512)]:
+        xs = [hip.spk_pack(torch.rand(n, cin, h, w, device=dev)) for _ in range(3)]
+        w2 = torch.randn(cout, cin, 3, 3, device=dev) / 30
+        row = []
+        for tw in (32, 16, 0):
+            L.fldr_debug_ring_tile_width(tw)
+            row.append("tw %2d: %.1f us" % (tw, timeit(lambda i: hip.conv2d_spk([xs[i % 3]], w2, None, relu=True, want_f32=False, want_spk=True), 30)))
+        print("N%d %3d->%2d @%4dx%4d  " % (n, cin, cout, h, w) + " | ".join(row), flush=True)
+    L.fldr_debug_ring_tile_width(0)
 
 
 def s2():
