@@ -520,7 +520,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     if (a.relu) v = fmaxf(v, 0.0f);
                     vv[r] = v;
                     acc[m][p][r] = 0.0f;
+#if defined(S2_NT) && S2_NT
+                    if (outn && co < a.cout_store && pix_ok) __builtin_nontemporal_store(v, &outn[(int64_t)co * HWo + po]);
+#else
                     if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+#endif
                 }
                 if (spkn) {
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));

@@ -103,7 +103,16 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
         for (int k = 0; k < 6; ++k)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch)
-                cv[a][k][ch] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k]) + pob);
+                {
+                    const float2* cp = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k]) + pob);
+#if defined(DEC3_NT) && (DEC3_NT & 1)
+                    typedef float d3_f2 __attribute__((ext_vector_type(2)));
+                    const d3_f2 t2 = __builtin_nontemporal_load(reinterpret_cast<const d3_f2*>(cp));          // read once: streaming hint
+                    cv[a][k][ch] = make_float2(t2[0], t2[1]);
+#else
+                    cv[a][k][ch] = *cp;
+#endif
+                }
     };
     load_cands(0);
 
@@ -190,8 +199,15 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             char* o = reinterpret_cast<char*>(out + ((int64_t)n * 3 + ch) * HW) + (uint32_t)po * (uint32_t)sizeof(OUT);      // scalar plane base + 32-bit offset
+#if defined(DEC3_NT) && (DEC3_NT & 2)
+            typedef double d3_d2 __attribute__((ext_vector_type(2)));
+            typedef float d3_f2o __attribute__((ext_vector_type(2)));
+            if constexpr (sizeof(OUT) == 8) __builtin_nontemporal_store(d3_d2{res[0][ch], res[1][ch]}, reinterpret_cast<d3_d2*>(o));
+            else __builtin_nontemporal_store(d3_f2o{(float)res[0][ch], (float)res[1][ch]}, reinterpret_cast<d3_f2o*>(o));
+#else
             if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0][ch], res[1][ch]);
             else *reinterpret_cast<float2*>(o) = make_float2((float)res[0][ch], (float)res[1][ch]);
+#endif
         }
     }
 }

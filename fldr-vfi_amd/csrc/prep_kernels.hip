@@ -31,7 +31,21 @@ struct PrepArgs {
 // address arithmetic per access (the kernel is bound by its VALU instruction count).  Planes are < 4 GB (host-checked).
 __device__ __forceinline__ float prep_ldf(const float* __restrict__ base, uint32_t boff) { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + boff); }
 __device__ __forceinline__ float2 prep_ldf2(const float2* __restrict__ base, uint32_t boff) { return *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(base) + boff); }
-__device__ __forceinline__ void prep_stf(float* __restrict__ base, uint32_t boff, float v) { *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v; }
+// The 16 output planes (566 MB at 4K, read back by the splats / enc1 / dec3 only after hundreds of MB of other traffic) are
+// stored with the streaming hint so that they do not displace what the Infinity Cache can actually keep (the packed
+// activations the convolutions hand to each other, enc1's output for enc2): +0.6-1.0 % frame pairs/s, A/B on one box.
+// The same hint on dec3's loads / stores and on the band splat's stores measured neutral, on the band splat's loads -1.3 %,
+// on enc1's stores -3.3 % (enc2 reads them right away).
+#ifndef PREP_NT
+#define PREP_NT 1
+#endif
+__device__ __forceinline__ void prep_stf(float* __restrict__ base, uint32_t boff, float v) {
+#if PREP_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff));
+#else
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff) = v;
+#endif
+}
 
 // Source indices / weight of F.interpolate(bilinear, align_corners=False) along one axis (fldr_lin_src), computed once
 // and shared by every plane and tap that is evaluated at the same coordinate.

@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
             if (cbase + c >= C) break;
             float v = acc[c * CELLS + i];
             if (MODE >= 1) v = v / norm;
+#if defined(BAND_NT) && (BAND_NT & 1)
+            __builtin_nontemporal_store((v - 0.5f) * 2.0f, &on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x]);
+#else
             on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x] = (v - 0.5f) * 2.0f;
+#endif
         }
     }
 }
@@ -406,6 +410,16 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
             const int py = (e >> 16) + r;
             const bool ok = px < W && py < H;
             const int64_t pix = ok ? (int64_t)py * W + px : 0;
+#if defined(BAND_NT) && (BAND_NT & 2)
+            fx[buf][r] = __builtin_nontemporal_load(&fl[pix]); fy[buf][r] = __builtin_nontemporal_load(&fl[HW + pix]);
+            mv[buf][r] = 0.0f;
+            if ((MODE == 2 || MODE == 3) && mt != nullptr) mv[buf][r] = __builtin_nontemporal_load(&mt[pix]);
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int cc = cbase + c < C ? cbase + c : C - 1;
+                val[buf][r][c] = __builtin_nontemporal_load(&inn[(int64_t)cc * in_cstride + pix]);
+            }
+#else
             fx[buf][r] = fl[pix]; fy[buf][r] = fl[HW + pix];
             mv[buf][r] = 0.0f;
             if ((MODE == 2 || MODE == 3) && mt != nullptr) mv[buf][r] = mt[pix];
@@ -414,6 +428,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
                 const int cc = cbase + c < C ? cbase + c : C - 1;
                 val[buf][r][c] = inn[(int64_t)cc * in_cstride + pix];
             }
+#endif
         }
     };
     // plain read-modify-write of one cell per active lane: ONLY for sets of lanes whose cells are pairwise distinct
@@ -693,7 +708,11 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
             if (cbase + c >= C) break;
             float v = acc[c * CELLS + i];
             if (MODE >= 1) v = v / norm;
+#if defined(BAND_NT) && (BAND_NT & 1)
+            __builtin_nontemporal_store((v - 0.5f) * 2.0f, &on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x]);
+#else
             on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x] = (v - 0.5f) * 2.0f;
+#endif
         }
     }
 #ifdef ST_STAMPS
