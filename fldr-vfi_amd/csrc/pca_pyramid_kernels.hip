@@ -24,6 +24,9 @@
 #include "common.h"
 
 #define PCAP_MAX_LEVELS 8
+#ifndef PCAP_REVERSE
+#define PCAP_REVERSE 1
+#endif
 #define PCAP_MM 16                      // doubles between the per-level bounds in the workspace: every bound on a 128-byte line of its own (all
                                         // 12 on one line serialised the ~25,000 atomics of the matrix-core pass A at one L2 channel: 139 vs 96 us)
 #ifndef PCAP_H
@@ -312,17 +315,20 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
     const int stride = gridDim.x;
     int item = blockIdx.x;
     if (item >= total_items) return;
-    PcapWhere wa = pcap_locate(a, item), wb = wa;
+    // Pass B walks the items in the opposite direction: what pass A read LAST is still in the Infinity Cache (the 267 MB of a
+    // 4K pyramid exceed its 256 MB, so a second scan in the same direction would miss everywhere).
+    auto phys = [&](int i) { return (EMIT && PCAP_REVERSE) ? total_items - 1 - i : i; };
+    PcapWhere wa = pcap_locate(a, phys(item)), wb = wa;
     pcap_load(wa.src, wa.W, xa);
     while (true) {
         int next = item + stride;                                        // workgroup-uniform control flow throughout
-        if (next < total_items) { wb = pcap_locate(a, next); pcap_load(wb.src, wb.W, xb); }
+        if (next < total_items) { wb = pcap_locate(a, phys(next)); pcap_load(wb.src, wb.W, xb); }
         __builtin_amdgcn_sched_barrier(0);                               // the prefetch is issued before the arithmetic below
         process(wa, xa);
         if (next >= total_items) break;
         item = next;
         next = item + stride;
-        if (next < total_items) { wa = pcap_locate(a, next); pcap_load(wa.src, wa.W, xa); }
+        if (next < total_items) { wa = pcap_locate(a, phys(next)); pcap_load(wa.src, wa.W, xa); }
         __builtin_amdgcn_sched_barrier(0);
         process(wb, xb);
         if (next >= total_items) break;
