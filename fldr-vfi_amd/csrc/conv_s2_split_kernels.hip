@@ -405,8 +405,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const auto* base = (const __attribute__((address_space(1))) char*)(live ? e + (unsigned long long)(iss_n * bs) * 4ull : (unsigned long long)reinterpret_cast<uintptr_t>(a.src[0]));
 #pragma unroll
         for (int i = 0; i < S2_NI; ++i) {
+#if defined(S2_NT) && (S2_NT & 2)
+            dst[2 * i] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]));
+            dst[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]));
+#else
             dst[2 * i] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]);
             dst[2 * i + 1] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]);
+#endif
         }
         dst[2 * S2_NI] = __uint_as_float(live ? iss_m0 : 0u); dst[2 * S2_NI + 1] = __uint_as_float(live ? iss_m1 : 0u);
         if (++iss_c == n_chunks) { iss_c = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }      // (past the end: the last tile again)
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     if (a.relu) v = fmaxf(v, 0.0f);
                     vv[r] = v;
                     acc[m][p][r] = 0.0f;
-#if defined(S2_NT) && S2_NT
+#if defined(S2_NT) && (S2_NT & 1)
                     if (outn && co < a.cout_store && pix_ok) __builtin_nontemporal_store(v, &outn[(int64_t)co * HWo + po]);
 #else
                     if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;

@@ -91,8 +91,15 @@ __device__ __forceinline__ void pcap_load(const float* __restrict__ p, int W, fl
 #endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
+#if defined(PCAP_NT) && PCAP_NT
+        typedef float pcap_f4 __attribute__((ext_vector_type(4)));
+        const pcap_f4 a_ = __builtin_nontemporal_load(reinterpret_cast<const pcap_f4*>(p + (int64_t)i * W));
+        const pcap_f4 b_ = __builtin_nontemporal_load(reinterpret_cast<const pcap_f4*>(p + (int64_t)i * W + 4));
+        const float4 a = make_float4(a_[0], a_[1], a_[2], a_[3]), b = make_float4(b_[0], b_[1], b_[2], b_[3]);
+#else
         const float4 a = *reinterpret_cast<const float4*>(p + (int64_t)i * W);
         const float4 b = *reinterpret_cast<const float4*>(p + (int64_t)i * W + 4);
+#endif
         x[i * 8 + 0] = a.x; x[i * 8 + 1] = a.y; x[i * 8 + 2] = a.z; x[i * 8 + 3] = a.w;
         x[i * 8 + 4] = b.x; x[i * 8 + 5] = b.y; x[i * 8 + 6] = b.z; x[i * 8 + 7] = b.w;
     }
