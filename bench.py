@@ -47,6 +47,7 @@ def parse():
                     help="independent frame-pair forwards kept in flight on separate HIP streams (1 = strictly serial)")
     ap.add_argument("--pairs", type=int, default=4, help="distinct frame pairs rotated through the timed loop (>= streams)")
     ap.add_argument("--sustained-s", type=float, default=3.0, help="length of the extra sustained-rate measurement (0 = skip)")
+    ap.add_argument("--fp16-mode-steps", type=int, default=60, help="steps of the informational fp16-input convolution run (BASELINE config 5; 0 = skip)")
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -228,7 +229,7 @@ def main():
 
     npairs = max(a.pairs, a.streams, 1)
     my_pairs = shard_pairs(world * npairs, rank, world)          # pair index = seed; disjoint across ranks
-    latency_ms = dt_e2e = sustained = None
+    latency_ms = dt_e2e = sustained = fp16_mode = None
     if gpu:
         import fldr_harness as Hn
         model, _, args = Hn.prepare_model(device)
@@ -306,6 +307,26 @@ def main():
         assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
         import fldr_hip
         fldr_hip.check_range()                         # no activation left the range of the fp16 hi/lo split (would raise)
+        # BASELINE config 5 (informational; never `value`): the same loop with plain fp16 convolution inputs (one MFMA per
+        # product instead of three; ~74 dB against the fp32-class frame, tests/test_gpu_parity.py::test_fp16_conv_path_config5)
+        fp16_mode = None
+        if rank == 0 and a.fp16_mode_steps > 0:
+            prev = fldr_hip.CONV_PRECISION
+            try:
+                fldr_hip.CONV_PRECISION = "fp16"
+                for i in range(npairs):
+                    step(i)
+                sync()
+                t1 = time.perf_counter()
+                for i in range(a.fp16_mode_steps):
+                    step(i)
+                sync()
+                d5 = time.perf_counter() - t1
+                fp16_mode = {"what": "3x3 convolutions on plain fp16 inputs (FLDR_CONV_PRECISION=fp16, BASELINE config 5): not fp32-equivalent, "
+                                     "reported for reference only", "steps": a.fp16_mode_steps, "ms_per_step": round(d5 / a.fp16_mode_steps * 1e3, 3),
+                             "pairs_per_s_this_gpu": round(a.fp16_mode_steps / d5, 2)}
+            finally:
+                fldr_hip.CONV_PRECISION = prev
     dt = max_over_ranks(dt_local, device)
     per_rank = gather_floats(a.steps / dt_local, device)
 
@@ -332,6 +353,8 @@ def main():
                                   "ms_uint8_in_to_uint8_out_single_stream": round(dt_e2e * 1e3, 3)})
             if sustained:
                 res["sustained"] = sustained
+            if fp16_mode:
+                res["fp16_conv_mode"] = fp16_mode
             res["roofline"] = dominant_conv_roofline(model, hp[0] // 8, hp[1] // 8, device, a.steps)
             pm = PATH_MODEL.get((a.height, a.width))
             if pm:
