@@ -317,7 +317,12 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
 //   * loads are unconditional from clamped offsets (one SGPR plane base + a 32-bit lane offset each) and masked afterwards.
 // Same operand layout, same MFMA order as the kernel above: bit-identical results.
 // ------------------------------------------------------------------------------------------------
-template <int MT, int NMT, int PT>
+//   * V4 (odd tile-grid shift, rows / planes 16-byte aligned: every 4K launch): the 68-float window [ix0 - 1, ix0 + 67) of a
+//     row starts on a 16-byte boundary, and an item is one (row pair, aligned quad of columns): TWO 16-byte loads instead of
+//     eight 4-byte ones.  This chip streams 16-byte lanes at 5.5-5.9 TB/s and 4-byte lanes at 3.9-4.1
+//     (tools/ubench/plane_bw_bench), and enc1 sat at that second figure; the two extra floats of a row land in the padding
+//     of the LDS lines.  Same LDS image, same MFMA order: bit-identical results.
+template <int MT, int NMT, int PT, bool V4>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv4x4s2_pers_kernel(S2Args a) {
     // (two workgroups per CU by LDS = 2 waves per SIMD: the full 256-VGPR budget, no spills — a scratch reload would sit in
     // the same in-order counter as the prefetched inputs and drain them)
@@ -362,16 +367,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
 
     // ---- staging geometry ----
-    // tile-independent: the LDS dword of item i; per tile: clamped byte offsets of its two rows and their validity bits
-    int l_dw[S2_NI], it_pr2[S2_NI], it_x[S2_NI];
+    // scalar path: an item = one column of one row pair (two 4-byte loads); V4: one aligned quad of columns of one row pair
+    // (two 16-byte loads).  Tile-independent: the LDS dword(s) of item i; per tile: clamped byte offsets of its two rows and
+    // their validity bits.
+    constexpr int NIT = V4 ? 3 : S2_NI;                                       // items per lane and channel
+    constexpr int QPR = 17;                                                   // V4: quads per row (68 floats)
+    constexpr int SETN = V4 ? 8 * NIT + 2 : 2 * S2_NI + 2;                    // floats of a register set (+ the two validity words)
+    int l_dw[NIT], it_pr2[NIT], it_x[NIT];                                    // V4: l_dw = even-plane dword of the quad, it_x = 4 * quad - 1
 #pragma unroll
-    for (int i = 0; i < S2_NI; ++i) {
+    for (int i = 0; i < NIT; ++i) {
         const int e = lane + 64 * i;
-        const int pr = e / S2_IW, x = e % S2_IW;
-        it_pr2[i] = 2 * pr; it_x[i] = x;
-        l_dw[i] = e < S2_RP * S2_IW ? (pr * 2 + (x & 1)) * IWHP + (x >> 1) : -1;
+        if constexpr (V4) {
+            const int pr = e / QPR, qd = e % QPR;
+            it_pr2[i] = 2 * pr; it_x[i] = 4 * qd - 1;
+            l_dw[i] = e < S2_RP * QPR ? (pr * 2) * IWHP + 2 * qd : -1;
+        } else {
+            const int pr = e / S2_IW, x = e % S2_IW;
+            it_pr2[i] = 2 * pr; it_x[i] = x;
+            l_dw[i] = e < S2_RP * S2_IW ? (pr * 2 + (x & 1)) * IWHP + (x >> 1) : -1;
+        }
     }
-    uint32_t voff0[S2_NI], voff1[S2_NI];
+    uint32_t voff0[NIT], voff1[NIT];
     unsigned iss_m0 = 0, iss_m1 = 0;
     int iss_k = 0, iss_c = 0, iss_n = 0;
     auto issue_geometry = [&]() __attribute__((always_inline)) {
@@ -382,20 +398,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const int iy0 = ty * S2_TH * 2 - 1, ix0 = ((tile - ty * a.tiles_x) * S2_TW - a.x_shift) * 2 - 1;
         iss_m0 = 0; iss_m1 = 0;
 #pragma unroll
-        for (int i = 0; i < S2_NI; ++i) {
+        for (int i = 0; i < NIT; ++i) {
             const int gy0 = iy0 + it_pr2[i], gy1 = gy0 + 1, gx = ix0 + it_x[i];
+            // (V4: gx is a multiple of 4 and Win % 4 == 0, so a quad is inside the image or outside it as a whole)
             const bool okx = l_dw[i] >= 0 && gx >= 0 && gx < a.Win;
             const bool ok0 = okx && gy0 >= 0 && gy0 < a.Hin, ok1 = okx && gy1 >= 0 && gy1 < a.Hin;
             iss_m0 |= ok0 ? (1u << i) : 0u;
             iss_m1 |= ok1 ? (1u << i) : 0u;
-            const int cx = min(max(gx, 0), a.Win - 1);
+            const int cx = okx ? gx : 0;                                      // (lanes without an item, columns outside: any valid address)
             voff0[i] = (uint32_t)(min(max(gy0, 0), a.Hin - 1) * a.Win + cx) * 4u;
             voff1[i] = (uint32_t)(min(max(gy1, 0), a.Hin - 1) * a.Win + cx) * 4u;
         }
     };
     // request the inputs of the issue side's (tile, chunk) into `dst` and step the issue side; wave w stages channel w
-    // (the two validity words travel in dst[2*S2_NI], dst[2*S2_NI+1])
-    auto issue_loads = [&](float (&dst)[2 * S2_NI + 2]) __attribute__((always_inline)) {
+    // (the two validity words travel in dst[SETN - 2], dst[SETN - 1])
+    auto issue_loads = [&](float (&dst)[SETN]) __attribute__((always_inline)) {
         const int c = iss_c * S2_CC + wave_u;                                 // wave-uniform
         const unsigned long long e = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(ctab >> 32), c & 63) << 32) |
                                      (unsigned)__builtin_amdgcn_readlane((int)(unsigned)ctab, c & 63);
@@ -404,33 +421,55 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         const bool live = c < a.cin;                                          // padding channels of the last chunk read plane 0 and are masked
         const auto* base = (const __attribute__((address_space(1))) char*)(live ? e + (unsigned long long)(iss_n * bs) * 4ull : (unsigned long long)reinterpret_cast<uintptr_t>(a.src[0]));
 #pragma unroll
-        for (int i = 0; i < S2_NI; ++i) {
+        for (int i = 0; i < NIT; ++i) {
+            if constexpr (V4) {
+                const s2_f4 q0 = *reinterpret_cast<const __attribute__((address_space(1))) s2_f4*>(base + voff0[i]);
+                const s2_f4 q1 = *reinterpret_cast<const __attribute__((address_space(1))) s2_f4*>(base + voff1[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dst[8 * i + j] = q0[j]; dst[8 * i + 4 + j] = q1[j]; }
+            } else {
 #if defined(S2_NT) && (S2_NT & 2)
-            dst[2 * i] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]));
-            dst[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]));
+                dst[2 * i] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]));
+                dst[2 * i + 1] = __builtin_nontemporal_load(reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]));
 #else
-            dst[2 * i] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]);
-            dst[2 * i + 1] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]);
+                dst[2 * i] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff0[i]);
+                dst[2 * i + 1] = *reinterpret_cast<const __attribute__((address_space(1))) float*>(base + voff1[i]);
 #endif
+            }
         }
-        dst[2 * S2_NI] = __uint_as_float(live ? iss_m0 : 0u); dst[2 * S2_NI + 1] = __uint_as_float(live ? iss_m1 : 0u);
+        dst[SETN - 2] = __uint_as_float(live ? iss_m0 : 0u); dst[SETN - 1] = __uint_as_float(live ? iss_m1 : 0u);
         if (++iss_c == n_chunks) { iss_c = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }      // (past the end: the last tile again)
     };
     bool range_bad = false;
-    auto store_inputs = [&](unsigned char* stage, const float (&src)[2 * S2_NI + 2]) __attribute__((always_inline)) {
+    auto store_inputs = [&](unsigned char* stage, const float (&src)[SETN]) __attribute__((always_inline)) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const unsigned m0 = __float_as_uint(src[2 * S2_NI]), m1 = __float_as_uint(src[2 * S2_NI + 1]);
+        const unsigned m0 = __float_as_uint(src[SETN - 2]), m1 = __float_as_uint(src[SETN - 1]);
         h2* hi = reinterpret_cast<h2*>(stage) + wave * CHS;
         h2* lo = hi + KIND;
 #pragma unroll
-        for (int i = 0; i < S2_NI; ++i) {
+        for (int i = 0; i < NIT; ++i) {
             if (l_dw[i] < 0) continue;
-            const float x0 = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
-            h2 h, l;
-            { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[0] = a_; l[0] = b_; }
-            { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[1] = a_; l[1] = b_; }
-            hi[l_dw[i]] = h;
-            lo[l_dw[i]] = l;
+            if constexpr (V4) {
+                // columns x = 4 q - 1 .. 4 q + 2 of the window: odd plane index 2 q - 1 (x = -1: the padding in front of the line),
+                // even 2 q, odd 2 q, even 2 q + 1 (x = 66: the padding behind it)
+                h2 h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float x0 = ((m0 >> i) & 1u) ? src[8 * i + j] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[8 * i + 4 + j] : 0.0f;
+                    { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[j][0] = a_; l[j][0] = b_; }
+                    { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[j][1] = a_; l[j][1] = b_; }
+                }
+                const int ev = l_dw[i], od = l_dw[i] + IWHP - 1;
+                hi[ev] = h[1]; hi[ev + 1] = h[3]; hi[od] = h[0]; hi[od + 1] = h[2];
+                lo[ev] = l[1]; lo[ev + 1] = l[3]; lo[od] = l[0]; lo[od + 1] = l[2];
+            } else {
+                const float x0 = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
+                h2 h, l;
+                { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[0] = a_; l[0] = b_; }
+                { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[1] = a_; l[1] = b_; }
+                hi[l_dw[i]] = h;
+                lo[l_dw[i]] = l;
+            }
         }
     };
 
@@ -559,7 +598,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     // Every iteration issues its 20 loads UNCONDITIONALLY (past the end they re-read the last tile: harmless) and the
     // epilogue's stores come after the LDS write, so that between the request of a register set and its use there is
     // exactly one other request: the compiler's wait becomes a counted vmcnt(20) instead of a drain.
-    float preA[2 * S2_NI + 2], preB[2 * S2_NI + 2];
+    float preA[SETN], preB[SETN];
     issue_geometry();
     issue_loads(preA);                                                        // iteration 0
     issue_loads(preB);                                                        // iteration 1
@@ -682,17 +721,26 @@ extern "C" int fldr_debug_s2_xshift(int v) { if (v >= -1 && v < S2_TW) g_s2_xshi
 static int g_s2_persistent = 1;
 extern "C" int fldr_debug_s2_persistent(int v) { if (v >= 0) g_s2_persistent = v; return g_s2_persistent; }
 
-template <int MT, int NMT, int PT>
-static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {
+template <int MT, int NMT, int PT, bool V4>
+static int s2_launch_pers2(S2Args& a, hipStream_t s, int lds_bytes) {
     static std::atomic<int> attr_bytes[64];                      // per device ordinal: the attribute is per device
     int dev = 0;
     if (hipError_t e = hipGetDevice(&dev); e != hipSuccess) return (int)e;
     if (attr_bytes[dev & 63].load(std::memory_order_acquire) < lds_bytes) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4x4s2_pers_kernel<MT, NMT, PT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv4x4s2_pers_kernel<MT, NMT, PT, V4>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e != hipSuccess) return (int)e;
         attr_bytes[dev & 63].store(lds_bytes, std::memory_order_release);
     }
+    hipLaunchKernelGGL((conv4x4s2_pers_kernel<MT, NMT, PT, V4>), dim3(8 * a.wgs_per_xcd), dim3(256), lds_bytes, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+static int g_s2_vec4 = 1;                        // 16-byte staging loads where the geometry allows (0: always the 4-byte path)
+extern "C" int fldr_debug_s2_vec4(int v) { if (v == 0 || v == 1) g_s2_vec4 = v; return g_s2_vec4; }
+
+template <int MT, int NMT, int PT>
+static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {
     // Tile grid shifted left by 15 output columns on wide images: a tile's 66 input columns then start ONE float into a
     // 128-byte line ([64 t - 31, 64 t + 34]) and touch 3 lines per row instead of the 4 of the unshifted span
     // [64 t - 1, 64 t + 64] (one float each into the lines left and right).  PMC at 4K, enc1: the L2 fetched 1,629 MB for
@@ -705,8 +753,12 @@ static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {
     if (total >= (1ll << 30)) return FLDR_E_SHAPE;
     a.tiles_per_xcd = (int)((total + 7) / 8);
     a.wgs_per_xcd = a.tiles_per_xcd < 64 ? a.tiles_per_xcd : 64;
-    hipLaunchKernelGGL((conv4x4s2_pers_kernel<MT, NMT, PT>), dim3(8 * a.wgs_per_xcd), dim3(256), lds_bytes, s, a);
-    FLDR_LAUNCH_RET();
+    // 16-byte staging: the window start ix0 - 1 = 64 t - 2 x_shift - 2 is a multiple of 4 floats for odd shifts; rows and
+    // planes must keep that alignment
+    bool v4 = g_s2_vec4 && (a.x_shift & 1) && (a.Win & 3) == 0;
+    for (int k = 0; k < a.n_src && v4; ++k)
+        v4 = (reinterpret_cast<uintptr_t>(a.src[k]) & 15) == 0 && (a.src_bstride[k] & 3) == 0 && (a.src_cstride[k] & 3) == 0;
+    return v4 ? s2_launch_pers2<MT, NMT, PT, true>(a, s, lds_bytes) : s2_launch_pers2<MT, NMT, PT, false>(a, s, lds_bytes);
 }
 
 // Same descriptor as fldr_conv2d (ksize 4, stride 2; no up2 sources, no residual); d->wpack from fldr_conv_s2_prepack.

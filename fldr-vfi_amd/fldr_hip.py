@@ -111,6 +111,7 @@ _SIGNATURES = {
     "fldr_debug_pca_workgroups": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_pca_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_tile_width": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_s2_vec4": (ctypes.c_int, [ctypes.c_int]),
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
     "fldr_resize_bilinear": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
@@ -176,7 +177,7 @@ def lib():
             fn.argtypes = args
         for env, hook in (("FLDR_RING_CONSUMERS", "fldr_debug_ring_consumers"), ("FLDR_SPK_VARIANT", "fldr_debug_spk_variant"),
                           ("FLDR_PCA_WORKGROUPS", "fldr_debug_pca_workgroups"), ("FLDR_PCA_VARIANT", "fldr_debug_pca_variant"),
-                          ("FLDR_RING_TILE_WIDTH", "fldr_debug_ring_tile_width")):   # tuning hooks from the environment (A/B runs)
+                          ("FLDR_RING_TILE_WIDTH", "fldr_debug_ring_tile_width"), ("FLDR_S2_VEC4", "fldr_debug_s2_vec4")):   # tuning hooks from the environment (A/B runs)
             if os.environ.get(env):
                 getattr(l, hook)(int(os.environ[env]))
         _lib = l

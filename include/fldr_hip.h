@@ -292,6 +292,7 @@ int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, f
 int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 int fldr_debug_s2_persistent(int v);                                /* tuning hook: 1 (default) persistent-workgroup kernel where the weights fit, 0 per-tile kernel; < 0 query */
 int fldr_debug_s2_xshift(int v);                                  /* tuning hook: left shift (output columns) of the persistent stride-2 kernel's tile grid; -1 (default): 15 on wide images */
+int fldr_debug_s2_vec4(int v);                                   /* tuning hook: 1 (default) 16-byte staging loads in the persistent stride-2 encoder where the geometry allows, 0 never; other: query.  Bit-identical results */
 int fldr_debug_dec3_xshift(int v);                                /* tuning hook: left shift (low-resolution columns) of fldr_dec3_synth's tile grid; -1 (default): 16 on wide frames */
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.

@@ -314,14 +314,18 @@ def test_stride2_persistent_kernel_bit_identical_to_per_tile(hip, dev, shape):
     b = (torch.rand(cout, generator=g) - 0.5).to(dev)
     outs = []
     try:
-        for mode, shift in ((0, -1), (1, -1), (1, 0), (1, 15), (1, 31)):      # per-tile kernel; persistent with the automatic / forced tile-grid shifts
+        # per-tile kernel; persistent with the automatic / forced tile-grid shifts, 16-byte staging loads (odd shifts, widths that
+        # are multiples of 4) and the 4-byte path
+        for mode, shift, v4 in ((0, -1, 1), (1, -1, 1), (1, 0, 1), (1, 15, 1), (1, 31, 1), (1, 15, 0), (1, 3, 1)):
             hip.lib().fldr_debug_s2_persistent(mode)
             hip.lib().fldr_debug_s2_xshift(shift)
+            hip.lib().fldr_debug_s2_vec4(v4)
             o, sp = hip.conv2d(srcs, wt, b, stride=2, relu=True, precision="split", want_spk=True)
             outs.append((o.clone(), sp.buf.clone()))
     finally:
         hip.lib().fldr_debug_s2_persistent(1)
         hip.lib().fldr_debug_s2_xshift(-1)
+        hip.lib().fldr_debug_s2_vec4(1)
     for k in range(1, len(outs)):
         assert torch.equal(outs[0][0], outs[k][0]) and torch.equal(outs[0][1], outs[k][1]), k
     # the packed twin is the split of the fp32 output, padding channels of the last group included (zeros, never

@@ -71,11 +71,11 @@ def s2():
         xs = [torch.rand(1, cin, h, w, device=dev) * 2 - 1 for _ in range(3)]      # rotated: 3 x 0.9 GB > Infinity Cache
         wt = torch.randn(cout, cin, 4, 4, device=dev) / 20; b = torch.randn(cout, device=dev)
         row = []
-        for sh in (0, 15, 31):
-            L.fldr_debug_s2_xshift(sh)
-            row.append("shift %2d: %.1f us" % (sh, timeit(lambda i: hip.conv2d([xs[i % 3]], wt, b, stride=2, relu=True, precision="split", want_f32=True, want_spk=True))))
+        for sh, v4 in ((0, 1), (15, 0), (15, 1), (31, 1)):
+            L.fldr_debug_s2_xshift(sh); L.fldr_debug_s2_vec4(v4)
+            row.append("shift %2d%s: %.1f us" % (sh, " 16-B loads" if v4 and sh & 1 else "", timeit(lambda i: hip.conv2d([xs[i % 3]], wt, b, stride=2, relu=True, precision="split", want_f32=True, want_spk=True))))
         print("%d->%d @%dx%d  " % (cin, cout, h, w) + " | ".join(row), flush=True)
-    L.fldr_debug_s2_xshift(-1)
+    L.fldr_debug_s2_xshift(-1); L.fldr_debug_s2_vec4(1)
 
 
 def dec3():
