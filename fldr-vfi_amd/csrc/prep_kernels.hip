@@ -25,6 +25,7 @@ struct PrepArgs {
     float sy, sx, mul, inv_wm1, inv_hm1, r_wm1, r_hm1, za0, za1;     // inv_*: the grid normalisation divisors max(S-1,1); r_*: their reciprocals
     int withmask;
     int phase;                     // bit 0: z0 / z1 + flow_t0 / flow_t1; bit 1: flowback_0 / _1 + im0_tot / im1_tot (3 = everything)
+    int vec_ok;                    // W % 4 == 0 and every output plane 16-byte aligned: 16-byte stores
 };
 
 // Uniform base pointer + 32-bit byte offset: one global_load / global_store with an SGPR base and a VGPR offset, no 64-bit
@@ -145,83 +146,131 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
     lo2[(int64_t)(N + n) * hw + i] = make_float2(p[2 * hw], p[3 * hw]);
 }
 
+// Optional output path (PREP_LDS_STORES): the 16 values of a pixel go to an LDS tile [plane][4 rows][64 pixels]; after one
+// barrier the workgroup writes every plane's tile as 16-byte pieces instead of 4-byte lanes straight from the pixel's thread.
+// The persistent encoders gained 10 % from 16-byte lanes; this kernel does not (it is bound by its ~1,000 vector
+// instructions per pixel, not by its stores), and the 16 KB of LDS cost throughput beside the other streams' kernels.
+#define PREP_NPL 16                // z0, z1, flow_t0 (x, y), flow_t1, flowback_0, flowback_1, im0_tot (3), im1_tot (3)
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
-    const int px = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int py = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float tile[PREP_NPL][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int px = blockIdx.x * 64 + tx;
+    const int py = blockIdx.y * 4 + ty;
     const int n = blockIdx.z;
-    if (px >= a.W || py >= a.H) return;
+    const bool live = px < a.W && py < a.H;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
-    const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;      // byte offset of this pixel inside a plane
-    const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;       // flow_10 (x,y)
-    const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;   // flow_01 (x,y); quad channels: 0,1 = flow_10, 2,3 = flow_01
-    const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
-    const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
-    const float tv = a.t[n], omt = 1.0f - tv;
-
     const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;        // uniform
-    // the frames at this pixel (direct reads, issued first; only the splat metrics use them)
-    float c0[3] = {0.0f, 0.0f, 0.0f}, c1[3] = {0.0f, 0.0f, 0.0f};
-    if (ph1 && a.z0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { c0[c] = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb); }
-    }
+    const int64_t o1 = (int64_t)n * HW, o2 = (int64_t)n * 2 * HW, o3 = (int64_t)n * 3 * HW;
+    float* const dst[PREP_NPL] = {
+        a.z0 ? a.z0 + o1 : nullptr, a.z1 ? a.z1 + o1 : nullptr,
+        a.flow_t0 + o2, a.flow_t0 + o2 + HW, a.flow_t1 + o2, a.flow_t1 + o2 + HW,
+        a.flowback_0 + o2, a.flowback_0 + o2 + HW, a.flowback_1 + o2, a.flowback_1 + o2 + HW,
+        a.im0_tot + o3, a.im0_tot + o3 + HW, a.im0_tot + o3 + 2 * HW, a.im1_tot + o3, a.im1_tot + o3 + HW, a.im1_tot + o3 + 2 * HW};
+#ifndef PREP_LDS_STORES
+#define PREP_LDS_STORES 0          // measured: the kernel alone 316 vs 321 us, but 433 vs 439 pairs/s with three pairs in flight: off
+#endif
+    const uint32_t pix_off = (__umul24((uint32_t)(live ? py : 0), (uint32_t)a.W) + (uint32_t)(live ? px : 0)) * 4u;
+    auto put = [&](int plane, float v) __attribute__((always_inline)) {
+        if (PREP_LDS_STORES && a.vec_ok) tile[plane][ty][tx] = v;
+        else prep_stf(dst[plane], pix_off, v);                          // 4-byte lanes, straight from the pixel's thread
+    };
+    if (live) {
+        const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;      // byte offset of this pixel inside a plane
+        const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;       // flow_10 (x,y)
+        const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;   // flow_01 (x,y); quad channels: 0,1 = flow_10, 2,3 = flow_01
+        const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
+        const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
+        const float tv = a.t[n], omt = 1.0f - tv;
 
-    // upsampled flows at this pixel (fLDRnet.py:419-422)
-    const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
-    const PrepQuad q = prep_quad(lo10, lo01, a.w, lx, ly);
-    const float f10x = prep_up(q, 0, lx, ly, a.mul, 0, 1.0f), f10y = prep_up(q, 1, lx, ly, a.mul, 0, 1.0f);
-    const float f01x = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f), f01y = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
-
-    // splat metrics (fLDRnet.py:442-446 = zmetric_kernel): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10)
-    if (ph1 && a.z0) {
-        const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-        const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-        const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
-        float acc0 = 0.0f, acc1 = 0.0f;
+        // the frames at this pixel (direct reads, issued first; only the splat metrics use them)
+        float c0[3] = {0.0f, 0.0f, 0.0f}, c1[3] = {0.0f, 0.0f, 0.0f};
+        if (ph1 && a.z0) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float w0 = fldr_tap_sample_p(t0, i1 + (int64_t)c * a.i1_cstride) * m0;
-            const float w1 = fldr_tap_sample_p(t1, i0 + (int64_t)c * a.i0_cstride) * m1;
-            acc0 += a.za0 * fabsf(c0[c] - w0);
-            acc1 += a.za1 * fabsf(c1[c] - w1);
+            for (int c = 0; c < 3; ++c) { c0[c] = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb); }
         }
-        prep_stf(a.z0 + (int64_t)n * HW, pixb, fldr_div_by(acc0, 3.0f, 1.0f / 3.0f));      // == acc0 / 3.0f (the mean over the 3 channels)
-        prep_stf(a.z1 + (int64_t)n * HW, pixb, fldr_div_by(acc1, 3.0f, 1.0f / 3.0f));
-    }
 
-    // t-scaled forward flows (fLDRnet.py:404-405,419-422): upsampling of (t * flow_01_lo) and ((1-t) * flow_10_lo)
-    const int64_t o2 = (int64_t)n * 2 * HW;                     // (uniform: plane bases below are scalar)
-    if (ph1) {
-        prep_stf(a.flow_t0 + o2, pixb, prep_up(q, 2, lx, ly, a.mul, 1, tv));
-        prep_stf(a.flow_t0 + o2 + HW, pixb, prep_up(q, 3, lx, ly, a.mul, 1, tv));
-        prep_stf(a.flow_t1 + o2, pixb, prep_up(q, 0, lx, ly, a.mul, 1, omt));
-        prep_stf(a.flow_t1 + o2 + HW, pixb, prep_up(q, 1, lx, ly, a.mul, 1, omt));
-    }
-    if (!ph2) return;
+        // upsampled flows at this pixel (fLDRnet.py:419-422)
+        const PrepLin lx = prep_lin(px, a.sx, a.w), ly = prep_lin(py, a.sy, a.h);
+        const PrepQuad q = prep_quad(lo10, lo01, a.w, lx, ly);
+        const float f10x = prep_up(q, 0, lx, ly, a.mul, 0, 1.0f), f10y = prep_up(q, 1, lx, ly, a.mul, 0, 1.0f);
+        const float f01x = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f), f01y = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
 
-    // backward flows (fLDRnet.py:474-475 = bwarp_kernel with scales): flowback_0 = bwarp(t * flow_10, (1-t) * flow_01),
-    // flowback_1 = bwarp((1-t) * flow_01, t * flow_10)
-    const FldrTap tb0 = fldr_grid_tap((float)px, (float)py, omt * f01x, omt * f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
-    const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
-    const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
-    const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
-    float fb0x, fb0y, fb1x, fb1y;
-    prep_sample_up2(tb0, tb0p, lo10, a, tv, fb0x, fb0y);
-    prep_sample_up2(tb1, tb1p, lo01, a, omt, fb1x, fb1y);
-    fb0x = fb0x * mb0; fb0y = fb0y * mb0; fb1x = fb1x * mb1; fb1y = fb1y * mb1;
-    prep_stf(a.flowback_0 + o2, pixb, fb0x); prep_stf(a.flowback_0 + o2 + HW, pixb, fb0y);
-    prep_stf(a.flowback_1 + o2, pixb, fb1x); prep_stf(a.flowback_1 + o2 + HW, pixb, fb1y);
-
-    // backward-warped frames (fLDRnet.py:478-479 = bwarp_kernel)
-    const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb0x, fb0y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-    const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb1x, fb1y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-    const float mi0 = a.withmask ? fldr_tap_mask_p(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1) : 1.0f;
-    const int64_t o3 = (int64_t)n * 3 * HW;
+        // splat metrics (fLDRnet.py:442-446 = zmetric_kernel): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10)
+        if (ph1 && a.z0) {
+            const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f01x, f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, f10x, f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
+            float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        prep_stf(a.im0_tot + o3 + (int64_t)c * HW, pixb, fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0);
-        prep_stf(a.im1_tot + o3 + (int64_t)c * HW, pixb, fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1);
+            for (int c = 0; c < 3; ++c) {
+                const float w0 = fldr_tap_sample_p(t0, i1 + (int64_t)c * a.i1_cstride) * m0;
+                const float w1 = fldr_tap_sample_p(t1, i0 + (int64_t)c * a.i0_cstride) * m1;
+                acc0 += a.za0 * fabsf(c0[c] - w0);
+                acc1 += a.za1 * fabsf(c1[c] - w1);
+            }
+            put(0, fldr_div_by(acc0, 3.0f, 1.0f / 3.0f));          // == acc0 / 3.0f (the mean over the 3 channels)
+            put(1, fldr_div_by(acc1, 3.0f, 1.0f / 3.0f));
+        }
+
+        // t-scaled forward flows (fLDRnet.py:404-405,419-422): upsampling of (t * flow_01_lo) and ((1-t) * flow_10_lo)
+        if (ph1) {
+            put(2, prep_up(q, 2, lx, ly, a.mul, 1, tv));
+            put(3, prep_up(q, 3, lx, ly, a.mul, 1, tv));
+            put(4, prep_up(q, 0, lx, ly, a.mul, 1, omt));
+            put(5, prep_up(q, 1, lx, ly, a.mul, 1, omt));
+        }
+        if (ph2) {
+            // backward flows (fLDRnet.py:474-475 = bwarp_kernel with scales): flowback_0 = bwarp(t * flow_10, (1-t) * flow_01),
+            // flowback_1 = bwarp((1-t) * flow_01, t * flow_10)
+            const FldrTap tb0 = fldr_grid_tap((float)px, (float)py, omt * f01x, omt * f01y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+            const FldrTap tb1 = fldr_grid_tap((float)px, (float)py, tv * f10x, tv * f10y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+            const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
+            const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
+            float fb0x, fb0y, fb1x, fb1y;
+            prep_sample_up2(tb0, tb0p, lo10, a, tv, fb0x, fb0y);
+            prep_sample_up2(tb1, tb1p, lo01, a, omt, fb1x, fb1y);
+            fb0x = fb0x * mb0; fb0y = fb0y * mb0; fb1x = fb1x * mb1; fb1y = fb1y * mb1;
+            put(6, fb0x); put(7, fb0y); put(8, fb1x); put(9, fb1y);
+
+            // backward-warped frames (fLDRnet.py:478-479 = bwarp_kernel)
+            const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb0x, fb0y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap((float)px, (float)py, fb1x, fb1y, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const float mi0 = a.withmask ? fldr_tap_mask_p(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1) : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                put(10 + c, fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0);
+                put(13 + c, fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1);
+            }
+        }
+    }
+    if (!PREP_LDS_STORES) return;
+    __syncthreads();
+
+    // ---- the planes of this launch, written as rows of the 64 x 4 tile ----
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    if (PREP_LDS_STORES && a.vec_ok) {                                // uniform: 16-byte pieces (W % 4 == 0, plane bases 16-byte aligned: host-checked)
+        // wave w writes planes w, w + 4, w + 8, w + 12; lane -> (row, quad) of the 4 x 64 tile: one 16-byte store per lane and plane
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+        const int r = lane >> 4, c4 = (lane & 15) * 4;
+        const bool ok = y0 + r < a.H && x0 + c4 < a.W;
+#pragma unroll
+        for (int pass = 0; pass < PREP_NPL / 4; ++pass) {
+            const int pl = pass * 4 + wave;                               // wave-uniform
+            const bool on = pl < 2 ? (ph1 && a.z0 != nullptr) : (pl < 6 ? ph1 : ph2);
+            float* d = dst[0];
+#pragma unroll
+            for (int k = 0; k < PREP_NPL; ++k) d = pl == k ? dst[k] : d;  // (scalar select chain: no dynamically indexed pointer array in scratch)
+            if (!on || !ok) continue;
+            typedef float prep_f4 __attribute__((ext_vector_type(4)));
+            const prep_f4 v = *reinterpret_cast<const prep_f4*>(&tile[pl][r][c4]);
+            prep_f4* o = reinterpret_cast<prep_f4*>(d + (int64_t)(y0 + r) * a.W + x0 + c4);
+#if PREP_NT
+            __builtin_nontemporal_store(v, o);
+#else
+            *o = v;
+#endif
+        }
     }
 }
 
@@ -240,6 +289,12 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     a.r_wm1 = 1.0f / a.inv_wm1; a.r_hm1 = 1.0f / a.inv_hm1;
     a.za0 = d->z_alpha0; a.za1 = d->z_alpha1; a.withmask = d->withmask;
     a.phase = (d->phase & 3) ? (d->phase & 3) : 3;
+    {
+        const void* outs[8] = {d->z0, d->z1, d->flow_t0, d->flow_t1, d->flowback_0, d->flowback_1, d->im0_tot, d->im1_tot};
+        bool v = (d->W & 3) == 0;
+        for (const void* o : outs) v = v && (reinterpret_cast<uintptr_t>(o) & 15) == 0;
+        a.vec_ok = v ? 1 : 0;
+    }
     const int64_t hw = (int64_t)d->h * d->w;
     if (!(d->phase & 4))                                          // bit 2: d->ws already holds the interleaved flow (second phase of a split call)
         hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
