@@ -757,6 +757,13 @@ static int ring_pick_tile_width(const SpkArgs& a, int N, int wgs_per_xcd_max) {
 template <int NMT, int TERMS, bool HAS_RES>
 static int ring_launch2(SpkArgs& a, int N, int wpx, hipStream_t s) {
     if (g_ring_consumers == 4) return ring_launch3<NMT, TERMS, HAS_RES, 4, 32>(a, N, wpx, s);
+    if constexpr (NMT == 1 && TERMS == 3) {
+        // 16 output channels at a large resolution (dec2: 48 -> 16 at half the frame size): with one 16-channel block every MFMA
+        // needs one LDS operand read when a wave owns one tile row (8 consumers), 0.83 when it owns two (4 consumers), and the
+        // LDS array, not the matrix pipe, paces the kernel: 170.7 vs 151.1 us at 1152x1920 (tools/kernel_bench.py conv).
+        const int64_t units = (int64_t)N * fldr_cdiv(a.W, SPK_TW) * fldr_cdiv(a.H, SPK_TH) * a.groups;
+        if (g_ring_consumers == 8 && g_ring_tile_width == 0 && units >= 32ll * wpx) return ring_launch3<NMT, TERMS, HAS_RES, 4, 32>(a, N, wpx, s);
+    }
     if constexpr (TERMS == 3) {
         if (ring_pick_tile_width(a, N, wpx) == 16) return ring_launch3<NMT, TERMS, HAS_RES, 8, 16>(a, N, wpx, s);
     }

@@ -419,6 +419,11 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
                 const int cc = cbase + c < C ? cbase + c : C - 1;
                 val[buf][r][c] = __builtin_nontemporal_load(&inn[(int64_t)cc * in_cstride + pix]);
             }
+#elif defined(BAND_ABLATE) && BAND_ABLATE == 1                         // diagnostic: only the flow is read
+            fx[buf][r] = fl[pix]; fy[buf][r] = fl[HW + pix];
+            mv[buf][r] = 0.25f;
+#pragma unroll
+            for (int c = 0; c < CB; ++c) val[buf][r][c] = 0.5f;
 #else
             fx[buf][r] = fl[pix]; fy[buf][r] = fl[HW + pix];
             mv[buf][r] = 0.0f;
