@@ -735,7 +735,7 @@ static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
 }
 
 // Tile width of a launch.  Persistent workgroups (one per CU) walk the units in rounds; a launch whose 8 x 32 tiles leave the
-// last round nearly empty (the second pyramid level of a 4K pair: 272 units on 256 workgroups = two rounds for 1.06 rounds
+// last round nearly empty (the second pyramid level of a 4K pair: 288 units on 256 workgroups = two rounds for 1.13 rounds
 // of work) runs 8 x 16 tiles instead when that is cheaper: twice the units, each costing RING_NARROW_COST of a wide one (half
 // the matrix work under the same weight stream).  Same arithmetic per output pixel: bit-identical results.
 #ifndef RING_NARROW_COST
@@ -751,7 +751,7 @@ static int ring_pick_tile_width(const SpkArgs& a, int N, int wgs_per_xcd_max) {
     const int64_t u32 = (int64_t)N * fldr_cdiv(a.W, 32) * ty * a.groups, u16 = (int64_t)N * fldr_cdiv(a.W, 16) * ty * a.groups;
     if (u32 <= wgs / 2) return 32;                                       // launches that do not fill the chip either way
     const double c32 = (double)((u32 + wgs - 1) / wgs), c16 = (double)((u16 + wgs - 1) / wgs) * RING_NARROW_COST;
-    return c16 < 0.97 * c32 ? 16 : 32;
+    return c16 < c32 ? 16 : 32;
 }
 
 template <int NMT, int TERMS, bool HAS_RES>

@@ -52,10 +52,10 @@ def conv_cold():
 
 
 def conv_tw():
-    """8x32 against 8x16 tiles of the ring pipeline at the second pyramid level of a 4K pair (136x240: 272 wide units on 256
+    """8x32 against 8x16 tiles of the ring pipeline at the second pyramid level of a 4K pair (144x240: 288 wide units on 256
     persistent workgroups) and at level 0."""
-    for (n, cin, cout, h, w) in [(1, 96, 96, 136, 240), (2, 96, 48, 136, 240), (1, 96, 48, 136, 240), (1, 48, 48, 136, 240), (1, 96, 96, 272, 480),
-                                 (1, 96, 96, 68, 120), (1, 96, 32, 544, 960), (1, 48, 16, 1088, 1920), (1, 96, 96, 144, 256), (1, 96, 96, 288, 512)]:
+    for (n, cin, cout, h, w) in [(1, 96, 96, 144, 240), (2, 96, 48, 144, 240), (1, 96, 48, 144, 240), (1, 48, 48, 144, 240), (1, 96, 96, 288, 480),
+                                 (1, 96, 96, 72, 120), (1, 96, 32, 576, 960), (1, 48, 16, 1152, 1920), (1, 96, 96, 144, 256), (1, 96, 96, 288, 512)]:
         xs = [hip.spk_pack(torch.rand(n, cin, h, w, device=dev)) for _ in range(3)]
         w2 = torch.randn(cout, cin, 3, 3, device=dev) / 30
         row = []
