@@ -81,7 +81,7 @@ def test_function_softsplat_modes(hip, oracle, dev, mode):
         _cmp(out, oracle.function_softsplat(x, flow, None, mode), atol=3e-5, what="softmax no metric")
 
 
-@pytest.mark.parametrize("shape", [(1, 9, 15, 8, 0.5), (2, 12, 20, 8, 0.125), (1, 36, 60, 4, 0.875)])
+@pytest.mark.parametrize("shape", [(1, 9, 15, 8, 0.5), (2, 12, 20, 8, 0.125), (1, 36, 60, 4, 0.875), (1, 11, 14, 3, 0.3), (1, 7, 9, 2, 0.6), (1, 10, 6, 16, 0.5)])
 def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
     """fldr_level0_prep (one pass) against the kernels it fuses: resize_bilinear, zmetric, bwarp_tscaled, bwarp."""
     N, h, w, up, tv = shape
