@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
 #pragma clang fp contract(off)
     constexpr int CA = MODE >= 1 ? CB + 1 : CB;
     constexpr int CELLS = TW * TH;
-    __shared__ float acc_all[4][CA * CELLS];
+    __shared__ __attribute__((aligned(16))) float acc_all[4][CA * CELLS];
     __shared__ unsigned char claim_all[4][CELLS];                 // lane ids (< 64)
     __shared__ unsigned short sbl_all[4][SB_LIST];                // matching super-blocks of each wave (nsb < 65536: host-checked)
     const int lane = threadIdx.x & 63;
@@ -362,6 +362,10 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
     const int tx0 = blockIdx.x * TW, ty0 = (blockIdx.y * 4 + wv) * TH;
     if (ty0 >= H) return;                                         // wave-uniform; the kernel has no workgroup barrier
     float* acc = acc_all[wv];
+    // accumulator of (channel c, cell): cell-major when a cell's CA values are one 16-byte record (the image splat: 3 channels
+    // + the normalisation sum), so that a read-modify-write of a cell is ONE ds_read_b128 + ONE ds_write_b128 instead of
+    // four of each; channel-major otherwise
+    auto ai = [](int c, int cell) __attribute__((always_inline)) { return CA == 4 ? cell * 4 + c : c * CELLS + cell; };
     volatile unsigned char* claim = claim_all[wv];                // volatile: the write / read-back pair must reach the LDS
     unsigned short* sbl = sbl_all[wv];
     const int64_t HW = (int64_t)H * W;
@@ -391,9 +395,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
             if (owner) {
                 float cur[CA];
 #pragma unroll
-                for (int c = 0; c < CA; ++c) cur[c] = acc[c * CELLS + cell];
+                for (int c = 0; c < CA; ++c) cur[c] = acc[ai(c, cell)];
 #pragma unroll
-                for (int c = 0; c < CA; ++c) acc[c * CELLS + cell] = cur[c] + v[c] * w;
+                for (int c = 0; c < CA; ++c) acc[ai(c, cell)] = cur[c] + v[c] * w;
             }
             pending = pending && !owner;
         }
@@ -442,9 +446,9 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
         if (active) {
             float cur[CA];
 #pragma unroll
-            for (int c = 0; c < CA; ++c) cur[c] = acc[c * CELLS + cell];
+            for (int c = 0; c < CA; ++c) cur[c] = acc[ai(c, cell)];
 #pragma unroll
-            for (int c = 0; c < CA; ++c) acc[c * CELLS + cell] = cur[c] + v[c];
+            for (int c = 0; c < CA; ++c) acc[ai(c, cell)] = cur[c] + v[c];
         }
     };
 
@@ -707,11 +711,11 @@ __global__ __launch_bounds__(256) void splat_band_kernel(const float* __restrict
         const int x = tx0 + i % TW, y = ty0 + i / TW;
         if (x >= W || y >= H) continue;
         float norm = 1.0f;
-        if (MODE >= 1) { norm = acc[CB * CELLS + i]; if (norm == 0.0f) norm = 1.0f; }
+        if (MODE >= 1) { norm = acc[ai(CB, i)]; if (norm == 0.0f) norm = 1.0f; }
 #pragma unroll
         for (int c = 0; c < CB; ++c) {
             if (cbase + c >= C) break;
-            float v = acc[c * CELLS + i];
+            float v = acc[ai(c, i)];
             if (MODE >= 1) v = v / norm;
 #if defined(BAND_NT) && (BAND_NT & 1)
             __builtin_nontemporal_store((v - 0.5f) * 2.0f, &on[(int64_t)(cbase + c) * HW + (int64_t)y * W + x]);
