@@ -193,7 +193,14 @@ def _check(code, what):
         raise FldrError("%s failed: %s (code %d)" % (what, lib().fldr_error_string(code).decode(), code))
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """Handle of torch's current HIP stream.  Called once per launch (~90 per forward): the raw getter costs ~0.3 us against
+    ~3 us for building a torch.cuda.Stream object (the coarse pyramid levels are paced by the host's time per launch)."""
+    if _raw_stream is not None:
+        return ctypes.c_void_p(_raw_stream(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
