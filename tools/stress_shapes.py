@@ -16,14 +16,14 @@ for it in range(40):
     srcs = [torch.randn(N, c, H, W, device=dev) for c in parts]
     wt = torch.randn(cout, cin, 4, 4, device=dev) / 8; b = torch.randn(cout, device=dev)
     outs = []
-    for mode in (0, 1):
-        hip.lib().fldr_debug_s2_persistent(mode)
+    for mode, shift, v4 in ((0, -1, 1), (1, -1, 1), (1, 15, 1), (1, 15, 0), (1, random.choice([1, 3, 7, 31]), 1)):   # per-tile; persistent: auto, 16-byte / 4-byte staging, odd shifts
+        hip.lib().fldr_debug_s2_persistent(mode); hip.lib().fldr_debug_s2_xshift(shift); hip.lib().fldr_debug_s2_vec4(v4)
         o, sp = hip.conv2d(srcs, wt, b, stride=2, relu=bool(it & 1), precision="split", want_spk=True)
         outs.append((o.clone(), sp.buf.clone()))
-    ok = torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ok = all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
     bad += not ok
     if not ok: print("s2 MISMATCH", N, parts, cout, H, W)
-hip.lib().fldr_debug_s2_persistent(1)
+hip.lib().fldr_debug_s2_persistent(1); hip.lib().fldr_debug_s2_xshift(-1); hip.lib().fldr_debug_s2_vec4(1)
 print("stride-2 persistent vs per-tile: 40 shapes,", bad, "mismatches", flush=True)
 bad = 0
 for it in range(30):
@@ -40,7 +40,7 @@ for it in range(30):
 print("band vs strip splat: 30 shapes,", bad, "mismatches", flush=True)
 bad = 0
 for it in range(20):
-    N = random.choice([1, 2]); h = random.choice([1, 2, 3, 9, 20]); w = random.choice([1, 2, 5, 15, 33]); up = random.choice([2, 4, 8])
+    N = random.choice([1, 2]); h = random.choice([1, 2, 3, 9, 20]); w = random.choice([1, 2, 5, 15, 33]); up = random.choice([2, 3, 4, 5, 8])
     H, W = h * up, w * up
     if W < 2: continue
     lo = (torch.rand(N, 4, h, w, device=dev) - 0.5) * random.choice([1.0, 6.0, 50.0])
@@ -54,6 +54,11 @@ for it in range(20):
     fb0 = hip.bwarp_tscaled(f10, f01, t4, "t", "1-t", withmask=bool(it & 1)); fb1 = hip.bwarp_tscaled(f01, f10, t4, "1-t", "t", withmask=bool(it & 1))
     ok = ok and torch.equal(r["flowback_0"], fb0) and torch.equal(r["flowback_1"], fb1)
     ok = ok and torch.equal(r["im0_tot"], hip.bwarp(I0c, fb0, bool(it & 1))) and torch.equal(r["im1_tot"], hip.bwarp(I1c, fb1, bool(it & 1)))
+    # the splat run on the bounds table made from the low-resolution flow equals the exact-bounds splat up to summation order
+    for img, flow, z, lo2, sm in ((I0, r["flow_t0"], r["z0"], lo[:, 2:], 1), (I1, r["flow_t1"], r["z1"], lo[:, :2], 2)):
+        ws = hip.splat_bounds_upsampled(lo2, t4, sm, float(up), H, W)
+        e1 = (hip.softsplat_fused(img, flow, z, "softmax", bounds_ws=ws) - hip.softsplat_fused(img, flow, z, "softmax", kernel="tile")).abs().max().item()
+        ok = ok and e1 <= 4e-6
     bad += not ok
     if not ok: print("prep MISMATCH", N, h, w, up)
 print("level0_prep vs unfused kernels: 20 shapes,", bad, "mismatches", flush=True)
@@ -73,13 +78,13 @@ for it in range(40):
     ref = hip.conv2d(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, precision="split")
     for su in (-1, 96):
         hip.lib().fldr_debug_spk_small_units(su)
-        for variant, cons in ((0, 8), (1, 4), (1, 8)):          # barrier pipeline, ring with 4 / 8 consumer waves
-            hip.lib().fldr_debug_spk_variant(variant); hip.lib().fldr_debug_ring_consumers(cons)
+        for variant, cons, tw in ((0, 8, 0), (1, 4, 0), (1, 8, 32), (1, 8, 16), (1, 8, 0)):   # barrier pipeline; ring with 4 consumers, 8 on 8x32 / 8x16 tiles / picked per launch
+            hip.lib().fldr_debug_spk_variant(variant); hip.lib().fldr_debug_ring_consumers(cons); hip.lib().fldr_debug_ring_tile_width(tw)
             got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=ups, want_f32=True, want_spk=True)
             ok = torch.equal(ref, got) and torch.equal(hip.spk_pack(ref).buf, gp.buf)
             bad += not ok
-            if not ok: print("spk MISMATCH", N, cs, ups, cout, cst, H, W, relu, res, "small_units", su, "variant", variant, cons)
-hip.lib().fldr_debug_spk_small_units(96); hip.lib().fldr_debug_spk_variant(1); hip.lib().fldr_debug_ring_consumers(8)
+            if not ok: print("spk MISMATCH", N, cs, ups, cout, cst, H, W, relu, res, "small_units", su, "variant", variant, cons, tw)
+hip.lib().fldr_debug_spk_small_units(96); hip.lib().fldr_debug_spk_variant(1); hip.lib().fldr_debug_ring_consumers(8); hip.lib().fldr_debug_ring_tile_width(0)
 bad += hip.lib().fldr_debug_ring_timeouts() != 0
 print("split-packed conv (3 pipelines) vs split conv: 40 shapes x 2 unit policies,", bad, "mismatches", flush=True)
 
