@@ -280,8 +280,9 @@ def main():
     barrier()
     dt_local = time.perf_counter() - t0
     # ---- sustained rate: the same loop for >= --sustained-s seconds (clocks settle, caches in steady state) ---
+    dt = max_over_ranks(dt_local, device)
     if gpu and a.sustained_s > 0:
-        n_s = max(a.steps, int(a.sustained_s / max(dt_local / a.steps, 1e-5)) + 1)
+        n_s = max(a.steps, int(a.sustained_s / max(dt / a.steps, 1e-5)) + 1)      # the same step count on every rank
         barrier()
         sync()
         t1 = time.perf_counter()
@@ -327,7 +328,6 @@ def main():
                              "pairs_per_s_this_gpu": round(a.fp16_mode_steps / d5, 2)}
             finally:
                 fldr_hip.CONV_PRECISION = prev
-    dt = max_over_ranks(dt_local, device)
     per_rank = gather_floats(a.steps / dt_local, device)
 
     if rank == 0:
