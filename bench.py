@@ -47,6 +47,7 @@ def parse():
                     help="independent frame-pair forwards kept in flight on separate HIP streams (1 = strictly serial)")
     ap.add_argument("--pairs", type=int, default=4, help="distinct frame pairs rotated through the timed loop (>= streams)")
     ap.add_argument("--sustained-s", type=float, default=3.0, help="length of the extra sustained-rate measurement (0 = skip)")
+    ap.add_argument("--varying-motion-steps", type=int, default=60, help="steps of the informational run on pairs with a smoothly varying motion field (0 = skip)")
     ap.add_argument("--fp16-mode-steps", type=int, default=60, help="steps of the informational fp16-input convolution run (BASELINE config 5; 0 = skip)")
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
@@ -229,7 +230,7 @@ def main():
 
     npairs = max(a.pairs, a.streams, 1)
     my_pairs = shard_pairs(world * npairs, rank, world)          # pair index = seed; disjoint across ranks
-    latency_ms = dt_e2e = sustained = fp16_mode = None
+    latency_ms = dt_e2e = sustained = fp16_mode = varying = None
     if gpu:
         import fldr_harness as Hn
         model, _, args = Hn.prepare_model(device)
@@ -310,6 +311,31 @@ def main():
         fldr_hip.check_range()                         # no activation left the range of the fp16 hi/lo split (would raise)
         # BASELINE config 5 (informational; never `value`): the same loop with plain fp16 convolution inputs (one MFMA per
         # product instead of three; ~74 dB against the fp32-class frame, tests/test_gpu_parity.py::test_fp16_conv_path_config5)
+        # Informational (never `value`): the same loop on pairs under a smoothly varying motion (zoom + rotation + shift,
+        # fldr_harness.synthetic_pair_varying) instead of the global shift of the headline pairs — the scatter kernels'
+        # cost depends on the flow field.
+        varying = None
+        if rank == 0 and a.varying_motion_steps > 0:
+            with torch.no_grad():
+                vf = [Hn.frames_from_uint8(Hn.synthetic_pair_varying(a.height, a.width, seed=100 + k)).to(device) for k in range(2)]
+                vp = [Hn.build_pyramid(Hn.pad_frames(f, args), args) for f in vf]
+
+            def vstep(i):
+                with torch.cuda.stream(streams[i % len(streams)]), torch.no_grad():
+                    return Hn.interpolate(model, args, vf[i % 2], t, pyramid=vp[i % 2])
+            for i in range(2 * len(streams)):
+                vout = vstep(i)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(a.varying_motion_steps):
+                vout = vstep(i)
+            sync()
+            dv = time.perf_counter() - t1
+            assert torch.isfinite(vout).all()
+            varying = {"what": "the same loop on pairs under a smoothly varying motion field (1.2 % zoom + 0.25 deg rotation + shift; "
+                               "2 distinct pairs): reported for reference only", "steps": a.varying_motion_steps,
+                       "ms_per_step": round(dv / a.varying_motion_steps * 1e3, 3), "pairs_per_s_this_gpu": round(a.varying_motion_steps / dv, 2)}
+            del vf, vp
         fp16_mode = None
         if rank == 0 and a.fp16_mode_steps > 0:
             prev = fldr_hip.CONV_PRECISION
@@ -355,6 +381,8 @@ def main():
                 res["sustained"] = sustained
             if fp16_mode:
                 res["fp16_conv_mode"] = fp16_mode
+            if varying:
+                res["varying_motion"] = varying
             res["roofline"] = dominant_conv_roofline(model, hp[0] // 8, hp[1] // 8, device, a.steps)
             pm = PATH_MODEL.get((a.height, a.width))
             if pm:
