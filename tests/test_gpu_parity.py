@@ -683,6 +683,23 @@ def test_model_matches_oracle_odd_sizes(hip, oracle, weights, dev, model, case):
     assert (out.cpu() - ref).abs().mean().item() <= 1e-6
 
 
+@pytest.mark.parametrize("case", [(256, 384, 0.5, 11), (200, 456, 0.25, 12)])
+def test_model_matches_oracle_varying_motion(hip, oracle, weights, dev, model, case):
+    """Pairs under a smoothly varying motion field (zoom + rotation + shift: the flow changes from pixel to pixel, sources of
+    one row land on several target rows) instead of the global / per-quadrant shifts of the other whole-model cases."""
+    import fldr_harness as Hn
+    H, W, tv, seed = case
+    m, a = model
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair_varying(H, W, seed=seed))
+    t = torch.tensor([[tv]])
+    out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)[..., :H, :W]
+    err = _cmp(out, ref, atol=1e-4, what="varying motion %dx%d" % (H, W))
+    print("%dx%d varying motion: max|err| %.2e" % (H, W, err))
+    assert (out.cpu() - ref).abs().mean().item() <= 1e-6
+
+
 # ---------------------------------------------------------------------------------------------------
 # full-size (BASELINE config 2: 3840x2160) checks
 # ---------------------------------------------------------------------------------------------------
