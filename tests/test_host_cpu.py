@@ -247,3 +247,17 @@ def test_markstein_quotient_is_the_correctly_rounded_fp64_division():
             assert q2 == float(Fr(x) / Fr(c)), (x, c, q2)
             checked += 1
     assert checked > 10000
+
+
+def test_synthetic_pairs_are_seeded_and_differ_by_motion_model():
+    """bench.py's workloads: the global-shift pairs of the headline and the varying-motion pairs of its `varying_motion`
+    record are deterministic functions of the seed, uint8 [2,3,H,W], and the second frame really moves."""
+    import torch
+    import fldr_harness as Hn
+    a, b = Hn.synthetic_pair(64, 96, seed=3), Hn.synthetic_pair(64, 96, seed=3)
+    v, w = Hn.synthetic_pair_varying(64, 96, seed=3), Hn.synthetic_pair_varying(64, 96, seed=3)
+    for x in (a, v):
+        assert x.shape == (2, 3, 64, 96) and x.dtype == torch.uint8
+    assert torch.equal(a, b) and torch.equal(v, w)
+    assert not torch.equal(Hn.synthetic_pair(64, 96, seed=4), a)
+    assert (v[0].float() - v[1].float()).abs().mean().item() > 1.0 and (a[0].float() - a[1].float()).abs().mean().item() > 1.0
