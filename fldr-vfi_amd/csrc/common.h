@@ -62,6 +62,7 @@ int fldr_range_read_s2(int reset);
 int fldr_range_read_split(int reset);
 int fldr_range_read_warp(int reset);
 int fldr_range_read_gather(int reset);
+int fldr_range_read_acc64(int reset);
 
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
 // the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.

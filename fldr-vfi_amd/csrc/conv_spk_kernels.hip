@@ -458,7 +458,7 @@ int fldr_range_read_spk(int reset) { return fldr_tu_range_read(reset); }
 extern "C" int fldr_range_status(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     int v = 0;
-    int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather};
+    int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather, fldr_range_read_acc64};
     for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x; }
     return v;
 }

@@ -1,0 +1,350 @@
+// Softmax splatting (softSplat.py:12-52, 320-352) with destination-owned tiles and FP64 LDS ATOMICS.
+//
+// Measured on gfx950 (tools/ubench/lds_int_atomic_bench.hip, ns per wave-instruction per CU, conflict-free / two lanes per
+// cell / random cells): ds_add_f32 80 / 94 / 80 — the reason the f32 tile kernel of splat_tile_kernels.hip lost to global
+// atomics and the band kernel went to claim rounds and DPP merging (~450 vector instructions per source row) — but
+// ds_add_f64 3.5 / 8.4 / 8.7 and ds_add_u64 2.6 / 5.1 / 4.5: the 64-bit LDS atomics run at (nearly) the plain LDS rate.
+// So: every workgroup owns a TW x TH tile of the output as fp64 accumulators in LDS (channel-major: neighbouring cells are
+// neighbouring 8-byte words, conflict-free for a coherent flow), every source pixel whose footprint can reach the tile adds
+// its four corner contributions (the fp32 products of the reference kernel, softSplat.py:40-51, widened to fp64) with one
+// ds_add_f64 each, and the finished tile is normalised and written once.  No global atomics, no accumulator tensor, no memset,
+// no normalisation pass, no conflict handling — and the fp64 sums make the result independent of the summation order to
+// ~1e-16 relative (run-to-run differences only where a sum lands within that of a rounding boundary of the fp32 output).
+//
+// Candidate sources: the flow-bounds tables of splat_tile_kernels.hip (per 64x4 block and 256x64 super-block; from the flow
+// itself or, for an upsampled flow, from its low-resolution source).  A tile tests the super-blocks, then the blocks of the
+// matching ones, and then walks EITHER the rectangle of source pixels those blocks' joint bounds allow (the normal case: a
+// smooth flow; no overhang beyond the bounds' slack, threads are laid out along the rectangle's rows) OR the queued blocks
+// (scattered candidates).  Queue overflow or too many super-blocks: the rectangle grows to the blocks' bounding box / the
+// image.  Every visited source is re-tested per corner, so any superset of the true candidates gives the exact result.
+#include "splat_common.h"
+
+#define SA_SBQ 64                    // matching super-blocks a tile can list
+#define SA_Q 512                     // matching blocks a tile can queue
+
+typedef _Float16 sa_h8 __attribute__((ext_vector_type(8)));
+
+struct SaProblem {
+    const float* img;                // sample n, channel c at img + n * img_bstride + c * img_cstride; [H,W] planes contiguous
+    const float* flow;               // [N,2,H,W], samples flow_bstride floats apart
+    const float* metric;             // [N,1,H,W] or null
+    const float* blk;                // bounds tables (splat_tile_kernels.hip)
+    const float* sbt;
+    float* out_f32;                  // [N,C,H,W] or null
+    unsigned char* out_spk;          // packed [N,C,H,W] or null
+    int64_t img_bstride, img_cstride, flow_bstride;
+};
+struct SaArgs {
+    SaProblem p[2];
+    int N, C, H, W, groups, nsb_x, nsb;
+};
+
+template <int CB, int U>
+struct SaBuf {
+    int x[U], y[U];
+    bool ok[U];
+    float fx[U], fy[U], mv[U], val[U][CB];
+};
+
+// MODE: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ the normalisation accumulator when
+// MODE >= 1); U source pixels per thread and iteration (all loads of iteration i + 1 are in flight under iteration i).
+template <int MODE, int CB, int TW, int TH, int U>
+__global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
+#pragma clang fp contract(off)
+    constexpr int CA = MODE >= 1 ? CB + 1 : CB;
+    constexpr int CELLS = TW * TH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sa_smem[];
+    double* acc = reinterpret_cast<double*>(sa_smem);                           // [CA][CELLS]
+    int* blkq = reinterpret_cast<int*>(sa_smem + (size_t)CA * CELLS * 8);       // [SA_Q]
+    float* redf = reinterpret_cast<float*>(blkq + SA_Q);                        // [4][4]
+    int* redi = reinterpret_cast<int*>(redf + 16);                              // [4][4]
+    int* cnt = redi + 16;                                                       // [2]
+    unsigned short* sbq = reinterpret_cast<unsigned short*>(cnt + 2);           // [SA_SBQ]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int per_prob = a.N * a.groups;
+    const int prob = blockIdx.z / per_prob;
+    const int rem = blockIdx.z - prob * per_prob;
+    const int n = rem / a.groups, grp = rem - n * a.groups;
+    const SaProblem& P = a.p[prob];
+    const int C = a.C, H = a.H, W = a.W, nsb_x = a.nsb_x, nsb = a.nsb;
+    const int cbase = grp * CB;
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int64_t HW = (int64_t)H * W;
+    const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fty0 = (float)ty0, fty1 = (float)(ty0 + TH - 1);
+    const float INF = __builtin_inff();
+
+    for (int i = tid; i < CA * CELLS / 2; i += 256) reinterpret_cast<double2*>(acc)[i] = make_double2(0.0, 0.0);
+    if ((CA * CELLS) & 1) { if (tid == 0) acc[CA * CELLS - 1] = 0.0; }
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
+
+    // ---- which super-blocks, then which blocks, can reach this tile ----
+    const float* sbn = P.sbt + (int64_t)n * nsb * 4;
+    const float* bkn = P.blk + (int64_t)n * nsb * ST_SB_BLOCKS * 4;
+    for (int s = tid; s < nsb; s += 256) {
+        const float4 b = *reinterpret_cast<const float4*>(sbn + s * 4);
+        const int sx = (s % nsb_x) * (ST_SBX * ST_BW), sy = (s / nsb_x) * (ST_SBY * ST_BH);
+        if (st_match(b, (float)sx, (float)(sx + ST_SBX * ST_BW - 1), (float)sy, (float)(sy + ST_SBY * ST_BH - 1), ftx0, ftx1, fty0, fty1)) {
+            const int i = atomicAdd(&cnt[0], 1);
+            if (i < SA_SBQ) sbq[i] = (unsigned short)s;
+        }
+    }
+    __syncthreads();
+    const int n_sb = cnt[0];
+    const bool sb_over = n_sb > SA_SBQ;                                 // workgroup-uniform
+    float rxmin = INF, rxmax = -INF, rymin = INF, rymax = -INF;         // joint flow bounds of the matching blocks
+    int cx0 = 0x7fffffff, cx1 = -1, cy0 = 0x7fffffff, cy1 = -1;         // their bounding box (pixels, inclusive)
+    if (!sb_over) {
+        for (int i = wv; i < n_sb; i += 4) {                            // one matching super-block per wave, one block per lane
+            const int s = sbq[i];
+            const float4 b = *reinterpret_cast<const float4*>(bkn + ((int64_t)s * ST_SB_BLOCKS + lane) * 4);
+            const int bx = (s % nsb_x) * ST_SBX + (lane % ST_SBX), by = (s / nsb_x) * ST_SBY + (lane / ST_SBX);
+            const int sx = bx * ST_BW, sy = by * ST_BH;
+            if (st_match(b, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fty0, fty1)) {
+                rxmin = fminf(rxmin, b.x); rxmax = fmaxf(rxmax, b.y); rymin = fminf(rymin, b.z); rymax = fmaxf(rymax, b.w);
+                cx0 = min(cx0, sx); cx1 = max(cx1, sx + ST_BW - 1); cy0 = min(cy0, sy); cy1 = max(cy1, sy + ST_BH - 1);
+                const int k = atomicAdd(&cnt[1], 1);
+                if (k < SA_Q) blkq[k] = (by << 16) | bx;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            rxmin = fminf(rxmin, __shfl_xor(rxmin, o)); rxmax = fmaxf(rxmax, __shfl_xor(rxmax, o));
+            rymin = fminf(rymin, __shfl_xor(rymin, o)); rymax = fmaxf(rymax, __shfl_xor(rymax, o));
+            cx0 = min(cx0, __shfl_xor(cx0, o)); cx1 = max(cx1, __shfl_xor(cx1, o));
+            cy0 = min(cy0, __shfl_xor(cy0, o)); cy1 = max(cy1, __shfl_xor(cy1, o));
+        }
+        if (lane == 0) {
+            redf[wv * 4 + 0] = rxmin; redf[wv * 4 + 1] = rxmax; redf[wv * 4 + 2] = rymin; redf[wv * 4 + 3] = rymax;
+            redi[wv * 4 + 0] = cx0; redi[wv * 4 + 1] = cx1; redi[wv * 4 + 2] = cy0; redi[wv * 4 + 3] = cy1;
+        }
+    }
+    __syncthreads();
+
+    // ---- the walk: a rectangle of source pixels, or the queued blocks (everything below is workgroup-uniform) ----
+    int X0 = 0, X1 = W - 1, Y0 = 0, Y1 = H - 1;
+    bool rect = true;
+    int n_chunks = 0;
+    if (!sb_over) {
+        const int n_match = cnt[1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            rxmin = fminf(rxmin, redf[k * 4 + 0]); rxmax = fmaxf(rxmax, redf[k * 4 + 1]);
+            rymin = fminf(rymin, redf[k * 4 + 2]); rymax = fmaxf(rymax, redf[k * 4 + 3]);
+            cx0 = min(cx0, redi[k * 4 + 0]); cx1 = max(cx1, redi[k * 4 + 1]); cy0 = min(cy0, redi[k * 4 + 2]); cy1 = max(cy1, redi[k * 4 + 3]);
+        }
+        if (n_match > 0) {
+            X0 = cx0; X1 = min(cx1, W - 1); Y0 = cy0; Y1 = min(cy1, H - 1);
+            if (fabsf(rxmin) < 1.0e6f && fabsf(rxmax) < 1.0e6f && fabsf(rymin) < 1.0e6f && fabsf(rymax) < 1.0e6f) {   // finite, int-safe
+                // x + fx >= tx0 - 2 and x + fx <= tx1 + 1 for some fx in [rxmin, rxmax]  (st_match for a single pixel)
+                X0 = max(X0, (int)floorf(ftx0 - 2.0f - rxmax)); X1 = min(X1, (int)ceilf(ftx1 + 1.0f - rxmin));
+                Y0 = max(Y0, (int)floorf(fty0 - 2.0f - rymax)); Y1 = min(Y1, (int)ceilf(fty1 + 1.0f - rymin));
+            }
+            const int64_t area = (int64_t)max(X1 - X0 + 1, 0) * max(Y1 - Y0 + 1, 0);
+            rect = n_match > SA_Q || area <= (int64_t)256 * n_match;    // never more pixels than the block walk would visit
+            n_chunks = rect ? (int)((area + 255) / 256) : n_match;
+        }
+    } else {
+        n_chunks = (int)((HW + 255) / 256);
+    }
+    const int Rw = max(X1 - X0 + 1, 1), Rh = max(Y1 - Y0 + 1, 0);
+    // rectangle walk: thread t of chunk k is pixel 256 k + t of the rectangle in row-major order, kept as (column, row)
+    int rx = tid % Rw, ry = tid / Rw;
+    const int dqx = 256 % Rw, dqy = 256 / Rw;
+
+    const float* fl = P.flow + (int64_t)n * P.flow_bstride;
+    const float* mt = P.metric ? P.metric + (int64_t)n * HW : nullptr;
+    const float* inn = P.img + (int64_t)n * P.img_bstride;
+
+    auto load_chunk = [&](SaBuf<CB, U>& b, int u, int k) __attribute__((always_inline)) {
+        int x, y;
+        bool ok;
+        if (rect) {
+            x = X0 + rx; y = Y0 + ry;
+            ok = k < n_chunks && ry < Rh;
+            rx += dqx; ry += dqy;
+            if (rx >= Rw) { rx -= Rw; ++ry; }
+        } else {
+            const int e = blkq[k < n_chunks ? k : 0];
+            x = (e & 0xFFFF) * ST_BW + lane; y = (e >> 16) * ST_BH + wv;
+            ok = k < n_chunks && x < W && y < H;
+        }
+        b.x[u] = x; b.y[u] = y; b.ok[u] = ok;
+        const int64_t pix = ok ? (int64_t)y * W + x : 0;                // clamped: every load below is unconditional
+        b.fx[u] = fl[pix]; b.fy[u] = fl[HW + pix];
+        b.mv[u] = 0.0f;
+        if ((MODE == 2 || MODE == 3) && mt != nullptr) b.mv[u] = mt[pix];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int cc = cbase + c < C ? cbase + c : C - 1;
+            b.val[u][c] = inn[(int64_t)cc * P.img_cstride + pix];
+        }
+    };
+    auto load_iter = [&](SaBuf<CB, U>& b, int k0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_chunk(b, u, k0 + u);
+    };
+    auto process = [&](SaBuf<CB, U>& b) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            fldr_pin(b.fx[u]); fldr_pin(b.fy[u]); fldr_pin(b.mv[u]);
+#pragma unroll
+            for (int c = 0; c < CB; ++c) fldr_pin(b.val[u][c]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!b.ok[u]) continue;
+            const StGeom g = st_geom(b.x[u], b.y[u], b.fx[u], b.fy[u], W, H);
+            const int lx = g.x0 - tx0, ly = g.y0 - ty0;                    // tile-local north-west corner
+            if (lx < -1 || lx >= TW || ly < -1 || ly >= TH) continue;     // footprint misses the tile
+            // a corner counts here when it lies in this tile AND in the image (tile origins are >= 0)
+            const bool cxa = lx >= 0 && g.x0 < W, cxb = lx + 1 < TW && g.x0 + 1 < W;
+            const bool cya = ly >= 0 && g.y0 < H, cyb = ly + 1 < TH && g.y0 + 1 < H;
+            const bool vnw = cxa && cya, vne = cxb && cya, vsw = cxa && cyb, vse = cxb && cyb;
+            float wgt = 1.0f;
+            if (MODE == 2) wgt = b.mv[u];
+            if (MODE == 3 && mt != nullptr) wgt = expf(b.mv[u]);
+            double* cell = acc + (ly * TW + lx);
+#pragma unroll
+            for (int c = 0; c < CA; ++c) {
+                float v;
+                if (c < CB) {
+                    v = b.val[u][c];
+                    if (MODE == 3) v = (v + 1.0f) / 2.0f;                  // softSplat.py:334
+                    if (MODE >= 2) v = v * wgt;                            // :328 / :338
+                    if (cbase + c >= C) v = 0.0f;
+                } else {
+                    v = wgt;                                               // normalisation accumulator
+                }
+                double* pc = cell + c * CELLS;
+                if (vnw) atomicAdd(pc, (double)(v * g.wnw));               // the reference's fp32 products (softSplat.py:40-51), summed in fp64
+                if (vne) atomicAdd(pc + 1, (double)(v * g.wne));
+                if (vsw) atomicAdd(pc + TW, (double)(v * g.wsw));
+                if (vse) atomicAdd(pc + TW + 1, (double)(v * g.wse));
+            }
+        }
+    };
+
+    if (n_chunks > 0) {
+        SaBuf<CB, U> b0, b1;
+        load_iter(b0, 0);
+        for (int k0 = 0; k0 < n_chunks; k0 += 2 * U) {
+            const bool more = k0 + U < n_chunks;
+            if (more) load_iter(b1, k0 + U);
+            process(b0);
+            if (!more) break;
+            if (k0 + 2 * U < n_chunks) load_iter(b0, k0 + 2 * U);
+            process(b1);
+        }
+    }
+    __syncthreads();
+
+    // ---- finish and write the tile: (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349) ----
+    float* on = P.out_f32 ? P.out_f32 + (int64_t)n * C * HW : nullptr;
+    const int G = (C + 7) >> 3;
+    unsigned char* sp = P.out_spk ? P.out_spk + (int64_t)n * G * 2 * HW * 16 : nullptr;
+    bool bad = false;
+    for (int i = tid; i < CELLS; i += 256) {
+        const int x = tx0 + i % TW, y = ty0 + i / TW;
+        if (x >= W || y >= H) continue;
+        const int64_t pix = (int64_t)y * W + x;
+        float norm = 1.0f;
+        if (MODE >= 1) { norm = (float)acc[CB * CELLS + i]; if (norm == 0.0f) norm = 1.0f; }
+        float o[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            float v = (float)acc[c * CELLS + i];
+            if (MODE >= 1) v = v / norm;
+            o[c] = cbase + c < C ? (v - 0.5f) * 2.0f : 0.0f;
+        }
+        if (on) {
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                if (cbase + c < C) on[(int64_t)(cbase + c) * HW + pix] = o[c];
+        }
+        if constexpr (CB % 8 == 0) {
+            if (sp) {
+#pragma unroll
+                for (int g8 = 0; g8 < CB / 8; ++g8) {
+                    const int gi = (cbase >> 3) + g8;
+                    if (gi >= G) break;
+                    sa_h8 hi, lo;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        _Float16 h_, l_;
+                        fldr_split_hl(o[g8 * 8 + k], h_, l_, bad);
+                        hi[k] = h_; lo[k] = l_;
+                    }
+                    unsigned char* d = sp + ((int64_t)gi * 2 * HW + pix) * 16;
+                    *reinterpret_cast<sa_h8*>(d) = hi;
+                    *reinterpret_cast<sa_h8*>(d + HW * 16) = lo;
+                }
+            }
+        }
+    }
+    fldr_note_range(bad);
+}
+
+int fldr_range_read_acc64(int reset) { return fldr_tu_range_read(reset); }
+
+template <int MODE, int CB, int TW, int TH, int U>
+static int sa_launch2(const SaArgs& a, int nprob, hipStream_t s) {
+    constexpr int CA = MODE >= 1 ? CB + 1 : CB;
+    constexpr int LDS = CA * TW * TH * 8 + SA_Q * 4 + 16 * 4 + 16 * 4 + 2 * 4 + SA_SBQ * 2;
+    static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&splat_acc64_kernel<MODE, CB, TW, TH, U>), LDS, attr_done)) return e;
+    const int64_t z = (int64_t)nprob * a.N * a.groups;
+    if (z > 65535) return FLDR_E_SHAPE;
+    dim3 grid(fldr_cdiv(a.W, TW), fldr_cdiv(a.H, TH), (unsigned)z);
+    hipLaunchKernelGGL((splat_acc64_kernel<MODE, CB, TW, TH, U>), grid, dim3(256), LDS, s, a);
+    return 0;
+}
+
+// Images (<= 3 channels): every channel + the normalisation sum in one 60 x 24 tile (46 KB: three workgroups per CU; 3840 and
+// 2304 / 2160 are whole multiples), four source pixels per thread in flight.  Anything wider: groups of 16 channels (two packed
+// groups), 32 x 16 tiles (70 KB), one pixel per thread in flight.
+template <int MODE>
+static int sa_launch(SaArgs& a, int nprob, hipStream_t s) {
+    if (a.C <= 3) { a.groups = 1; return sa_launch2<MODE, 3, 60, 24, 4>(a, nprob, s); }
+    a.groups = fldr_cdiv(a.C, 16);
+    return sa_launch2<MODE, 16, 32, 16, 1>(a, nprob, s);
+}
+
+extern "C" int fldr_softsplat_acc64(const fldr_splat_acc_desc* d, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d && d->nprob >= 1 && d->nprob <= 2 && d->N > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->mode >= 0 && d->mode <= 3);
+    if (d->W > 65535 * ST_BW || d->H > 32767 * ST_BH || (int64_t)d->H * d->W * 4 >= (1ll << 32)) return FLDR_E_SHAPE;
+    if ((int64_t)fldr_cdiv(d->W, ST_SBX * ST_BW) * fldr_cdiv(d->H, ST_SBY * ST_BH) > 65535) return FLDR_E_SHAPE;
+    SaArgs a;
+    a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.groups = 1;
+    a.nsb_x = fldr_cdiv(d->W, ST_SBX * ST_BW);
+    a.nsb = a.nsb_x * fldr_cdiv(d->H, ST_SBY * ST_BH);
+    hipStream_t s = fldr_s(stream);
+    const int64_t HW = (int64_t)d->H * d->W;
+    for (int k = 0; k < 2; ++k) {
+        const int j = k < d->nprob ? k : 0;
+        FLDR_CHECK_ARG(d->img[j] && d->flow[j] && d->ws[j] && (d->out_f32[j] || d->out_spk[j]));
+        FLDR_CHECK_ARG(d->mode != 2 || d->metric[j] != nullptr);
+        FLDR_CHECK_ARG(!d->out_spk[j] || d->C > 3);                     // packed output: the 16-channel configuration only
+        SaProblem& p = a.p[k];
+        p.img = d->img[j]; p.flow = d->flow[j]; p.metric = d->metric[j];
+        p.blk = d->ws[j]; p.sbt = d->ws[j] + (int64_t)d->N * a.nsb * ST_SB_BLOCKS * 4;
+        p.out_f32 = d->out_f32[j]; p.out_spk = reinterpret_cast<unsigned char*>(d->out_spk[j]);
+        p.img_bstride = d->img_bstride[j];
+        p.img_cstride = d->img_cstride[j] ? d->img_cstride[j] : HW;
+        p.flow_bstride = d->flow_bstride[j] ? d->flow_bstride[j] : 2 * HW;
+        if (k < d->nprob && !(d->flags & 1))
+            fldr_splat_bounds_launch(p.flow, p.flow_bstride, const_cast<float*>(p.blk), const_cast<float*>(p.sbt), d->N, d->H, d->W, a.nsb_x, a.nsb, s);
+    }
+    int e;
+    switch (d->mode) {
+        case 0: e = sa_launch<0>(a, d->nprob, s); break;
+        case 1: e = sa_launch<1>(a, d->nprob, s); break;
+        case 2: e = sa_launch<2>(a, d->nprob, s); break;
+        default: e = sa_launch<3>(a, d->nprob, s); break;
+    }
+    if (e) return e;
+    FLDR_LAUNCH_RET();
+}

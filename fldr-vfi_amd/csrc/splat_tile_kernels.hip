@@ -14,52 +14,21 @@
 // table in parallel, then the blocks of the matching super-blocks, and queues the blocks whose target bounding box
 // overlaps it.  Exact for arbitrary flows: the test is conservative, every queued source is re-tested per corner, and
 // a queue overflow (pathological flows that collapse a large area into one tile) falls back to a scan of all blocks.
-#include "common.h"
-
-#define ST_BW 64                    // source block
-#define ST_BH 4
-#define ST_SBX 4                    // blocks per super-block
-#define ST_SBY 16
-#define ST_SB_BLOCKS (ST_SBX * ST_SBY)
-#define ST_Q 1024                   // block queue entries per tile
-#define ST_SBQ 64                   // super-block queue entries per tile
-#define ST_U 4                      // source blocks in flight per iteration (memory-level parallelism)
-
-struct StGeom {
-    int   x0, y0;
-    float wnw, wne, wsw, wse;
-};
-
-// identical arithmetic to splat_geom (warp_kernels.hip): softSplat.py:23-38
-__device__ __forceinline__ StGeom st_geom(int x, int y, float fx, float fy, int W, int H) {
-#pragma clang fp contract(off)
-    StGeom g;
-    float ox = (float)x + fx;
-    float oy = (float)y + fy;
-    float xf = floorf(ox), yf = floorf(oy);
-    float x1 = xf + 1.0f, y1 = yf + 1.0f;
-    g.wnw = (x1 - ox) * (y1 - oy);
-    g.wne = (ox - xf) * (y1 - oy);
-    g.wsw = (x1 - ox) * (oy - yf);
-    g.wse = (ox - xf) * (oy - yf);
-    xf = fminf(fmaxf(xf, -2.0f), (float)W + 1.0f);
-    yf = fminf(fmaxf(yf, -2.0f), (float)H + 1.0f);
-    g.x0 = (int)xf; g.y0 = (int)yf;
-    return g;
-}
+#include "splat_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // pre-pass: flow bounds per block and per super-block
 //   blk[n][sb][block in sb][4] = {fxmin, fxmax, fymin, fymax};  sbt[n][sb][4]
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void splat_bounds_kernel(const float* __restrict__ flow, float* __restrict__ blk,
-                                                           float* __restrict__ sbt, int H, int W, int nsb_x, int nsb) {
+                                                           float* __restrict__ sbt, int H, int W, int nsb_x, int nsb,
+                                                           int64_t flow_bstride) {
     const int sb = blockIdx.x, n = blockIdx.y;
     const int sbx = sb % nsb_x, sby = sb / nsb_x;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int x = sbx * (ST_SBX * ST_BW) + threadIdx.x;
     const int64_t HW = (int64_t)H * W;
-    const float* fl = flow + (int64_t)n * 2 * HW;
+    const float* fl = flow + (int64_t)n * flow_bstride;          // samples flow_bstride floats apart ([2,H,W] each)
     const float INF = __builtin_inff();
     __shared__ float red[4][4];
     float sxmin = INF, sxmax = -INF, symin = INF, symax = -INF;
@@ -114,6 +83,12 @@ __global__ __launch_bounds__(256) void splat_bounds_kernel(const float* __restri
     }
 }
 
+// (also used by splat_acc64_kernels.hip)
+void fldr_splat_bounds_launch(const float* flow, int64_t flow_bstride, float* blk, float* sbt, int N, int H, int W, int nsb_x, int nsb,
+                              hipStream_t s) {
+    hipLaunchKernelGGL(splat_bounds_kernel, dim3(nsb, N), dim3(256), 0, s, flow, blk, sbt, H, W, nsb_x, nsb, flow_bstride);
+}
+
 // The same table for a flow that is the bilinear upsampling of a low-resolution field — flow = up(scale * lo) * mul, what
 // fldr_level0_prep writes as flow_t0 / flow_t1 (fLDRnet.py:404-405,419-422) — computed from the low-resolution field alone:
 // bilinear weights are a convex combination, so every value of a 64x4 block lies between the extremes of the low-resolution
@@ -151,13 +126,6 @@ __global__ __launch_bounds__(64) void splat_bounds_up_kernel(const float* __rest
         ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
     }
     if (lane == 0) *reinterpret_cast<float4*>(sbt + ((int64_t)n * nsb + sb) * 4) = make_float4(xmin, xmax, ymin, ymax);
-}
-
-// Can a source region [rx0, rx1] x [ry0, ry1] (inclusive pixel coordinates) with flow bounds b touch the tile?
-// Target corner columns of a source: floor(x + fx) and floor(x + fx) + 1.  Conservative by one cell.
-__device__ __forceinline__ bool st_match(const float4 b, float rx0, float rx1, float ry0, float ry1, float tx0, float tx1,
-                                         float ty0, float ty1) {
-    return (rx1 + b.y >= tx0 - 2.0f) && (rx0 + b.x <= tx1 + 1.0f) && (ry1 + b.w >= ty0 - 2.0f) && (ry0 + b.z <= ty1 + 1.0f);
 }
 
 // mode: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ 1 normalisation accumulator
@@ -792,7 +760,7 @@ static int splat_tile_run(const float* img, int64_t img_bstride, int64_t img_cst
     float* blk = ws;
     float* sbt = ws + (int64_t)N * nsb * ST_SB_BLOCKS * 4;
     hipStream_t s = fldr_s(stream);
-    if (!(mode_flags & 1)) hipLaunchKernelGGL(splat_bounds_kernel, dim3(nsb, N), dim3(256), 0, s, flow, blk, sbt, H, W, nsb_x, nsb);
+    if (!(mode_flags & 1)) fldr_splat_bounds_launch(flow, 2 * (int64_t)H * W, blk, sbt, N, H, W, nsb_x, nsb, s);
     if (g_splat_tile_variant == 1) {
         switch (mode) {
             case 0: splat_band_launch<0>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;

@@ -18,8 +18,20 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_WEIGHTS = os.path.join(_HERE, "weights", "fLDRnet_X4K1000FPS_exp1_best_PSNR.npz")
 
 
-def args_config(gpu=0):
-    """The namespace `run_on_your_images.args_config()` produces (--papermodel --test5scales)."""
+# --test3scales ... --test7scales (main.py:243-268): pyramid depth S_tst and the scales / fractions lists of that length.
+# --test3scales leaves the --papermodel values (useful.getmodelconfig: S_tst = 3, four scales).
+_TEST_SCALES = {
+    3: ([8, 16, 32, 64], [4, 16, 64, 256]),
+    4: ([8, 16, 32, 64, 128], [4, 16, 64, 256, 1024]),
+    5: ([8, 16, 32, 64, 128, 256], [4, 16, 64, 256, 1024, 4096]),
+    6: ([8, 16, 32, 64, 128, 256, 512], [4, 16, 64, 256, 1024, 4096, 16384]),
+    7: ([8, 16, 32, 64, 128, 256, 512, 1024], [4, 16, 64, 256, 1024, 4096, 16384, 65536]),
+}
+
+
+def args_config(gpu=0, test_scales=5):
+    """The namespace `run_on_your_images.args_config()` produces (--papermodel --test5scales); test_scales = 3 / 4 / 6 / 7
+    gives what main.py builds under --papermodel --test<n>scales (main.py:240-273)."""
     from fLDRnet import DCTXVFInet
     a = Namespace(
         gpu=gpu, net_type='fLDRnet', exp_num=1, text_dir='./text_dir', checkpoint_dir='./checkpoint_dir',
@@ -36,11 +48,15 @@ def args_config(gpu=0):
         S_trn=3, S_tst=5, timetest=False, testgetflowout=False, outMaskLess=False,
     )
     getmodelconfig(a)                                   # run_on_your_images.py:190-191
-    a.fractions = [4, 16, 64, 256, 1024, 4096]          # :193-203
-    a.scales = [8, 16, 32, 64, 128, 256]
-    a.moreTstSc = True
+    if test_scales not in _TEST_SCALES:
+        raise ValueError("test_scales must be one of %s (main.py:243-268)" % sorted(_TEST_SCALES))
+    a.test5scales = test_scales == 5
+    for n in (3, 4, 6, 7):
+        setattr(a, "test%dscales" % n, test_scales == n)
+    a.scales, a.fractions = (list(v) for v in _TEST_SCALES[test_scales])   # :193-203 / main.py:243-268
+    a.moreTstSc = test_scales != 3
     a.phase = "test"
-    a.S_tst = 5
+    a.S_tst = test_scales
     a.dctvfi_nf = a.scales[0] ** 2 // a.fractions[0]
     a.padding = "reflect"
     a.takeBestModel = True

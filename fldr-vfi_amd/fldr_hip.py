@@ -65,6 +65,14 @@ class SplatGatherDesc(ctypes.Structure):
                 ("mode", ctypes.c_int32)]
 
 
+class SplatAccDesc(ctypes.Structure):
+    _fields_ = [("img", ctypes.c_void_p * 2), ("img_bstride", ctypes.c_int64 * 2), ("img_cstride", ctypes.c_int64 * 2),
+                ("flow", ctypes.c_void_p * 2), ("flow_bstride", ctypes.c_int64 * 2), ("metric", ctypes.c_void_p * 2),
+                ("ws", ctypes.c_void_p * 2), ("out_f32", ctypes.c_void_p * 2), ("out_spk", ctypes.c_void_p * 2),
+                ("nprob", ctypes.c_int32), ("N", ctypes.c_int32), ("C", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("mode", ctypes.c_int32), ("flags", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class SpkConvDesc(ctypes.Structure):
     _fields_ = [
         ("src", ctypes.c_void_p * MAX_SRC),
@@ -93,6 +101,7 @@ _SIGNATURES = {
     "fldr_softsplat_gather_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 4),
     "fldr_softsplat_gather": (ctypes.c_int, [ctypes.POINTER(SplatGatherDesc), ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
+    "fldr_softsplat_acc64": (ctypes.c_int, [ctypes.POINTER(SplatAccDesc), ctypes.c_void_p]),
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile_strided": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64] + [_c_float_p] * 4 + [ctypes.c_int] * 5
                                     + [ctypes.c_void_p]),
@@ -274,7 +283,8 @@ def correlation_bwd(first, second, grad_out, need_first=True, need_second=True):
 _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 
 
-# Forward-splat kernels (FLDR_SPLAT = auto | strip | tile):
+# Forward-splat kernels (FLDR_SPLAT = auto | acc64 | strip | tile):
+#   "acc64" (= auto, default since round 3): destination-owned tiles with fp64 LDS atomics (splat_acc64_kernels.hip);
 #   "strip": global float atomics with in-register merging + a normalisation pass (warp_kernels.hip);
 #   "tile":  destination-owned bands, no atomics (splat_tile_kernels.hip): every wave owns a 128x8 band of the output in
 #            LDS, finds the sources that reach it through per-block flow bounds and adds them with plain LDS
@@ -286,7 +296,7 @@ SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 # normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
 # splat_gather_kernels.hip (bitwise run-to-run reproducible output frames; measured 531 us per forward: every match costs a
 # 48-load body whose latency the few waves of a feature map cannot hide).
-SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "strip")
+SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (default since round 3: fp64 LDS-atomic tiles) | strip | gather
 # Level-0 prep kernel in one launch (0, default) or in two around the image splats (1: enc1 then reads flowback_* / im*_tot
 # right behind their producer; measured 408 vs 419 pairs/s: the second launch's repeated flow evaluation costs more than the
 # Infinity-Cache hits give)
@@ -324,7 +334,19 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
         metric = metric.contiguous()
     kern = kernel or SPLAT_KERNEL
     if kern == "auto":
-        kern = "tile" if C <= 3 else "strip"
+        kern = "acc64"
+    if kern == "acc64":
+        if want_spk and C <= 3:
+            kern = "strip"
+        else:
+            r = softsplat_acc64([img], [flow], None if metric is None else [metric], mode, want_f32=not want_spk, want_spk=want_spk,
+                                bounds_ws=None if bounds_ws is None else [bounds_ws])[0]
+            if out is not None and not want_spk:
+                out.copy_(r)
+                return out
+            if out_spk is not None and want_spk:
+                raise ValueError("softsplat_fused(kernel='acc64') allocates its packed output")
+            return r
     if kern == "tile" and not want_spk:
         img, ibs, ics = _planes(img, "img")
         ws = bounds_ws if bounds_ws is not None else torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
@@ -355,6 +377,61 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
                                       _dev(out, "out"), _dev(scratch, "scratch"), N, C, H, W, _MODES[mode], _stream()),
            "fldr_softsplat_fused")
     return out
+
+
+def softsplat_acc64(imgs, flows, metrics=None, mode="softmax", want_f32=True, want_spk=False, bounds_ws=None, spk_batch=False):
+    """FunctionSoftsplat (softSplat.py:320-352) of one or two (img [N,C,H,W], flow [N,2,H,W]) problems of the same shape with
+    destination-owned tiles and fp64 LDS atomics (fldr_softsplat_acc64): no global atomics, accumulator, memset or
+    normalisation pass.  img may be a view with contiguous [H,W] planes (x_l[0][:, :, 0]); flow a batch-strided channel slice
+    (up[:, :2]) whose [2,H,W] block is contiguous.  bounds_ws: per-problem bounds tables from splat_bounds_upsampled.
+    spk_batch (N == 1, two problems): the packed results form ONE batch of two (sample k = problem k).
+    -> list of fp32 tensors, of Spk tensors, or of (fp32, Spk); with spk_batch the two-sample Spk."""
+    nd = len(imgs)
+    assert 1 <= nd <= 2 and len(flows) == nd
+    N, C, H, W = imgs[0].shape
+    assert want_f32 or want_spk
+    assert not want_spk or C > 3, "packed output needs the 16-channel configuration (C > 3)"
+    d = SplatAccDesc()
+    keep, outs = [], []
+    batch = None
+    if spk_batch:
+        assert nd == 2 and N == 1 and want_spk and not want_f32
+        batch = _spk_alloc(2, C, H, W, imgs[0].device)
+    for k in range(nd):
+        im, fl = imgs[k], flows[k]
+        assert im.shape == (N, C, H, W) and fl.shape == (N, 2, H, W)
+        im, ibs, ics = _planes(im, "img")
+        if not fl.is_cuda:
+            raise NotImplementedError("fldr softsplat has no CPU path (the reference has none either, softSplat.py:251-252)")
+        if fl.dtype != torch.float32:
+            raise TypeError("flow must be float32")
+        if not fl[0].is_contiguous():
+            fl = fl.contiguous()
+        keep += [im, fl]
+        d.img[k], d.img_bstride[k], d.img_cstride[k] = im.data_ptr(), ibs, ics
+        d.flow[k], d.flow_bstride[k] = fl.data_ptr(), (fl.stride(0) if N > 1 else 0)
+        mt = metrics[k] if metrics is not None else None
+        if mt is not None:
+            assert mt.shape == (N, 1, H, W)
+            mt = mt.contiguous()
+            _dev(mt, "metric")
+            keep.append(mt)
+        d.metric[k] = mt.data_ptr() if mt is not None else None
+        ws = bounds_ws[k] if bounds_ws is not None else torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=im.device, dtype=torch.float32)
+        keep.append(ws)
+        d.ws[k] = ws.data_ptr()
+        o32 = torch.empty(N, C, H, W, device=im.device, dtype=torch.float32) if want_f32 else None
+        if batch is not None:
+            osp = batch.sample(k)
+        else:
+            osp = _spk_alloc(N, C, H, W, im.device) if want_spk else None
+        d.out_f32[k] = o32.data_ptr() if o32 is not None else None
+        d.out_spk[k] = osp.ptr if osp is not None else None
+        outs.append((o32, osp) if (want_f32 and want_spk) else (osp if want_spk else o32))
+    d.nprob, d.N, d.C, d.H, d.W, d.mode = nd, N, C, H, W, _MODES[mode]
+    d.flags = 1 if bounds_ws is not None else 0
+    _check(lib().fldr_softsplat_acc64(ctypes.byref(d), _stream()), "fldr_softsplat_acc64")
+    return batch if batch is not None else outs
 
 
 def softsplat_gather(imgs, flows, metrics=None, mode="softmax", want_f32=False, want_spk=True):

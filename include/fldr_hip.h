@@ -78,6 +78,29 @@ typedef struct fldr_splat_gather_desc {
 int64_t fldr_softsplat_gather_ws_floats(int ndir, int N, int H, int W);
 int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stream);
 
+/* FunctionSoftsplat (softSplat.py:320-352) with destination-owned tiles and fp64 LDS atomics (csrc/splat_acc64_kernels.hip):
+ * every workgroup owns an output tile as fp64 accumulators in LDS, the sources that can reach it (flow-bounds tables, as for
+ * fldr_softsplat_tile) add the reference kernel's fp32 corner products (softSplat.py:40-51) with ds_add_f64, and the
+ * normalised tile is written once: no global atomics, no accumulator tensor / memset / normalisation pass; exact for any
+ * flow; independent of the summation order to ~1e-16 (the reference's own fp32 atomics are unordered).  One or
+ * two problems of the same shape per call (the two image splats of fLDRnet.py:449-450, the two feature splats of :386-387).
+ * img: sample n, channel c at img + n*img_bstride + c*img_cstride floats (cstride 0 = H*W); flow [N,2,H,W], samples
+ * flow_bstride floats apart (0 = 2*H*W); metric [N,1,H,W] contiguous or NULL; ws: fldr_softsplat_tile_ws_floats(N,H,W)
+ * floats per problem (flags bit 0: it already holds a bounds table, e.g. from fldr_splat_bounds_upsampled);
+ * out_f32 [N,C,H,W] and / or out_spk (packed, C > 3 only; fldr_spk_bytes per sample). */
+typedef struct fldr_splat_acc_desc {
+    const float* img[2];
+    int64_t      img_bstride[2], img_cstride[2];
+    const float* flow[2];
+    int64_t      flow_bstride[2];
+    const float* metric[2];
+    float*       ws[2];
+    float*       out_f32[2];
+    void*        out_spk[2];
+    int32_t      nprob, N, C, H, W, mode, flags, reserved;
+} fldr_splat_acc_desc;
+int fldr_softsplat_acc64(const fldr_splat_acc_desc* desc, fldr_stream_t stream);
+
 /* fldr_softsplat_fused with the result in the split-packed layout of the convolution section (fldr_spk_bytes(C,H,W) bytes
  * per sample) instead of fp32 NCHW: the warped feature maps of fLDRnet.py:386-387 are read by conv_flow1 only. */
 int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric_or_null, void* out_spk,

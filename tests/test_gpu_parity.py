@@ -424,6 +424,81 @@ def test_gather_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
         _cmp(one, oracle.function_softsplat(feat[:, C:], up[:, :2], None, mode), atol=3e-5, rtol=1e-5, what="gather softmax, no metric")
 
 
+@pytest.mark.parametrize("mode", ["summation", "average", "linear", "softmax"])
+@pytest.mark.parametrize("shape", [(2, 4, 33, 70, 9.0), (1, 3, 70, 300, 40.0), (1, 13, 40, 130, 600.0), (2, 3, 130, 190, 3.0), (1, 48, 36, 60, 9.0)])
+def test_acc64_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
+    """fldr_softsplat_acc64 (destination-owned tiles, fp64 LDS atomics: the default splat since round 3) against the oracle:
+    image (<= 3 channels) and 16-channel-group configurations, coherent to wild flows (600 px: queue overflow -> the
+    rectangle / whole-image walks), all four modes; run-to-run identical."""
+    N, C, H, W, amp = shape
+    g = _gen(12)
+    x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+    flow = (torch.rand(N, 2, H, W, generator=g) - 0.5) * amp
+    z = torch.randn(N, 1, H, W, generator=g) if mode in ("linear", "softmax") else None
+    if mode == "linear":
+        z = z.abs() + 0.1
+    zs = None if z is None else [z.to(dev)]
+    out = hip.softsplat_acc64([x.to(dev)], [flow.to(dev)], zs, mode)[0]
+    _cmp(out, oracle.function_softsplat(x, flow, z, mode), atol=3e-5, rtol=1e-5, what="acc64 " + mode)
+    assert torch.equal(out, hip.softsplat_acc64([x.to(dev)], [flow.to(dev)], zs, mode)[0])
+    # the public operator takes the same path
+    import softSplat
+    _cmp(softSplat.FunctionSoftsplat(x.to(dev), flow.to(dev), None if z is None else z.to(dev), mode), out, atol=0.0, what="FunctionSoftsplat == acc64")
+
+
+@pytest.mark.parametrize("mode", ["summation", "average", "softmax"])
+@pytest.mark.parametrize("shape", [(2, 48, 33, 70, 3.0, "smooth"), (1, 48, 36, 60, 9.0, "random"), (1, 13, 40, 130, 80.0, "random"),
+                                   (1, 48, 72, 120, 30.0, "smooth"), (1, 48, 9, 15, 2.0, "smooth")])
+def test_acc64_softsplat_pair(hip, oracle, dev, mode, shape):
+    """Two problems per launch, the way the model calls it (fLDRnet.py:386-387 / :449-450): sources as channel slices of one
+    tensor, flows as channel slices of the [N,4,H,W] level flow, fp32 and packed outputs (packed == pack(fp32)), and the
+    one-batch-of-two packed form the batched conv_flow1 consumes."""
+    N, C, H, W, amp, kind = shape
+    g = _gen(19)
+    feat = torch.rand(N, 2 * C, H, W, generator=g) * 2 - 1
+    if kind == "smooth":
+        lo = (torch.rand(N, 4, max(H // 8, 2), max(W // 8, 2), generator=g) - 0.5) * amp + torch.tensor([amp, -amp / 2, -amp, amp / 3]).view(1, 4, 1, 1)
+        up = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+    else:
+        up = (torch.rand(N, 4, H, W, generator=g) - 0.5) * amp
+    z = [torch.randn(N, 1, H, W, generator=g) for _ in range(2)] if mode == "softmax" else None
+    fd, ud = feat.to(dev), up.to(dev)
+    imgs, flows = [fd[:, C:], fd[:, :C]], [ud[:, :2], ud[:, 2:]]
+    zs = None if z is None else [t.to(dev) for t in z]
+    res = hip.softsplat_acc64(imgs, flows, zs, mode, want_f32=True, want_spk=True)
+    for k in range(2):
+        ref = oracle.function_softsplat(feat[:, C:] if k == 0 else feat[:, :C], up[:, :2] if k == 0 else up[:, 2:],
+                                        None if z is None else z[k], mode)
+        _cmp(res[k][0], ref, atol=3e-5, rtol=1e-5, what="acc64 pair %s dir %d" % (mode, k))
+        assert torch.equal(hip.spk_pack(res[k][0]).buf, res[k][1].buf)                                 # packed twin
+    if N == 1:
+        pair = hip.softsplat_acc64(imgs, flows, zs, mode, want_f32=False, want_spk=True, spk_batch=True)
+        assert pair.shape == (2, C, H, W)
+        assert torch.equal(pair.buf.view(torch.int16), torch.cat([res[0][1].buf.view(torch.int16), res[1][1].buf.view(torch.int16)]))
+
+
+def test_acc64_softsplat_frames_in_place_and_low_res_bounds(hip, oracle, dev):
+    """The level-0 call of the model: both image splats in one launch, frames read in place as channel-strided views of the
+    [B,3,2,H,W] tensor, metrics given, bounds tables from the low-resolution flows."""
+    g = _gen(23)
+    B, H, W, up = 2, 128, 192, 8
+    frames = (torch.rand(B, 3, 2, H, W, generator=g) * 2 - 1).to(dev)
+    lo = (torch.randn(B, 4, H // up, W // up, generator=g) * 1.5).to(dev)
+    t4 = torch.tensor([0.5, 0.125]).view(B, 1, 1, 1).to(dev)
+    I0, I1 = frames[:, :, 0], frames[:, :, 1]
+    ft0 = F.interpolate(t4 * lo[:, 2:], scale_factor=up, mode="bilinear", align_corners=False) * up
+    ft1 = F.interpolate((1 - t4) * lo[:, :2], scale_factor=up, mode="bilinear", align_corners=False) * up
+    z0 = -torch.rand(B, 1, H, W, generator=g).to(dev) * 3
+    z1 = -torch.rand(B, 1, H, W, generator=g).to(dev) * 3
+    b0 = hip.splat_bounds_upsampled(lo[:, 2:], t4, 1, up, H, W)
+    b1 = hip.splat_bounds_upsampled(lo[:, :2], t4, 2, up, H, W)
+    w0, w1 = hip.softsplat_acc64([I0, I1], [ft0, ft1], [z0, z1], "softmax", bounds_ws=[b0, b1])
+    _cmp(w0, oracle.function_softsplat(I0.contiguous().cpu(), ft0.cpu(), z0.cpu(), "softmax"), atol=3e-5, what="acc64 I0")
+    _cmp(w1, oracle.function_softsplat(I1.contiguous().cpu(), ft1.cpu(), z1.cpu(), "softmax"), atol=3e-5, what="acc64 I1")
+    e0, e1 = hip.softsplat_acc64([I0.contiguous(), I1.contiguous()], [ft0, ft1], [z0, z1], "softmax")      # exact bounds pre-pass
+    assert torch.equal(e0, w0) and torch.equal(e1, w1)
+
+
 def test_tile_softsplat_extreme_and_smooth_flows(hip, oracle, dev):
     """Band splat corner cases: a smooth flow field (trimmed candidate walk) with 1 % of the vectors thrown out to
     +-3e9 px (bounds far beyond int range: the block walk takes over where they occur) and a pure sub-pixel shift."""

@@ -309,9 +309,64 @@ def import_contract(out_path):
     print("wrote", out_path, {m: len(c["names"]) + len(c["star_names"]) for m, c in out.items()})
 
 
+# --test3scales / --test4scales / --test6scales / --test7scales (main.py:243-268): what main.py does to the namespace after
+# --papermodel, then one small forward of the reference at that pyramid depth (frames + output frame only).
+DEPTH_CASES = {3: (100, 150, 0.5, 21), 4: (128, 200, 0.25, 22), 6: (300, 400, 0.5, 23), 7: (520, 530, 0.75, 24)}   # reflect padding needs H, W > half the unit
+DEPTH_LISTS = {3: ([8, 16, 32, 64], [4, 16, 64, 256]),
+               4: ([8, 16, 32, 64, 128], [4, 16, 64, 256, 1024]),
+               6: ([8, 16, 32, 64, 128, 256, 512], [4, 16, 64, 256, 1024, 4096, 16384]),
+               7: ([8, 16, 32, 64, 128, 256, 512, 1024], [4, 16, 64, 256, 1024, 4096, 16384, 65536])}
+
+
+def depth_cases(R, fLDRnet, pca_comp, args, gold):
+    import copy
+    for S, (H, W, tval, seed) in DEPTH_CASES.items():
+        a = copy.copy(args)
+        a.scales, a.fractions = (list(v) for v in DEPTH_LISTS[S])
+        a.S_tst = S
+        a.moreTstSc = S != 3
+        a.phase = "test"
+        model, _ = load_model(fLDRnet, pca_comp, a)
+        # one DCTParams per level (run_on_your_images.py:66 builds six; save_params only takes the first list it is given)
+        model.params = [pca_comp.DCTParams(8, 0.25, 0.5) for _ in range(S + 1)]
+        u8 = O.synthetic_pair(H, W, seed=seed, quadrant=True)
+        frames = O.frames_from_uint8(u8)
+        B, C, T, _, _ = frames.shape
+        div = (2 ** a.S_tst) * 8                                                   # main.py:842
+        ph, pw = (div - H % div) % div, (div - W % div) % div
+        x = torch.nn.functional.pad(frames.reshape(B, -1, H, W), (0, pw, 0, ph), a.padding).reshape(B, C, T, H + ph, W + pw)
+        Bp, Cp, Tp, Hp, Wp = x.shape
+        pyr = [torch.nn.functional.interpolate(                                       # main.py:855-856
+            x.permute(0, 2, 1, 3, 4).reshape(Bp * Tp, Cp, Hp, Wp), scale_factor=a.scales[0] / a.scales[i],
+            mode="bicubic", align_corners=a.align_cornerse).reshape(
+                Bp, Tp, Cp, int(Hp * (a.scales[0] / a.scales[i])), int(Wp * (a.scales[0] / a.scales[i]))
+            ).permute(0, 2, 1, 3, 4) if i != 0 else x for i in range(a.S_tst + 1)]
+        t = torch.tensor([[tval]], dtype=torch.float32)
+        with torch.no_grad():
+            out, _ = model([torch.zeros(B, 96, Hp // 8, Wp // 8) for _ in range(S + 1)], t, normInput=[p.clone() for p in pyr], is_training=False, validation=False)
+        out = out[:, :, :H, :W]
+        path = os.path.join(gold, "depth_S%d_%dx%d.npz" % (S, H, W))
+        # the whole frame for the small cases; for the deep pyramids (large padded frames) a 160 x 240 window from the middle
+        # plus per-channel sums of the whole frame
+        y0, x0 = (0, 0) if S < 6 else ((H - 160) // 2, (W - 240) // 2)
+        win = out if S < 6 else out[..., y0:y0 + 160, x0:x0 + 240]
+        np.savez_compressed(path, frames_u8=u8.numpy(), t=np.float32(tval), S_tst=np.int32(S), padded=np.int32([Hp, Wp]),
+                            out=win.float().numpy(), window=np.int32([y0, x0, win.shape[-2], win.shape[-1]]),
+                            out_sum=out.sum((0, 2, 3)).numpy(), out_abssum=out.abs().sum((0, 2, 3)).numpy())
+        print("wrote", path, os.path.getsize(path) >> 10, "KiB  padded", (Hp, Wp))
+
+
 def main():
     if "--contract-only" in sys.argv:
         import_contract(os.path.join(ROOT, "tests", "golden", "import_contract.json"))
+        return
+    if "--depths-only" in sys.argv:
+        if sys.flags.optimize < 1:
+            raise SystemExit("run with python -O (fLDRnet.py:448 asserts a CUDA device index)")
+        torch.manual_seed(0)
+        torch.set_num_threads(8)
+        R, fLDRnet, pca_comp, args = import_reference()
+        depth_cases(R, fLDRnet, pca_comp, args, os.path.join(ROOT, "tests", "golden"))
         return
     if sys.flags.optimize < 1:
         raise SystemExit("run with python -O (fLDRnet.py:448 asserts a CUDA device index)")
@@ -342,6 +397,7 @@ def main():
     with open(os.path.join(gold, "args_papermodel_test5scales.json"), "w") as f:
         json.dump({n: getattr(args, n) for n in names if hasattr(args, n)}, f, indent=1, sort_keys=True)
     import_contract(os.path.join(gold, "import_contract.json"))
+    depth_cases(R, fLDRnet, pca_comp, args, gold)
 
 
 if __name__ == "__main__":
