@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--pairs", type=int, default=4, help="distinct frame pairs rotated through the timed loop (>= streams)")
     ap.add_argument("--sustained-s", type=float, default=3.0, help="length of the extra sustained-rate measurement (0 = skip)")
     ap.add_argument("--varying-motion-steps", type=int, default=60, help="steps of the informational run on pairs with a smoothly varying motion field (0 = skip)")
+    ap.add_argument("--incl-ingest-steps", type=int, default=60, help="steps of the informational uint8-in -> uint8-out run with the ingest kernels inside the loop (0 = skip)")
+    ap.add_argument("--multi-t-pairs", type=int, default=4, help="pairs of the informational 4096x2160 7-outputs-per-pair run, BASELINE config 3 (0 = skip)")
     ap.add_argument("--fp16-mode-steps", type=int, default=60, help="steps of the informational fp16-input convolution run (BASELINE config 5; 0 = skip)")
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
@@ -105,13 +107,13 @@ def dominant_conv_roofline(model, h, w, device, steps):
     ms32 = timed(lambda: fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision="fp32"))
     flops = 2.0 * 96 * 96 * 9 * h * w
     alg = flops / (ms * 1e-3) / 1e12
-    tr = _measured_traffic()
+    tr, tr_src = _measured_traffic()
     return {"bound": "mfma", "kernel": "conv3x3_ring_kernel<3,3,false,8> (3x3 96->96 @%dx%d, persistent loader/consumer ring, split-packed operands, "
                                        "3 x fp16-split v_mfma_f32_16x16x32_f16)" % (h, w),
             "achieved": round(alg, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(alg / PEAK_FP16_MFMA_TFLOPS, 4),
             "frac_algorithmic": round(alg / PEAK_FP16_MFMA_TFLOPS, 4), "frac_issued": round(3 * alg / PEAK_FP16_MFMA_TFLOPS, 4),
             "frac_of_fp32_mfma_peak": round(alg / PEAK_FP32_MFMA_TFLOPS, 3),
-            "traffic": tr, "launch_ms": round(ms, 4), "flops_per_launch": flops, "issued_mfma_flops_per_launch": 3.0 * flops,
+            "traffic": tr, "traffic_source": tr_src, "launch_ms": round(ms, 4), "flops_per_launch": flops, "issued_mfma_flops_per_launch": 3.0 * flops,
             "algorithmic_bytes_per_launch": 2 * 96 * h * w * 4,
             "exact_fp32_mfma_kernel": {"launch_ms": round(ms32, 4), "achieved": round(flops / (ms32 * 1e-3) / 1e12, 1),
                                        "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
@@ -120,12 +122,13 @@ def dominant_conv_roofline(model, h, w, device, steps):
 def _measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate --pmc passes); newest round first."""
-    for name in ("r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
+    for name in ("r03_conv96_ring_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
         try:
-            return json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
+            v = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
+            return v, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_round.sh; not measured in this run)" % name
         except Exception:
             pass
-    return None
+    return None, None
 
 
 def host_info():
@@ -230,7 +233,7 @@ def main():
 
     npairs = max(a.pairs, a.streams, 1)
     my_pairs = shard_pairs(world * npairs, rank, world)          # pair index = seed; disjoint across ranks
-    latency_ms = dt_e2e = sustained = fp16_mode = varying = None
+    latency_ms = dt_e2e = sustained = fp16_mode = varying = incl = multi_t = None
     if gpu:
         import fldr_harness as Hn
         model, _, args = Hn.prepare_model(device)
@@ -336,6 +339,58 @@ def main():
                                "2 distinct pairs): reported for reference only", "steps": a.varying_motion_steps,
                        "ms_per_step": round(dv / a.varying_motion_steps * 1e3, 3), "pairs_per_s_this_gpu": round(a.varying_motion_steps / dv, 2)}
             del vf, vp
+        # Informational (never `value`): SURVEY 8d's unit of work — two uint8 frames resident on the GPU -> ingest kernels
+        # (normalise, reflect pad, bicubic pyramid) -> forward -> rounded uint8 frame — with the same number of pairs in flight
+        # on separate streams as the headline loop.
+        incl = None
+        if rank == 0 and a.incl_ingest_steps > 0:
+            u8s = [Hn.synthetic_pair(a.height, a.width, seed=my_pairs[k % npairs]).unsqueeze(0).to(device) for k in range(npairs)]
+
+            def istep(i):
+                with torch.cuda.stream(streams[i % len(streams)]), torch.no_grad():
+                    return Hn.interpolate_u8(model, args, u8s[i % npairs], t)[0]
+            for i in range(2 * len(streams)):
+                iout = istep(i)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(a.incl_ingest_steps):
+                iout = istep(i)
+            sync()
+            di = time.perf_counter() - t1
+            assert iout.dtype == torch.uint8
+            incl = {"what": "uint8 frame pair resident in HBM -> ingest (normalise, reflect pad, bicubic pyramid) -> forward -> rounded uint8 "
+                            "frame, %d pairs in flight: SURVEY 8d's unit of work; reported for reference only" % len(streams),
+                    "steps": a.incl_ingest_steps, "ms_per_step": round(di / a.incl_ingest_steps * 1e3, 3),
+                    "pairs_per_s_this_gpu": round(a.incl_ingest_steps / di, 2)}
+            del u8s
+        # Informational: BASELINE config 3 — 4096x2160 (padded 2304x4096), t = 1/8 ... 7/8 (7 output frames per pair, main.py:833)
+        # with and without the pair-invariant cache; single stream, output frames per second.
+        multi_t = None
+        if rank == 0 and a.multi_t_pairs > 0 and (a.height, a.width) == (H4K, W4K):
+            tvals = [k / 8.0 for k in range(1, 8)]
+            with torch.no_grad():
+                mf = [Hn.frames_from_uint8(Hn.synthetic_pair(2160, 4096, seed=200 + k)).to(device) for k in range(2)]
+                mp = [Hn.build_pyramid(Hn.pad_frames(f, args), args) for f in mf]
+
+                def pair_cached(i):
+                    return Hn.interpolate_multi(model, args, mf[i % 2], tvals, pyramid=mp[i % 2])
+
+                def pair_plain(i):
+                    return [Hn.interpolate(model, args, mf[i % 2], torch.full((1, 1), tv, device=device), pyramid=mp[i % 2]) for tv in tvals]
+                rec = {}
+                for name, fn in (("pair_cache", pair_cached), ("no_cache", pair_plain)):
+                    fn(0)
+                    sync()
+                    t1 = time.perf_counter()
+                    for i in range(a.multi_t_pairs):
+                        mo = fn(i)
+                    sync()
+                    dm = time.perf_counter() - t1
+                    assert len(mo) == 7 and torch.isfinite(mo[-1]).all()
+                    rec[name] = {"ms_per_pair": round(dm / a.multi_t_pairs * 1e3, 3), "output_frames_per_s": round(7 * a.multi_t_pairs / dm, 2)}
+            multi_t = dict(rec, what="BASELINE config 3: 4096x2160 pair (padded 2304x4096), 7 outputs per pair (t = 1/8 ... 7/8), single "
+                                     "stream, with / without the pair-invariant cache; reported for reference only", pairs=a.multi_t_pairs)
+            del mf, mp
         fp16_mode = None
         if rank == 0 and a.fp16_mode_steps > 0:
             prev = fldr_hip.CONV_PRECISION
@@ -383,6 +438,10 @@ def main():
                 res["fp16_conv_mode"] = fp16_mode
             if varying:
                 res["varying_motion"] = varying
+            if incl:
+                res["incl_ingest"] = incl
+            if multi_t:
+                res["multi_t"] = multi_t
             res["roofline"] = dominant_conv_roofline(model, hp[0] // 8, hp[1] // 8, device, a.steps)
             pm = PATH_MODEL.get((a.height, a.width))
             if pm:

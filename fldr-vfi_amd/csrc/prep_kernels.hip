@@ -27,6 +27,7 @@ struct PrepArgs {
     int phase;                     // bit 0: z0 / z1 + flow_t0 / flow_t1; bit 1: flowback_0 / _1 + im0_tot / im1_tot (3 = everything)
     int vec_ok;                    // W % 4 == 0 and every output plane 16-byte aligned: 16-byte stores
     int kx, ky;                    // sx == 2^-kx / sy == 2^-ky exactly (integer source-index arithmetic), else -1
+    float rkx, rky;                // 2^-(kx+1), 2^-(ky+1)
 };
 
 // Uniform base pointer + 32-bit byte offset: one global_load / global_store with an SGPR base and a VGPR offset, no 64-bit
@@ -56,7 +57,7 @@ struct PrepLin { int i0, i1; float l; };
 // (2 o + 1 - 2^k) / 2^(k+1) is exact in fp32 and fldr_lin_src's floor / fraction are a shift and a mask of the integer
 // numerator — the same i0, i1 and l bit for bit, in 6 integer instructions instead of 12 (the kernel is bound by its
 // vector-instruction count, and this runs ten times per pixel).
-__device__ __forceinline__ PrepLin prep_lin(int o, float scale, int in_size, int kshift) {
+__device__ __forceinline__ PrepLin prep_lin(int o, float scale, int in_size, int kshift, float rk) {
     PrepLin r;
     if (kshift >= 0) {                                                   // uniform
         const int t = 2 * o + 1 - (1 << kshift);                         // numerator of r over 2^(k+1); r < 0 clamps to 0
@@ -65,7 +66,7 @@ __device__ __forceinline__ PrepLin prep_lin(int o, float scale, int in_size, int
         r.i0 = i < in_size - 1 ? i : in_size - 1;
         r.i1 = r.i0 + (r.i0 < in_size - 1 ? 1 : 0);
         // r - i0: the fraction while i <= in_size - 1 (always, for o inside the upsampled image); the general clamp otherwise
-        const float l = (float)(tc - (r.i0 << (kshift + 1))) * (1.0f / (float)(1 << (kshift + 1)));
+        const float l = (float)(tc - (r.i0 << (kshift + 1))) * rk;        // rk = 2^-(kshift+1) from the host (a reciprocal computed here is a 10-instruction division, ten times per pixel)
         r.l = l > 1.0f ? 1.0f : l;
     } else {
         fldr_lin_src(o, scale, in_size, r.i0, r.i1, r.l);
@@ -112,8 +113,8 @@ __device__ __forceinline__ void prep_sample_up2(const FldrTap& tp, const FldrTap
 #pragma clang fp contract(off)
     const int xa = min(max(tp.x0, 0), a.W - 1), xb = min(max(tp.x0 + 1, 0), a.W - 1);
     const int ya = min(max(tp.y0, 0), a.H - 1), yb = min(max(tp.y0 + 1, 0), a.H - 1);
-    const PrepLin lxa = prep_lin(xa, a.sx, a.w, a.kx), lxb = prep_lin(xb, a.sx, a.w, a.kx);
-    const PrepLin lya = prep_lin(ya, a.sy, a.h, a.ky), lyb = prep_lin(yb, a.sy, a.h, a.ky);
+    const PrepLin lxa = prep_lin(xa, a.sx, a.w, a.kx, a.rkx), lxb = prep_lin(xb, a.sx, a.w, a.kx, a.rkx);
+    const PrepLin lya = prep_lin(ya, a.sy, a.h, a.ky, a.rky), lyb = prep_lin(yb, a.sy, a.h, a.ky, a.rky);
     // columns lxa.i0 + {0,1,2} and rows lya.i0 + {0,1,2}, clamped like fldr_lin_src's i1: (i0, i1) of xa is columns (0,1),
     // of xb columns (dx, dx+1) with dx = lxb.i0 - lxa.i0 in {0,1}; rows alike
     const int c0 = lxa.i0, c1 = min(c0 + 1, a.w - 1), c2 = min(c0 + 2, a.w - 1);
@@ -207,7 +208,7 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
         }
 
         // upsampled flows at this pixel (fLDRnet.py:419-422)
-        const PrepLin lx = prep_lin(px, a.sx, a.w, a.kx), ly = prep_lin(py, a.sy, a.h, a.ky);
+        const PrepLin lx = prep_lin(px, a.sx, a.w, a.kx, a.rkx), ly = prep_lin(py, a.sy, a.h, a.ky, a.rky);
         const PrepQuad q = prep_quad(lo10, lo01, a.w, lx, ly);
         const float f10x = prep_up(q, 0, lx, ly, a.mul, 0, 1.0f), f10y = prep_up(q, 1, lx, ly, a.mul, 0, 1.0f);
         const float f01x = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f), f01y = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
@@ -310,6 +311,8 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
         if (a.sx == 1.0f / (float)(1 << k)) a.kx = k;
         if (a.sy == 1.0f / (float)(1 << k)) a.ky = k;
     }
+    a.rkx = a.kx >= 0 ? 1.0f / (float)(1 << (a.kx + 1)) : 0.0f;
+    a.rky = a.ky >= 0 ? 1.0f / (float)(1 << (a.ky + 1)) : 0.0f;
     {
         const void* outs[8] = {d->z0, d->z1, d->flow_t0, d->flow_t1, d->flowback_0, d->flowback_1, d->im0_tot, d->im1_tot};
         bool v = (d->W & 3) == 0;

@@ -19,8 +19,23 @@
 // image.  Every visited source is re-tested per corner, so any superset of the true candidates gives the exact result.
 #include "splat_common.h"
 
-#define SA_SBQ 64                    // matching super-blocks a tile can list
-#define SA_Q 512                     // matching blocks a tile can queue
+#define SA_SBQ 64                    // matching super-blocks a workgroup can list
+#define SA_Q 512                     // matching blocks a workgroup can queue
+#ifndef SA_WHOLE_PIXELS
+#define SA_WHOLE_PIXELS 2304         // up to 36 x 64: every tile walks the whole map instead of reading bounds tables
+#endif
+#ifndef SA_IMG_TW
+#define SA_IMG_TW 64                 // image configuration: tile, tiles per workgroup, source pixels per thread in flight
+#define SA_IMG_TH 24
+#define SA_IMG_K 3
+#define SA_IMG_U 4
+#endif
+#ifndef SA_FEAT_TW
+#define SA_FEAT_TW 32                // 16-channel-group configuration
+#define SA_FEAT_TH 8
+#define SA_FEAT_K 1
+#define SA_FEAT_U 1
+#endif
 
 typedef _Float16 sa_h8 __attribute__((ext_vector_type(8)));
 
@@ -37,6 +52,8 @@ struct SaProblem {
 struct SaArgs {
     SaProblem p[2];
     int N, C, H, W, groups, nsb_x, nsb;
+    int whole;                                    // 1: no bounds tables, every tile walks the whole map
+    int tiles_x, st_y, n_st, total, per_xcd;      // tiles per row, super-tile rows, super-tiles per (problem, sample, group), all work items, items per XCD
 };
 
 template <int CB, int U>
@@ -47,8 +64,13 @@ struct SaBuf {
 };
 
 // MODE: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ the normalisation accumulator when
-// MODE >= 1); U source pixels per thread and iteration (all loads of iteration i + 1 are in flight under iteration i).
-template <int MODE, int CB, int TW, int TH, int U>
+// MODE >= 1).  A workgroup owns a column of K vertically adjacent TW x TH tiles: ONE candidate search for the whole column
+// (the search is a chain of two dependent table reads and three barriers: ~40 % of the kernel when done per tile), then the
+// tiles one after the other through the same LDS accumulator.  U source pixels per thread and iteration; all loads of
+// iteration i + 1 — and of the next tile's first iteration — are in flight under iteration i / under the tile's write-out.
+// Work items are dealt to the XCDs in contiguous row-major ranges (blockIdx & 7 = XCD): neighbouring tiles read overlapping
+// source rows and the two halves of partly covered 128-byte lines, which then hit in the same L2.
+template <int MODE, int CB, int TW, int TH, int K, int U>
 __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
 #pragma clang fp contract(off)
     constexpr int CA = MODE >= 1 ? CB + 1 : CB;
@@ -63,37 +85,49 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lin = (int)(blockIdx.x & 7) * a.per_xcd + (int)(blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= a.per_xcd || lin >= a.total) return;           // workgroup-uniform
+    const int zi = lin / a.n_st, st = lin - zi * a.n_st;
+    const int sty = st / a.tiles_x, stx = st - sty * a.tiles_x;
     const int per_prob = a.N * a.groups;
-    const int prob = blockIdx.z / per_prob;
-    const int rem = blockIdx.z - prob * per_prob;
+    const int prob = zi / per_prob;
+    const int rem = zi - prob * per_prob;
     const int n = rem / a.groups, grp = rem - n * a.groups;
     const SaProblem& P = a.p[prob];
     const int C = a.C, H = a.H, W = a.W, nsb_x = a.nsb_x, nsb = a.nsb;
     const int cbase = grp * CB;
-    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int tx0 = stx * TW, sy0 = sty * (K * TH);
     const int64_t HW = (int64_t)H * W;
-    const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fty0 = (float)ty0, fty1 = (float)(ty0 + TH - 1);
+    const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fsy0 = (float)sy0, fsy1 = (float)(min(sy0 + K * TH, H) - 1);
     const float INF = __builtin_inff();
 
-    for (int i = tid; i < CA * CELLS / 2; i += 256) reinterpret_cast<double2*>(acc)[i] = make_double2(0.0, 0.0);
-    if ((CA * CELLS) & 1) { if (tid == 0) acc[CA * CELLS - 1] = 0.0; }
-    if (tid < 2) cnt[tid] = 0;
-    __syncthreads();
-
-    // ---- which super-blocks, then which blocks, can reach this tile ----
+    // ---- which super-blocks, then which blocks, can reach this column of tiles ----
     const float* sbn = P.sbt + (int64_t)n * nsb * 4;
     const float* bkn = P.blk + (int64_t)n * nsb * ST_SB_BLOCKS * 4;
-    for (int s = tid; s < nsb; s += 256) {
-        const float4 b = *reinterpret_cast<const float4*>(sbn + s * 4);
-        const int sx = (s % nsb_x) * (ST_SBX * ST_BW), sy = (s / nsb_x) * (ST_SBY * ST_BH);
-        if (st_match(b, (float)sx, (float)(sx + ST_SBX * ST_BW - 1), (float)sy, (float)(sy + ST_SBY * ST_BH - 1), ftx0, ftx1, fty0, fty1)) {
-            const int i = atomicAdd(&cnt[0], 1);
-            if (i < SA_SBQ) sbq[i] = (unsigned short)s;
-        }
-    }
+    // a.whole: no table at all, every tile walks the whole map (maps of a few thousand pixels: cheaper than a bounds launch
+    // and the search's two dependent table reads).  nsb <= SA_SBQ (feature maps): the super-block level is skipped, every
+    // super-block's blocks are tested directly.
+    const bool small = nsb <= SA_SBQ;                                   // kernel-uniform
+    if (tid < 2) cnt[tid] = small && tid == 0 ? nsb : 0;
+    if (small && tid < nsb) sbq[tid] = (unsigned short)tid;
+    float4 b_first = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!small && !a.whole) b_first = *reinterpret_cast<const float4*>(sbn + (tid < nsb ? tid : 0) * 4);   // in flight while the accumulator is cleared
+    for (int i = tid; i < CA * CELLS / 2; i += 256) reinterpret_cast<double2*>(acc)[i] = make_double2(0.0, 0.0);
+    if ((CA * CELLS) & 1) { if (tid == 0) acc[CA * CELLS - 1] = 0.0; }
     __syncthreads();
+    if (!small && !a.whole) {
+        for (int s = tid; s < nsb; s += 256) {
+            const float4 b = s == tid ? b_first : *reinterpret_cast<const float4*>(sbn + s * 4);
+            const int sx = (s % nsb_x) * (ST_SBX * ST_BW), sy = (s / nsb_x) * (ST_SBY * ST_BH);
+            if (st_match(b, (float)sx, (float)(sx + ST_SBX * ST_BW - 1), (float)sy, (float)(sy + ST_SBY * ST_BH - 1), ftx0, ftx1, fsy0, fsy1)) {
+                const int i = atomicAdd(&cnt[0], 1);
+                if (i < SA_SBQ) sbq[i] = (unsigned short)s;
+            }
+        }
+        __syncthreads();
+    }
     const int n_sb = cnt[0];
-    const bool sb_over = n_sb > SA_SBQ;                                 // workgroup-uniform
+    const bool sb_over = a.whole || n_sb > SA_SBQ;                      // workgroup-uniform: walk the whole map
     float rxmin = INF, rxmax = -INF, rymin = INF, rymax = -INF;         // joint flow bounds of the matching blocks
     int cx0 = 0x7fffffff, cx1 = -1, cy0 = 0x7fffffff, cy1 = -1;         // their bounding box (pixels, inclusive)
     if (!sb_over) {
@@ -102,7 +136,7 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
             const float4 b = *reinterpret_cast<const float4*>(bkn + ((int64_t)s * ST_SB_BLOCKS + lane) * 4);
             const int bx = (s % nsb_x) * ST_SBX + (lane % ST_SBX), by = (s / nsb_x) * ST_SBY + (lane / ST_SBX);
             const int sx = bx * ST_BW, sy = by * ST_BH;
-            if (st_match(b, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fty0, fty1)) {
+            if (st_match(b, (float)sx, (float)(sx + ST_BW - 1), (float)sy, (float)(sy + ST_BH - 1), ftx0, ftx1, fsy0, fsy1)) {
                 rxmin = fminf(rxmin, b.x); rxmax = fmaxf(rxmax, b.y); rymin = fminf(rymin, b.z); rymax = fmaxf(rymax, b.w);
                 cx0 = min(cx0, sx); cx1 = max(cx1, sx + ST_BW - 1); cy0 = min(cy0, sy); cy1 = max(cy1, sy + ST_BH - 1);
                 const int k = atomicAdd(&cnt[1], 1);
@@ -122,22 +156,42 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
         }
     }
     __syncthreads();
-
-    // ---- the walk: a rectangle of source pixels, or the queued blocks (everything below is workgroup-uniform) ----
-    int X0 = 0, X1 = W - 1, Y0 = 0, Y1 = H - 1;
-    bool rect = true;
-    int n_chunks = 0;
+    int n_match = 0;
+    bool bounded = false;                                               // the joint flow bounds are finite and int-safe
     if (!sb_over) {
-        const int n_match = cnt[1];
+        n_match = cnt[1];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             rxmin = fminf(rxmin, redf[k * 4 + 0]); rxmax = fmaxf(rxmax, redf[k * 4 + 1]);
             rymin = fminf(rymin, redf[k * 4 + 2]); rymax = fmaxf(rymax, redf[k * 4 + 3]);
             cx0 = min(cx0, redi[k * 4 + 0]); cx1 = max(cx1, redi[k * 4 + 1]); cy0 = min(cy0, redi[k * 4 + 2]); cy1 = max(cy1, redi[k * 4 + 3]);
         }
-        if (n_match > 0) {
+        bounded = fabsf(rxmin) < 1.0e6f && fabsf(rxmax) < 1.0e6f && fabsf(rymin) < 1.0e6f && fabsf(rymax) < 1.0e6f;
+    }
+
+    const float* fl = P.flow + (int64_t)n * P.flow_bstride;
+    const float* mt = P.metric ? P.metric + (int64_t)n * HW : nullptr;
+    const float* inn = P.img + (int64_t)n * P.img_bstride;
+    float* on = P.out_f32 ? P.out_f32 + (int64_t)n * C * HW : nullptr;
+    const int G = (C + 7) >> 3;
+    unsigned char* sp = P.out_spk ? P.out_spk + (int64_t)n * G * 2 * HW * 16 : nullptr;
+    bool bad = false;
+
+    // ---- the walk of one tile: a rectangle of source pixels, or the queued blocks (everything here is workgroup-uniform) ----
+    int ty0 = 0;                                                        // tile being accumulated
+    int X0 = 0, Y0 = 0, Rw = 1, Rh = 0, n_chunks = 0;
+    bool rect = true;
+    int rx = 0, ry = 0, dqx = 0, dqy = 0;                               // rectangle walk: this thread's next pixel (column, row) and the step of 256 pixels
+    auto plan_tile = [&](int k) __attribute__((always_inline)) {
+        ty0 = sy0 + k * TH;
+        const float fty0 = (float)ty0, fty1 = (float)(ty0 + TH - 1);
+        int X1 = W - 1, Y1 = H - 1;
+        X0 = 0; Y0 = 0; rect = true; n_chunks = 0;
+        if (sb_over) {
+            n_chunks = (int)((HW + 255) / 256);
+        } else if (n_match > 0) {
             X0 = cx0; X1 = min(cx1, W - 1); Y0 = cy0; Y1 = min(cy1, H - 1);
-            if (fabsf(rxmin) < 1.0e6f && fabsf(rxmax) < 1.0e6f && fabsf(rymin) < 1.0e6f && fabsf(rymax) < 1.0e6f) {   // finite, int-safe
+            if (bounded) {
                 // x + fx >= tx0 - 2 and x + fx <= tx1 + 1 for some fx in [rxmin, rxmax]  (st_match for a single pixel)
                 X0 = max(X0, (int)floorf(ftx0 - 2.0f - rxmax)); X1 = min(X1, (int)ceilf(ftx1 + 1.0f - rxmin));
                 Y0 = max(Y0, (int)floorf(fty0 - 2.0f - rymax)); Y1 = min(Y1, (int)ceilf(fty1 + 1.0f - rymin));
@@ -146,17 +200,13 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
             rect = n_match > SA_Q || area <= (int64_t)256 * n_match;    // never more pixels than the block walk would visit
             n_chunks = rect ? (int)((area + 255) / 256) : n_match;
         }
-    } else {
-        n_chunks = (int)((HW + 255) / 256);
-    }
-    const int Rw = max(X1 - X0 + 1, 1), Rh = max(Y1 - Y0 + 1, 0);
-    // rectangle walk: thread t of chunk k is pixel 256 k + t of the rectangle in row-major order, kept as (column, row)
-    int rx = tid % Rw, ry = tid / Rw;
-    const int dqx = 256 % Rw, dqy = 256 / Rw;
-
-    const float* fl = P.flow + (int64_t)n * P.flow_bstride;
-    const float* mt = P.metric ? P.metric + (int64_t)n * HW : nullptr;
-    const float* inn = P.img + (int64_t)n * P.img_bstride;
+        Rw = max(X1 - X0 + 1, 1); Rh = max(Y1 - Y0 + 1, 0);
+        rx = tid % Rw; ry = tid / Rw;
+        dqx = 256 % Rw; dqy = 256 / Rw;
+#if defined(SA_ABLATE) && SA_ABLATE == 1                              // diagnostic: search + zero + finish only
+        n_chunks = 0;
+#endif
+    };
 
     auto load_chunk = [&](SaBuf<CB, U>& b, int u, int k) __attribute__((always_inline)) {
         int x, y;
@@ -219,17 +269,68 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
                     v = wgt;                                               // normalisation accumulator
                 }
                 double* pc = cell + c * CELLS;
+#if defined(SA_ABLATE) && SA_ABLATE == 2                              // diagnostic: everything but the LDS atomics
+                asm volatile("" :: "v"(pc), "v"(v * g.wnw), "v"(v * g.wne), "v"(v * g.wsw), "v"(v * g.wse), "v"((int)vnw + (int)vne + (int)vsw + (int)vse));
+#else
                 if (vnw) atomicAdd(pc, (double)(v * g.wnw));               // the reference's fp32 products (softSplat.py:40-51), summed in fp64
                 if (vne) atomicAdd(pc + 1, (double)(v * g.wne));
                 if (vsw) atomicAdd(pc + TW, (double)(v * g.wsw));
                 if (vse) atomicAdd(pc + TW + 1, (double)(v * g.wse));
+#endif
+            }
+        }
+    };
+    // finish and write tile (tx0, fy0): (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349); the cells are left zeroed
+    auto finish = [&](int fy0) __attribute__((always_inline)) {
+        for (int i = tid; i < CELLS; i += 256) {
+            const int x = tx0 + i % TW, y = fy0 + i / TW;
+            float norm = 1.0f;
+            if (MODE >= 1) { norm = (float)acc[CB * CELLS + i]; acc[CB * CELLS + i] = 0.0; if (norm == 0.0f) norm = 1.0f; }
+            float o[CB];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                float v = (float)acc[c * CELLS + i];
+                acc[c * CELLS + i] = 0.0;
+                if (MODE >= 1) v = v / norm;
+                o[c] = cbase + c < C ? (v - 0.5f) * 2.0f : 0.0f;
+            }
+            if (x >= W || y >= H) continue;
+            const int64_t pix = (int64_t)y * W + x;
+            if (on) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c)
+                    if (cbase + c < C) on[(int64_t)(cbase + c) * HW + pix] = o[c];
+            }
+            if constexpr (CB % 8 == 0) {
+                if (sp) {
+#pragma unroll
+                    for (int g8 = 0; g8 < CB / 8; ++g8) {
+                        const int gi = (cbase >> 3) + g8;
+                        if (gi >= G) break;
+                        sa_h8 hi, lo;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            _Float16 h_, l_;
+                            fldr_split_hl(o[g8 * 8 + k], h_, l_, bad);
+                            hi[k] = h_; lo[k] = l_;
+                        }
+                        unsigned char* d = sp + ((int64_t)gi * 2 * HW + pix) * 16;
+                        *reinterpret_cast<sa_h8*>(d) = hi;
+                        *reinterpret_cast<sa_h8*>(d + HW * 16) = lo;
+                    }
+                }
             }
         }
     };
 
-    if (n_chunks > 0) {
-        SaBuf<CB, U> b0, b1;
-        load_iter(b0, 0);
+    SaBuf<CB, U> b0, b1;
+    plan_tile(0);
+    if (n_chunks > 0) load_iter(b0, 0);
+#pragma unroll 1
+    for (int k = 0; k < K; ++k) {
+        const int cur_y0 = ty0;
+        if (cur_y0 >= H) break;                                         // workgroup-uniform
+        // tile k: its first iteration's loads are already in flight in b0
         for (int k0 = 0; k0 < n_chunks; k0 += 2 * U) {
             const bool more = k0 + U < n_chunks;
             if (more) load_iter(b1, k0 + U);
@@ -238,79 +339,45 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
             if (k0 + 2 * U < n_chunks) load_iter(b0, k0 + 2 * U);
             process(b1);
         }
-    }
-    __syncthreads();
-
-    // ---- finish and write the tile: (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349) ----
-    float* on = P.out_f32 ? P.out_f32 + (int64_t)n * C * HW : nullptr;
-    const int G = (C + 7) >> 3;
-    unsigned char* sp = P.out_spk ? P.out_spk + (int64_t)n * G * 2 * HW * 16 : nullptr;
-    bool bad = false;
-    for (int i = tid; i < CELLS; i += 256) {
-        const int x = tx0 + i % TW, y = ty0 + i / TW;
-        if (x >= W || y >= H) continue;
-        const int64_t pix = (int64_t)y * W + x;
-        float norm = 1.0f;
-        if (MODE >= 1) { norm = (float)acc[CB * CELLS + i]; if (norm == 0.0f) norm = 1.0f; }
-        float o[CB];
-#pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            float v = (float)acc[c * CELLS + i];
-            if (MODE >= 1) v = v / norm;
-            o[c] = cbase + c < C ? (v - 0.5f) * 2.0f : 0.0f;
-        }
-        if (on) {
-#pragma unroll
-            for (int c = 0; c < CB; ++c)
-                if (cbase + c < C) on[(int64_t)(cbase + c) * HW + pix] = o[c];
-        }
-        if constexpr (CB % 8 == 0) {
-            if (sp) {
-#pragma unroll
-                for (int g8 = 0; g8 < CB / 8; ++g8) {
-                    const int gi = (cbase >> 3) + g8;
-                    if (gi >= G) break;
-                    sa_h8 hi, lo;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        _Float16 h_, l_;
-                        fldr_split_hl(o[g8 * 8 + k], h_, l_, bad);
-                        hi[k] = h_; lo[k] = l_;
-                    }
-                    unsigned char* d = sp + ((int64_t)gi * 2 * HW + pix) * 16;
-                    *reinterpret_cast<sa_h8*>(d) = hi;
-                    *reinterpret_cast<sa_h8*>(d + HW * 16) = lo;
-                }
-            }
-        }
+        // the next tile's first loads go out before this tile is written
+        const bool next = k + 1 < K && sy0 + (k + 1) * TH < H;
+        if (next) { plan_tile(k + 1); if (n_chunks > 0) load_iter(b0, 0); }
+        __syncthreads();
+        finish(cur_y0);
+        if (!next) break;
+        __syncthreads();
     }
     fldr_note_range(bad);
 }
 
 int fldr_range_read_acc64(int reset) { return fldr_tu_range_read(reset); }
 
-template <int MODE, int CB, int TW, int TH, int U>
-static int sa_launch2(const SaArgs& a, int nprob, hipStream_t s) {
+template <int MODE, int CB, int TW, int TH, int K, int U>
+static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
     constexpr int CA = MODE >= 1 ? CB + 1 : CB;
     constexpr int LDS = CA * TW * TH * 8 + SA_Q * 4 + 16 * 4 + 16 * 4 + 2 * 4 + SA_SBQ * 2;
     static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
     static std::atomic<uint64_t> attr_done{0};
-    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&splat_acc64_kernel<MODE, CB, TW, TH, U>), LDS, attr_done)) return e;
-    const int64_t z = (int64_t)nprob * a.N * a.groups;
-    if (z > 65535) return FLDR_E_SHAPE;
-    dim3 grid(fldr_cdiv(a.W, TW), fldr_cdiv(a.H, TH), (unsigned)z);
-    hipLaunchKernelGGL((splat_acc64_kernel<MODE, CB, TW, TH, U>), grid, dim3(256), LDS, s, a);
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&splat_acc64_kernel<MODE, CB, TW, TH, K, U>), LDS, attr_done)) return e;
+    a.tiles_x = fldr_cdiv(a.W, TW);
+    a.st_y = fldr_cdiv(a.H, K * TH);
+    a.n_st = a.tiles_x * a.st_y;
+    const int64_t total = (int64_t)nprob * a.N * a.groups * a.n_st;
+    if (total > (1ll << 30)) return FLDR_E_SHAPE;
+    a.total = (int)total;
+    a.per_xcd = (a.total + 7) / 8;
+    hipLaunchKernelGGL((splat_acc64_kernel<MODE, CB, TW, TH, K, U>), dim3(8 * a.per_xcd), dim3(256), LDS, s, a);
     return 0;
 }
 
-// Images (<= 3 channels): every channel + the normalisation sum in one 60 x 24 tile (46 KB: three workgroups per CU; 3840 and
-// 2304 / 2160 are whole multiples), four source pixels per thread in flight.  Anything wider: groups of 16 channels (two packed
-// groups), 32 x 16 tiles (70 KB), one pixel per thread in flight.
+// Images (<= 3 channels): every channel + the normalisation sum in one 64 x 24 tile (48 KB: three workgroups per CU; rows are
+// 256-byte aligned), three tiles per workgroup (72 rows: 2304 / 72 = 32), four source pixels per thread in flight.  Anything wider: groups of 16
+// channels (two packed groups), 32 x 8 tiles (35 KB: four workgroups per CU), one pixel per thread in flight.
 template <int MODE>
 static int sa_launch(SaArgs& a, int nprob, hipStream_t s) {
-    if (a.C <= 3) { a.groups = 1; return sa_launch2<MODE, 3, 60, 24, 4>(a, nprob, s); }
+    if (a.C <= 3) { a.groups = 1; return sa_launch2<MODE, 3, SA_IMG_TW, SA_IMG_TH, SA_IMG_K, SA_IMG_U>(a, nprob, s); }
     a.groups = fldr_cdiv(a.C, 16);
-    return sa_launch2<MODE, 16, 32, 16, 1>(a, nprob, s);
+    return sa_launch2<MODE, 16, SA_FEAT_TW, SA_FEAT_TH, SA_FEAT_K, SA_FEAT_U>(a, nprob, s);
 }
 
 extern "C" int fldr_softsplat_acc64(const fldr_splat_acc_desc* d, fldr_stream_t stream) {
@@ -319,23 +386,32 @@ extern "C" int fldr_softsplat_acc64(const fldr_splat_acc_desc* d, fldr_stream_t 
     if ((int64_t)fldr_cdiv(d->W, ST_SBX * ST_BW) * fldr_cdiv(d->H, ST_SBY * ST_BH) > 65535) return FLDR_E_SHAPE;
     SaArgs a;
     a.N = d->N; a.C = d->C; a.H = d->H; a.W = d->W; a.groups = 1;
+    // maps of at most SA_WHOLE_PIXELS pixels (the coarse pyramid levels) need no tables: flags bit 2 forces that walk for any size
+    a.whole = ((d->flags & 4) || (!(d->flags & 3) && (int64_t)d->H * d->W <= SA_WHOLE_PIXELS)) ? 1 : 0;
     a.nsb_x = fldr_cdiv(d->W, ST_SBX * ST_BW);
     a.nsb = a.nsb_x * fldr_cdiv(d->H, ST_SBY * ST_BH);
     hipStream_t s = fldr_s(stream);
     const int64_t HW = (int64_t)d->H * d->W;
     for (int k = 0; k < 2; ++k) {
         const int j = k < d->nprob ? k : 0;
-        FLDR_CHECK_ARG(d->img[j] && d->flow[j] && d->ws[j] && (d->out_f32[j] || d->out_spk[j]));
+        FLDR_CHECK_ARG(d->img[j] && d->flow[j] && (a.whole || d->ws[(d->flags & 2) ? 0 : j]) && (d->out_f32[j] || d->out_spk[j]));
         FLDR_CHECK_ARG(d->mode != 2 || d->metric[j] != nullptr);
         FLDR_CHECK_ARG(!d->out_spk[j] || d->C > 3);                     // packed output: the 16-channel configuration only
         SaProblem& p = a.p[k];
         p.img = d->img[j]; p.flow = d->flow[j]; p.metric = d->metric[j];
-        p.blk = d->ws[j]; p.sbt = d->ws[j] + (int64_t)d->N * a.nsb * ST_SB_BLOCKS * 4;
+        if (a.whole) {
+            p.blk = p.sbt = nullptr;
+        } else if (d->flags & 2) {                                             // ws[0]: tables of the 2 N flows of both problems (fldr_splat_bounds_upsampled_pair)
+            p.blk = d->ws[0] + (int64_t)k * d->N * a.nsb * ST_SB_BLOCKS * 4;
+            p.sbt = d->ws[0] + (int64_t)d->nprob * d->N * a.nsb * ST_SB_BLOCKS * 4 + (int64_t)k * d->N * a.nsb * 4;
+        } else {
+            p.blk = d->ws[j]; p.sbt = d->ws[j] + (int64_t)d->N * a.nsb * ST_SB_BLOCKS * 4;
+        }
         p.out_f32 = d->out_f32[j]; p.out_spk = reinterpret_cast<unsigned char*>(d->out_spk[j]);
         p.img_bstride = d->img_bstride[j];
         p.img_cstride = d->img_cstride[j] ? d->img_cstride[j] : HW;
         p.flow_bstride = d->flow_bstride[j] ? d->flow_bstride[j] : 2 * HW;
-        if (k < d->nprob && !(d->flags & 1))
+        if (k < d->nprob && !a.whole && !(d->flags & 3))
             fldr_splat_bounds_launch(p.flow, p.flow_bstride, const_cast<float*>(p.blk), const_cast<float*>(p.sbt), d->N, d->H, d->W, a.nsb_x, a.nsb, s);
     }
     int e;

@@ -94,38 +94,86 @@ void fldr_splat_bounds_launch(const float* flow, int64_t flow_bstride, float* bl
 // bilinear weights are a convex combination, so every value of a 64x4 block lies between the extremes of the low-resolution
 // pixels its rows and columns interpolate between (fldr_lin_src is monotone: the footprint is the index range of the block's
 // first and last pixel), widened by 2e-6 of the magnitude for the roundings of the three interpolation steps.  The bounds
-// only select candidate sources (st_match / the trimmed walk): a superset is exact.  One wave per super-block, lane = block;
-// 2 MB read instead of the two full-resolution flow planes (4K: 23 -> 3 us).
-__global__ __launch_bounds__(64) void splat_bounds_up_kernel(const float* __restrict__ lo, int64_t lo_bstride, const float* __restrict__ tv,
+// only select candidate sources (st_match / the trimmed walk): a superset is exact.  2 MB read instead of the two
+// full-resolution flow planes.
+// pair (0: off): blockIdx.y runs over the 2 N flows of BOTH problems of a pair call, lo = the [N,4,h,w] level flow (channels
+// 0-1 flow_10, 2-3 flow_01), table sample k N + n = problem k, sample n.  pair 1 = the level-0 image splats (fLDRnet.py:
+// 404-405, 449-450: problem 0 = t * flow_01, problem 1 = (1 - t) * flow_10), pair 2 = the feature splats of a level (:386-387:
+// problem 0 = flow_10 — feat1's flow —, problem 1 = flow_01, unscaled).
+// One workgroup of 16 waves per super-block: wave v takes blocks v, v + 16, v + 32, v + 48, lanes run over the columns of a
+// block's low-resolution footprint (all loads of a wave's four blocks are independent), wave shuffles reduce, LDS joins the
+// 64 block bounds into the super-block's.  (The first version ran one LANE per block over its footprint — 99 dependent
+// iterations for a x2 upsampling: 12-22 us per launch whatever the size, rocprofv3 round 3; this one is ~3 us.)
+#define ST_UP_WAVES 16
+__global__ __launch_bounds__(64 * ST_UP_WAVES) void splat_bounds_up_kernel(const float* __restrict__ lo, int64_t lo_bstride, const float* __restrict__ tv,
                                                              int smode, float mul, float* __restrict__ blk, float* __restrict__ sbt,
-                                                             int h, int w, int H, int W, float sy, float sx, int nsb_x, int nsb) {
+                                                             int h, int w, int H, int W, float sy, float sx, int nsb_x, int nsb,
+                                                             int pair, int N) {
 #pragma clang fp contract(off)
-    const int sb = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
-    const int X0 = ((sb % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
+    __shared__ float red[ST_UP_WAVES][4];
+    const int sb = blockIdx.x, lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int n = blockIdx.y;
+    const int tab = n;                                                  // table sample
+    if (pair) {
+        const int k = n / N;
+        n -= k * N;
+        const bool second_half = (pair == 1) == (k == 0);             // channels 2-3 (flow_01)
+        lo += second_half ? 2 * (int64_t)h * w : 0;
+        smode = pair == 1 ? (k == 0 ? 1 : 2) : 0;
+    }
     const float INF = __builtin_inff();
-    float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
-    if (X0 < W && Y0 < H) {
-        const float scale = smode == 0 ? 1.0f : (smode == 1 ? tv[n] : 1.0f - tv[n]);
-        int c0, c1, r0, r1, d0, d1; float l;
-        fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
-        fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
-        const float* px = lo + (int64_t)n * lo_bstride;
-        const float* py = px + (int64_t)h * w;
-        for (int r = r0; r <= r1; ++r)
-            for (int c = c0; c <= c1; ++c) {
-                const float vx = (scale * px[(int64_t)r * w + c]) * mul, vy = (scale * py[(int64_t)r * w + c]) * mul;
-                xmin = fminf(xmin, vx); xmax = fmaxf(xmax, vx); ymin = fminf(ymin, vy); ymax = fmaxf(ymax, vy);
-            }
-        const float ex = fmaxf(fabsf(xmin), fabsf(xmax)) * 2.0e-6f, ey = fmaxf(fabsf(ymin), fabsf(ymax)) * 2.0e-6f;
-        xmin -= ex; xmax += ex; ymin -= ey; ymax += ey;
-    }
-    *reinterpret_cast<float4*>(blk + (((int64_t)n * nsb + sb) * ST_SB_BLOCKS + lane) * 4) = make_float4(xmin, xmax, ymin, ymax);
+    const float scale = smode == 0 ? 1.0f : (smode == 1 ? tv[n] : 1.0f - tv[n]);
+    const float* px = lo + (int64_t)n * lo_bstride;
+    const float* py = px + (int64_t)h * w;
+    float sxmin = INF, sxmax = -INF, symin = INF, symax = -INF;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-        ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    for (int j = 0; j < ST_SB_BLOCKS / ST_UP_WAVES; ++j) {
+        const int b = wv + j * ST_UP_WAVES;                             // block of the super-block (wave-uniform)
+        const int X0 = ((sb % nsb_x) * ST_SBX + b % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + b / ST_SBX) * ST_BH;
+        float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
+        if (X0 < W && Y0 < H) {                                         // wave-uniform
+            int c0, c1, r0, r1, d0, d1; float l;
+            fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
+            fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
+            // footprint: at most ST_BH + 1 rows and ST_BW + 2 columns when upsampling (H >= h, W >= w: host-checked).  Clamped indices
+            // instead of loop bounds (a repeated pixel does not change a minimum): all 2 * 5 * 2 loads are independent and issued
+            // back to back — with data-dependent loop bounds every iteration waited for its own loads.
+            float vx[(ST_BH + 1) * 2], vy[(ST_BH + 1) * 2];
+#pragma unroll
+            for (int k = 0; k < ST_BH + 1; ++k) {
+                const int r = min(r0 + k, r1);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int c = min(c0 + lane + 64 * j, c1);
+                    vx[k * 2 + j] = px[(int64_t)r * w + c]; vy[k * 2 + j] = py[(int64_t)r * w + c];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < (ST_BH + 1) * 2; ++k) {
+                const float ax = (scale * vx[k]) * mul, ay = (scale * vy[k]) * mul;
+                xmin = fminf(xmin, ax); xmax = fmaxf(xmax, ax); ymin = fminf(ymin, ay); ymax = fmaxf(ymax, ay);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+                ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+            }
+            const float ex = fmaxf(fabsf(xmin), fabsf(xmax)) * 2.0e-6f, ey = fmaxf(fabsf(ymin), fabsf(ymax)) * 2.0e-6f;
+            xmin -= ex; xmax += ex; ymin -= ey; ymax += ey;
+        }
+        if (lane == 0) *reinterpret_cast<float4*>(blk + (((int64_t)tab * nsb + sb) * ST_SB_BLOCKS + b) * 4) = make_float4(xmin, xmax, ymin, ymax);
+        sxmin = fminf(sxmin, xmin); sxmax = fmaxf(sxmax, xmax); symin = fminf(symin, ymin); symax = fmaxf(symax, ymax);
     }
-    if (lane == 0) *reinterpret_cast<float4*>(sbt + ((int64_t)n * nsb + sb) * 4) = make_float4(xmin, xmax, ymin, ymax);
+    if (lane == 0) { red[wv][0] = sxmin; red[wv][1] = sxmax; red[wv][2] = symin; red[wv][3] = symax; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 1; k < ST_UP_WAVES; ++k) {
+            sxmin = fminf(sxmin, red[k][0]); sxmax = fmaxf(sxmax, red[k][1]); symin = fminf(symin, red[k][2]); symax = fmaxf(symax, red[k][3]);
+        }
+        *reinterpret_cast<float4*>(sbt + ((int64_t)tab * nsb + sb) * 4) = make_float4(sxmin, sxmax, symin, symax);
+    }
 }
 
 // mode: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ 1 normalisation accumulator
@@ -797,8 +845,26 @@ extern "C" int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstr
     const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
     float* blk = ws;
     float* sbt = ws + (int64_t)N * nsb * ST_SB_BLOCKS * 4;
-    hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, N), dim3(64), 0, fldr_s(stream), flow_lo, lo_bstride, t, scale_mode, mul, blk, sbt,
-                       h, w, H, W, (float)h / (float)H, (float)w / (float)W, nsb_x, nsb);
+    hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, N), dim3(64 * ST_UP_WAVES), 0, fldr_s(stream), flow_lo, lo_bstride, t, scale_mode, mul, blk, sbt,
+                       h, w, H, W, (float)h / (float)H, (float)w / (float)W, nsb_x, nsb, 0, N);
+    FLDR_LAUNCH_RET();
+}
+
+// Both bounds tables of a pair call of fldr_softsplat_acc64 (flags bit 1) in ONE launch, from the [N,4,h,w] flow of a pyramid
+// level (channels 0-1 flow_10, 2-3 flow_01; samples lo_bstride floats apart, 0 = 4*h*w): pair 1 = the level-0 image splats
+// (problem 0: flow = up(t * flow_01) * mul, problem 1: up((1 - t) * flow_10) * mul), pair 2 = the feature splats (problem 0:
+// up(flow_10) * mul, problem 1: up(flow_01) * mul).  ws: 2 * fldr_softsplat_tile_ws_floats(N, H, W) floats.
+extern "C" int fldr_splat_bounds_upsampled_pair(const float* flow_l, int64_t lo_bstride, const float* t, int pair, float mul, float* ws,
+                                                int N, int h, int w, int H, int W, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(flow_l && ws && N > 0 && h > 0 && w > 0 && H >= h && W >= w && (pair == 1 || pair == 2) && mul > 0.0f);
+    FLDR_CHECK_ARG(pair == 2 || t != nullptr);
+    if (W > 65535 * ST_BW || H > 32767 * ST_BH) return FLDR_E_SHAPE;
+    if ((int64_t)fldr_cdiv(W, ST_SBX * ST_BW) * fldr_cdiv(H, ST_SBY * ST_BH) > 65535) return FLDR_E_SHAPE;
+    const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
+    float* blk = ws;
+    float* sbt = ws + (int64_t)2 * N * nsb * ST_SB_BLOCKS * 4;
+    hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, 2 * N), dim3(64 * ST_UP_WAVES), 0, fldr_s(stream), flow_l, lo_bstride ? lo_bstride : 4 * (int64_t)h * w, t, 0,
+                       mul, blk, sbt, h, w, H, W, (float)h / (float)H, (float)w / (float)W, nsb_x, nsb, pair, N);
     FLDR_LAUNCH_RET();
 }
 

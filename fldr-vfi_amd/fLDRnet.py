@@ -247,15 +247,19 @@ class DCTVFInet(nn.Module):
                 w1, w0 = fldr_hip.softsplat_gather([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax")   # :386-387
             elif spk and B == 1 and half % 8 == 0 and fldr_hip.SPLAT_FEATURES == "acc64":
                 # both directions in one launch of the fp64-LDS-atomic tile splat: no accumulator, memset or normalisation pass
+                # (maps of <= 2304 pixels need no table: every tile walks the whole map)
+                bw = fldr_hip.splat_bounds_upsampled_pair(flow_l_prev, None, "features", W / flow_l_prev.shape[3], H, W) if H * W > 2304 else None
                 wpair = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False,
-                                                 want_spk=True, spk_batch=True)                        # :386-387
+                                                 want_spk=True, spk_batch=True, bounds_ws=bw)          # :386-387
                 w1, w0 = wpair.sample(0), wpair.sample(1)
             elif spk and B == 1 and half % 8 == 0:
                 wpair = fldr_hip.softsplat_pair_spk(feat1, up[:, :2], feat0, up[:, 2:], "softmax")     # :386-387, one memset / finish
                 w1, w0 = wpair.sample(0), wpair.sample(1)
             elif spk and fldr_hip.SPLAT_FEATURES == "acc64":
                 wpair = None
-                w1, w0 = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True)
+                bw = fldr_hip.splat_bounds_upsampled_pair(flow_l_prev, None, "features", W / flow_l_prev.shape[3], H, W) if H * W > 2304 else None
+                w1, w0 = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True,
+                                                   bounds_ws=bw)
             elif spk:
                 wpair = None
                 w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True)        # :386
@@ -312,12 +316,13 @@ class DCTVFInet(nn.Module):
         flow_t0, flow_t1 = r["flow_t0"], r["flow_t1"]                                                   # :404-405,419-422
         if fldr_hip.SPLAT_BOUNDS == "lowres" and fldr_hip.SPLAT_KERNEL in ("auto", "acc64", "tile"):
             # candidate-source bounds of the two splats from the low-resolution flow their flow_t is the upsampling of
-            b0 = fldr_hip.splat_bounds_upsampled(flow_01_lo, t4, 1, up, H, W)
-            b1 = fldr_hip.splat_bounds_upsampled(flow_10_lo, t4, 2, up, H, W)
-            if fldr_hip.SPLAT_KERNEL != "tile":                   # both image splats in one launch (fp64 LDS atomics)
+            if fldr_hip.SPLAT_KERNEL != "tile":                   # both image splats in one launch (fp64 LDS atomics), one bounds launch
+                bw = fldr_hip.splat_bounds_upsampled_pair(flow_l, t4, "images", up, H, W)
                 warped0, warped1 = fldr_hip.softsplat_acc64([I0, I1], [flow_t0, flow_t1], [z0, z1] if z0 is not None else None,
-                                                            self.softsplat.strType, bounds_ws=[b0, b1])    # :449-450
+                                                            self.softsplat.strType, bounds_ws=bw)          # :449-450
             else:
+                b0 = fldr_hip.splat_bounds_upsampled(flow_01_lo, t4, 1, up, H, W)
+                b1 = fldr_hip.splat_bounds_upsampled(flow_10_lo, t4, 2, up, H, W)
                 warped0 = fldr_hip.softsplat_fused(I0, flow_t0, z0, self.softsplat.strType, bounds_ws=b0)   # :449
                 warped1 = fldr_hip.softsplat_fused(I1, flow_t1, z1, self.softsplat.strType, bounds_ws=b1)   # :450
         else:

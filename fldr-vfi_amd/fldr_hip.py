@@ -102,6 +102,8 @@ _SIGNATURES = {
     "fldr_softsplat_gather": (ctypes.c_int, [ctypes.POINTER(SplatGatherDesc), ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_softsplat_acc64": (ctypes.c_int, [ctypes.POINTER(SplatAccDesc), ctypes.c_void_p]),
+    "fldr_splat_bounds_upsampled_pair": (ctypes.c_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int, ctypes.c_float, _c_float_p]
+                                         + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_tile_strided": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_int64] + [_c_float_p] * 4 + [ctypes.c_int] * 5
                                     + [ctypes.c_void_p]),
@@ -323,6 +325,23 @@ def splat_bounds_upsampled(flow_lo, t, scale_mode, mul, H, W):
     return ws
 
 
+def splat_bounds_upsampled_pair(flow_l, t, pair, mul, H, W):
+    """Both bounds tables of a two-problem softsplat_acc64 call in one launch (pass the result as bounds_ws): flow_l [N,4,h,w] =
+    the flow of a pyramid level; pair = "images" (problem 0: flow = up(t * flow_l[:, 2:]) * mul, problem 1:
+    up((1 - t) * flow_l[:, :2]) * mul) or "features" (problem 0: up(flow_l[:, :2]) * mul, problem 1: up(flow_l[:, 2:]) * mul)."""
+    N, four, h, w = flow_l.shape
+    assert four == 4 and flow_l.stride(3) == 1 and flow_l.stride(2) == w and flow_l.stride(1) == h * w
+    ws = torch.empty(2 * lib().fldr_softsplat_tile_ws_floats(N, H, W), device=flow_l.device, dtype=torch.float32)
+    if t is not None:
+        t = t.reshape(N).contiguous().float()
+    if not flow_l.is_cuda or flow_l.dtype != torch.float32:
+        raise TypeError("flow_l must be a float32 device tensor")
+    _check(lib().fldr_splat_bounds_upsampled_pair(ctypes.c_void_p(flow_l.data_ptr()), flow_l.stride(0) if N > 1 else 0, _dev(t, "t") if t is not None else None,
+                                                  {"images": 1, "features": 2}[pair], float(mul), _dev(ws, "ws"), N, h, w, H, W, _stream()),
+           "fldr_splat_bounds_upsampled_pair")
+    return ws
+
+
 def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None, want_spk=False, out_spk=None, bounds_ws=None):
     """FunctionSoftsplat (softSplat.py:320-352).  want_spk: return the result split-packed (Spk) instead of fp32 NCHW
     (written into `out_spk`, a Spk of the same shape, when given).  bounds_ws: a bounds table from splat_bounds_upsampled
@@ -417,9 +436,13 @@ def softsplat_acc64(imgs, flows, metrics=None, mode="softmax", want_f32=True, wa
             _dev(mt, "metric")
             keep.append(mt)
         d.metric[k] = mt.data_ptr() if mt is not None else None
-        ws = bounds_ws[k] if bounds_ws is not None else torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=im.device, dtype=torch.float32)
+        if torch.is_tensor(bounds_ws):                       # one table for both problems (splat_bounds_upsampled_pair)
+            ws = bounds_ws
+        else:
+            ws = bounds_ws[k] if bounds_ws is not None else (torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=im.device, dtype=torch.float32)
+                                                            if H * W > 2304 else None)      # (small maps: no tables, see the header)
         keep.append(ws)
-        d.ws[k] = ws.data_ptr()
+        d.ws[k] = ws.data_ptr() if ws is not None else None
         o32 = torch.empty(N, C, H, W, device=im.device, dtype=torch.float32) if want_f32 else None
         if batch is not None:
             osp = batch.sample(k)
@@ -429,7 +452,8 @@ def softsplat_acc64(imgs, flows, metrics=None, mode="softmax", want_f32=True, wa
         d.out_spk[k] = osp.ptr if osp is not None else None
         outs.append((o32, osp) if (want_f32 and want_spk) else (osp if want_spk else o32))
     d.nprob, d.N, d.C, d.H, d.W, d.mode = nd, N, C, H, W, _MODES[mode]
-    d.flags = 1 if bounds_ws is not None else 0
+    d.flags = 0 if bounds_ws is None else (2 if torch.is_tensor(bounds_ws) else 1)
+    assert not torch.is_tensor(bounds_ws) or nd == 2
     _check(lib().fldr_softsplat_acc64(ctypes.byref(d), _stream()), "fldr_softsplat_acc64")
     return batch if batch is not None else outs
 

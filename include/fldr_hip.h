@@ -86,8 +86,16 @@ int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stre
  * two problems of the same shape per call (the two image splats of fLDRnet.py:449-450, the two feature splats of :386-387).
  * img: sample n, channel c at img + n*img_bstride + c*img_cstride floats (cstride 0 = H*W); flow [N,2,H,W], samples
  * flow_bstride floats apart (0 = 2*H*W); metric [N,1,H,W] contiguous or NULL; ws: fldr_softsplat_tile_ws_floats(N,H,W)
- * floats per problem (flags bit 0: it already holds a bounds table, e.g. from fldr_splat_bounds_upsampled);
+ * floats per problem (flags bit 0: it already holds a bounds table, e.g. from fldr_splat_bounds_upsampled; bit 2, and
+ * automatically for maps of at most 2304 pixels when no table is passed: no tables, every tile walks the whole map, ws unused);
  * out_f32 [N,C,H,W] and / or out_spk (packed, C > 3 only; fldr_spk_bytes per sample). */
+/* flags bit 1: ws[0] holds the tables of BOTH problems as written by fldr_splat_bounds_upsampled_pair (ONE launch for the two
+ * flows of a pyramid level: pair 1 = the level-0 image splats, problem 0: flow = up(t * flow_01) * mul, problem 1:
+ * up((1 - t) * flow_10) * mul, fLDRnet.py:404-405; pair 2 = the feature splats, problem 0: up(flow_10) * mul, problem 1:
+ * up(flow_01) * mul, :384-387).  flow_l [N,4,h,w], samples lo_bstride floats apart (0 = 4*h*w); ws: 2 *
+ * fldr_softsplat_tile_ws_floats(N,H,W) floats. */
+int fldr_splat_bounds_upsampled_pair(const float* flow_l, int64_t lo_bstride, const float* t, int pair, float mul, float* ws,
+                                     int N, int h, int w, int H, int W, fldr_stream_t stream);
 typedef struct fldr_splat_acc_desc {
     const float* img[2];
     int64_t      img_bstride[2], img_cstride[2];

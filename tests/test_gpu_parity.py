@@ -497,6 +497,19 @@ def test_acc64_softsplat_frames_in_place_and_low_res_bounds(hip, oracle, dev):
     _cmp(w1, oracle.function_softsplat(I1.contiguous().cpu(), ft1.cpu(), z1.cpu(), "softmax"), atol=3e-5, what="acc64 I1")
     e0, e1 = hip.softsplat_acc64([I0.contiguous(), I1.contiguous()], [ft0, ft1], [z0, z1], "softmax")      # exact bounds pre-pass
     assert torch.equal(e0, w0) and torch.equal(e1, w1)
+    bw = hip.splat_bounds_upsampled_pair(lo, t4, "images", up, H, W)                                       # both tables, one launch
+    p0, p1 = hip.softsplat_acc64([I0, I1], [ft0, ft1], [z0, z1], "softmax", bounds_ws=bw)
+    assert torch.equal(p0, w0) and torch.equal(p1, w1)
+    # the feature pair of a level: flow = the x2 upsampling of the previous level's flow (fLDRnet.py:384-387)
+    C, h, w = 48, 23, 37
+    feat = (torch.rand(1, 2 * C, 2 * h, 2 * w, generator=g) * 2 - 1).to(dev)
+    prev = (torch.randn(1, 4, h, w, generator=g) * 2).to(dev)
+    upf = hip.resize_bilinear(prev, 2 * h, 2 * w, mul=2.0)
+    bwf = hip.splat_bounds_upsampled_pair(prev, None, "features", 2.0, 2 * h, 2 * w)
+    a = hip.softsplat_acc64([feat[:, C:], feat[:, :C]], [upf[:, :2], upf[:, 2:]], None, "softmax", bounds_ws=bwf)
+    b = hip.softsplat_acc64([feat[:, C:], feat[:, :C]], [upf[:, :2], upf[:, 2:]], None, "softmax")
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    _cmp(a[0], oracle.function_softsplat(feat[:, C:].cpu(), upf[:, :2].cpu(), None, "softmax"), atol=3e-5, what="feature pair, low-res bounds")
 
 
 def test_tile_softsplat_extreme_and_smooth_flows(hip, oracle, dev):
@@ -756,6 +769,30 @@ def test_model_matches_oracle_odd_sizes(hip, oracle, weights, dev, model, case):
     err = _cmp(out, ref, atol=1e-4, what="forward %dx%d" % (H, W))
     print("%dx%d: max|err| %.2e" % (H, W, err))
     assert (out.cpu() - ref).abs().mean().item() <= 1e-6
+
+
+@pytest.mark.parametrize("case", ["depth_S3_100x150", "depth_S4_128x200", "depth_S6_300x400", "depth_S7_520x530"])
+def test_model_pyramid_depths(hip, oracle, weights, golden, dev, case):
+    """--test3scales / --test4scales / --test6scales / --test7scales (main.py:243-268): the whole forward with S_tst + 1 pyramid
+    levels (padding unit 2^S_tst * 8) against the REFERENCE's own output at that depth and against the oracle."""
+    import fldr_harness as Hn
+    g = golden(case)
+    S = int(g["S_tst"])
+    m, _, a = Hn.prepare_model(dev, args=Hn.args_config(test_scales=S))
+    frames = Hn.frames_from_uint8(torch.from_numpy(g["frames_u8"]))
+    H, W = frames.shape[-2:]
+    t = torch.tensor([[float(g["t"])]])
+    out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    assert out.shape[-2:] == (H, W) and out.dtype == torch.float64
+    y0, x0, h, w = (int(v) for v in g["window"])
+    err = _cmp(out[..., y0:y0 + h, x0:x0 + w], torch.from_numpy(g["out"]), atol=1e-4, what="S_tst=%d vs reference" % S)
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames, n_levels=S + 1), t)[..., :H, :W]
+    _cmp(out, ref, atol=1e-4, what="S_tst=%d vs oracle" % S)
+    assert (out.cpu() - ref).abs().mean().item() <= 1e-6
+    p8 = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
+    print("S_tst=%d: max|err| vs reference %.2e, 8-bit PSNR vs oracle %.1f dB" % (S, err, p8))
+    assert p8 >= 90.0
 
 
 @pytest.mark.parametrize("case", [(256, 384, 0.5, 11), (200, 456, 0.25, 12)])

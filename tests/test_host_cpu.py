@@ -83,6 +83,29 @@ def test_pad_and_pyramid_match_oracle_and_golden(oracle, golden):
     assert torch.equal(u, torch.from_numpy(g["frames_u8"])) and torch.equal(u, oracle.synthetic_pair(200, 500, 1, True))
 
 
+@pytest.mark.parametrize("S", [3, 4, 6, 7])
+def test_pyramid_depth_configs(oracle, golden, S):
+    """args_config(test_scales=S) = what main.py builds under --papermodel --test<S>scales (main.py:240-273); the harness pads
+    to 2^S * 8 and builds S + 1 levels exactly as the oracle (and the reference fixture) does."""
+    import fldr_harness as Hn
+    name = {3: "depth_S3_100x150", 4: "depth_S4_128x200", 6: "depth_S6_300x400", 7: "depth_S7_520x530"}[S]
+    g = golden(name)
+    a = Hn.args_config(test_scales=S)
+    assert a.S_tst == S and len(a.scales) == S + 1 == len(a.fractions) and a.scales[0] == 8 and a.dctvfi_nf == 16
+    assert a.scales == [8 * 2 ** i for i in range(S + 1)] and a.fractions == [4 ** (i + 1) for i in range(S + 1)]
+    assert a.moreTstSc == (S != 3) and a.phase == "test"
+    fr = Hn.frames_from_uint8(torch.from_numpy(g["frames_u8"]))
+    pyr = Hn.build_pyramid(Hn.pad_frames(fr, a), a)
+    ref = oracle.pad_and_pyramid(fr, n_levels=S + 1)
+    assert len(pyr) == S + 1 and list(pyr[0].shape[-2:]) == list(g["padded"])
+    for i in range(S + 1):
+        assert torch.equal(pyr[i], ref[i])
+    with pytest.raises(ValueError):
+        Hn.args_config(test_scales=2)
+    m = a.net_object(a)                                    # the model builds at any depth (the parameters do not depend on it)
+    assert set(m.state_dict()) == set(Hn.args_config().net_object(Hn.args_config()).state_dict())
+
+
 def test_cpu_tensors_fail_loudly():
     """No CPU fallback anywhere: same behaviour as the reference (softSplat.py:251-252, correlation.py:343-344)."""
     import softSplat

@@ -36,7 +36,31 @@ def test_full_forward_matches_reference(oracle, weights, golden, case):
         np.testing.assert_allclose(cat[..., y0:y0 + h, x0:x0 + w].numpy(), g["cat26_crops"][ci], atol=1e-5)
         np.testing.assert_allclose(keep["refine_out"][..., y0:y0 + h, x0:x0 + w].numpy(),
                                    g["refine_out_crops"][ci], atol=1e-4)
-    np.testing.assert_allclose(out.numpy(), g["out"], atol=1e-6)
+    if g["out"].dtype == np.float64:
+        assert np.array_equal(out.numpy(), g["out"])            # the oracle reproduces the reference's fp64 frame bit for bit
+    else:
+        np.testing.assert_allclose(out.numpy(), g["out"], atol=1e-6)        # (fixture stored as fp32)
+
+
+DEPTHS = ["depth_S3_100x150", "depth_S4_128x200", "depth_S6_300x400", "depth_S7_520x530"]
+
+
+@pytest.mark.parametrize("case", DEPTHS)
+def test_pyramid_depths_match_reference(oracle, weights, golden, case):
+    """--test3scales / --test4scales / --test6scales / --test7scales (main.py:243-268): the oracle at S_tst + 1 levels against
+    the reference's own forward at that depth (fixtures: tools/make_golden.py depth_cases)."""
+    g = golden(case)
+    S = int(g["S_tst"])
+    fr = oracle.frames_from_uint8(torch.from_numpy(g["frames_u8"]))
+    H, W = fr.shape[-2:]
+    pyr = oracle.pad_and_pyramid(fr, n_levels=S + 1)
+    assert list(pyr[0].shape[-2:]) == list(g["padded"]) and len(pyr) == S + 1
+    with torch.no_grad():
+        out = oracle.forward(weights, pyr, torch.tensor([[float(g["t"])]]))[..., :H, :W]
+    y0, x0, h, w = (int(v) for v in g["window"])
+    np.testing.assert_allclose(out[..., y0:y0 + h, x0:x0 + w].numpy(), g["out"], atol=1e-6)
+    np.testing.assert_allclose(out.sum((0, 2, 3)).numpy(), g["out_sum"], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(out.abs().sum((0, 2, 3)).numpy(), g["out_abssum"], rtol=1e-9, atol=1e-6)
 
 
 def test_identity_splat_flows(oracle, weights, golden):

@@ -33,13 +33,14 @@ def images():
         ft1 = (F.interpolate((1 - t4) * lo[:, :2], scale_factor=up, mode="bilinear", align_corners=False) * up).contiguous()
         z0 = -torch.rand(1, 1, H, W, device=dev) * 3; z1 = -torch.rand(1, 1, H, W, device=dev) * 3
         b0 = hip.splat_bounds_upsampled(lo[:, 2:], t4, 1, up, H, W); b1 = hip.splat_bounds_upsampled(lo[:, :2], t4, 2, up, H, W)
+        bw = hip.splat_bounds_upsampled_pair(lo, t4, "images", up, H, W)
         def band(i):
             f = frames[i % 3]
             hip.softsplat_fused(f[:, :, 0], ft0, z0, "softmax", kernel="tile", bounds_ws=b0)
             hip.softsplat_fused(f[:, :, 1], ft1, z1, "softmax", kernel="tile", bounds_ws=b1)
         def acc(i):
             f = frames[i % 3]
-            hip.softsplat_acc64([f[:, :, 0], f[:, :, 1]], [ft0, ft1], [z0, z1], "softmax", bounds_ws=[b0, b1])
+            hip.softsplat_acc64([f[:, :, 0], f[:, :, 1]], [ft0, ft1], [z0, z1], "softmax", bounds_ws=bw)
         tb, ta = timeit(band), timeit(acc)
         f = frames[0]
         r = hip.softsplat_acc64([f[:, :, 0], f[:, :, 1]], [ft0, ft1], [z0, z1], "softmax", bounds_ws=[b0, b1])
@@ -48,14 +49,16 @@ def images():
 
 
 def features():
-    for (h, w) in [(288, 480), (144, 240), (72, 120), (36, 60)]:
+    for (h, w) in [(288, 480), (144, 240), (72, 120), (36, 60), (18, 30)]:
         feat = torch.rand(1, 96, h, w, device=dev) * 2 - 1
         for kind in ("shift", "smooth"):
-            up = flows(kind, h, w)
+            prev = flows(kind, h // 2, w // 2)
+            up = hip.resize_bilinear(prev, h, w, mul=2.0)
             f1, f0 = feat[:, 48:], feat[:, :48]
             f1c, f0c, ua, ub = f1.contiguous(), f0.contiguous(), up[:, :2].contiguous(), up[:, 2:].contiguous()
             tp = timeit(lambda i: hip.softsplat_pair_spk(f1c, ua, f0c, ub, "softmax"))
-            ta = timeit(lambda i: hip.softsplat_acc64([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True, spk_batch=True))
+            ta = timeit(lambda i: hip.softsplat_acc64([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True, spk_batch=True,
+                                                      bounds_ws=hip.splat_bounds_upsampled_pair(prev, None, "features", 2.0, h, w) if h * w > 2304 else None))
             a = hip.softsplat_acc64([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=True, want_spk=False)
             s = hip.softsplat_fused(f1c, ua, None, "softmax", kernel="strip")
             print("features %dx%d %s: strip pair %.1f us | acc64 pair %.1f us | max |acc64 - strip| %.2e" % (h, w, kind, tp, ta, (a[0] - s).abs().max().item()), flush=True)
