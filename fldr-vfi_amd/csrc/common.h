@@ -5,6 +5,16 @@
 #include <atomic>
 #include "fldr_hip.h"
 
+// Tuning / cross-check hooks (fldr_debug_*, include/fldr_hip_test_hooks.h) and the retired kernel generations that only serve as
+// bit-exact cross-checks are compiled into the TEST build only (make hooks: -DFLDR_TEST_HOOKS -> libfldr_hip_test.so, loaded by
+// the test suite through fldr_hip.test_hooks()).  The product library exports the integration ABI of include/fldr_hip.h and
+// nothing else; in it the hook functions are file-local and unused, so the state they would change stays at its default.
+#ifdef FLDR_TEST_HOOKS
+#define FLDR_HOOK extern "C"
+#else
+#define FLDR_HOOK __attribute__((unused)) static
+#endif
+
 #define FLDR_CHECK_ARG(cond) do { if (!(cond)) return FLDR_E_ARG; } while (0)
 #define FLDR_LAUNCH_RET() do { hipError_t e_ = hipGetLastError(); return e_ == hipSuccess ? 0 : (int)e_; } while (0)
 

@@ -26,7 +26,7 @@
 #endif
 __device__ unsigned long long fldr_stamp_buf[4 * 8];
 #define STAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-extern "C" int fldr_debug_read_stamps(unsigned long long* host) {
+FLDR_HOOK int fldr_debug_read_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_stamp_buf), sizeof(unsigned long long) * 32);
 }
 #else
@@ -486,7 +486,7 @@ extern "C" const char* fldr_error_string(int code) {
 }
 
 // Diagnostic: resident workgroups per CU the runtime reports for the main 3x3 instances at their LDS sizes.
-extern "C" int fldr_debug_conv_occupancy(int* out4) {
+FLDR_HOOK int fldr_debug_conv_occupancy(int* out4) {
     int n = 0;
     hipError_t e;
     {

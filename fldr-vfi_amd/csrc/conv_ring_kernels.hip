@@ -55,11 +55,11 @@
 // Diagnostic build only (tools/stamps): per-phase s_memtime sums of consumer wave 0 and loader wave 4 of two workgroups.
 __device__ unsigned long long fldr_ring_stamp_buf[4 * 8];
 __device__ unsigned long long fldr_ring_trace[4 * 24 * 4];            // [wave slot][iteration < 24][event] absolute s_memtime, workgroup 0
-extern "C" int fldr_debug_read_ring_trace(unsigned long long* host) {
+FLDR_HOOK int fldr_debug_read_ring_trace(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_ring_trace), sizeof(unsigned long long) * 4 * 24 * 4);
 }
 #define RSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-extern "C" int fldr_debug_read_ring_stamps(unsigned long long* host) {
+FLDR_HOOK int fldr_debug_read_ring_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_ring_stamp_buf), sizeof(unsigned long long) * 32);
 }
 #else
@@ -67,7 +67,7 @@ extern "C" int fldr_debug_read_ring_stamps(unsigned long long* host) {
 #endif
 
 __device__ int fldr_ring_timeouts;
-extern "C" int fldr_debug_ring_timeouts(void) {
+FLDR_HOOK int fldr_debug_ring_timeouts(void) {
     int v = -1;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_ring_timeouts), sizeof(int)) != hipSuccess) return -1;
     return v;
@@ -126,7 +126,10 @@ __device__ __forceinline__ void ring_signal(uint32_t lds_addr, int lane) {
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NMT, int TERMS, bool HAS_RES, int NC, int TW>
+// ML: multi-level launch (SpkArgs::lv: units of several images of different sizes, one source tensor each; rec_ctx_ds over the
+// pyramid levels).  A template parameter, not a kernel argument: the single-level kernels keep exactly their registers (with
+// the level geometry as run-time state they needed a scratch reservation, and that costs ~2 us per launch).
+template <int NMT, int TERMS, bool HAS_RES, int NC, int TW, bool ML = false>
 __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(SpkArgs a) {
     // NC consumer waves (4: two tile rows each, one consumer per SIMD; 8: one row each, two per SIMD)
     using Cfg = RingCfg<NMT, TW>;
@@ -191,20 +194,35 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         }
         int iss_u = u_first, iss_c = 0, iss_n = 0;
         uint32_t g_full[Cfg::NXI], g_half[Cfg::NXI];                      // byte offsets in a plane; ~0u = outside the image
+        // multi-level launch: base of the unit's level-l source (its group g, kind k plane lies (2 g + k) * ml_plane bytes further)
+        unsigned long long ml_base = 0ull;
+        long long ml_plane = 0;
         auto issue_geometry = [&]() {
+            int uH = a.H, uW = a.W, tiles_x = a.tiles_x, tile, ty;
             const int t = spk_div(iss_u, a.m_groups, a.groups);
-            iss_n = spk_div(t, a.m_tiles, a.n_tiles);
-            const int tile = t - iss_n * a.n_tiles;
-            const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * TW;
+            if constexpr (ML) {
+                int l = 0;
+                for (int k = 1; k < a.n_levels; ++k) l = t * a.groups >= a.lv[k].unit0 ? k : l;
+                uH = a.lv[l].H; uW = a.lv[l].W; tiles_x = a.lv[l].tiles_x;
+                tile = t - a.lv[l].unit0 / a.groups;
+                iss_n = 0;
+                ml_base = a.grp_ptr[0] + (unsigned long long)a.lv[l].in_off;
+                ml_plane = (long long)uH * uW * 16;
+                ty = tile / tiles_x;
+            } else {
+                iss_n = spk_div(t, a.m_tiles, a.n_tiles);
+                tile = t - iss_n * a.n_tiles;
+                ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+            }
+            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * tiles_x) * TW;
 #pragma unroll
             for (int i = 0; i < Cfg::NXI; ++i) {
                 const int e = x_piece[i] + lane;
                 const int y = e / Cfg::IW, x = e % Cfg::IW;
                 const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
-                const bool ok = e < SPK_IH * Cfg::IW && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-                g_full[i] = ok ? (uint32_t)(gy * a.W + gx) * 16u : ~0u;
-                g_half[i] = ok ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : ~0u;
+                const bool ok = e < SPK_IH * Cfg::IW && gy >= 0 && gy < uH && gx >= 0 && gx < uW;
+                g_full[i] = ok ? (uint32_t)(gy * uW + gx) * 16u : ~0u;
+                g_half[i] = ok ? (uint32_t)((gy >> 1) * (uW >> 1) + (gx >> 1)) * 16u : ~0u;
             }
         };
         const char* const iss_w = reinterpret_cast<const char*>(a.wpack + SPK_HDR) + (int64_t)pgrp * n_chunks * pack_w_bytes;
@@ -222,8 +240,9 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             const int gi = iss_c * 2 + igrp;
             const uint32_t e_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_ptr, gi), e_hi = __builtin_amdgcn_readlane((int)(uint32_t)(tab_ptr >> 32), gi);
             const uint32_t b_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_bs, gi), b_hi = __builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)tab_bs >> 32), gi);
-            const unsigned long long e = ((unsigned long long)e_hi << 32) | e_lo;
+            unsigned long long e = ((unsigned long long)e_hi << 32) | e_lo;
             const long long bs = (long long)(((unsigned long long)b_hi << 32) | b_lo);
+            if constexpr (ML) e = e == 0ull ? 0ull : ml_base + (unsigned long long)((2 * gi + ikind) * ml_plane);   // (padding groups stay null)
             const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
             const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * bs;
             const char* dptr[Cfg::NXI];
@@ -290,8 +309,27 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         for (int q = 0; q < NQ; ++q) acc[m][q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
     int cur_u = u_first, cur_c = 0;
     const float inv_scale = a.wpack[0];
-    const int64_t HW = (int64_t)a.H * a.W;
-    const uint32_t HW32 = (uint32_t)HW;                                   // byte offsets below fit 32 bits (host-checked)
+    // geometry of the unit being finished: constants of the kernel, or (ML) the values of the unit's level, set by unit_decode
+    int uH = a.H, uW = a.W;
+    int64_t HW = (int64_t)a.H * a.W;
+    uint32_t HW32 = (uint32_t)HW;                                         // byte offsets below fit 32 bits (host-checked)
+    int64_t u_spk_off = 0, u_f32_off = 0, u_res_off = 0;                  // byte offsets of the unit's level (ML)
+    // (sample, tile row, tile column) of unit u
+    auto unit_decode = [&](int u, int& n, int& ty, int& tx) __attribute__((always_inline)) {
+        const int t = spk_div(u, a.m_groups, a.groups);
+        if constexpr (ML) {
+            int l = 0;
+            for (int k = 1; k < a.n_levels; ++k) l = t * a.groups >= a.lv[k].unit0 ? k : l;
+            uH = a.lv[l].H; uW = a.lv[l].W; HW = (int64_t)uH * uW; HW32 = (uint32_t)HW;
+            u_spk_off = a.lv[l].out_spk_off; u_f32_off = a.lv[l].out_f32_off; u_res_off = a.lv[l].res_off;
+            const int tile = t - a.lv[l].unit0 / a.groups;
+            n = 0; ty = tile / a.lv[l].tiles_x; tx = tile - ty * a.lv[l].tiles_x;
+        } else {
+            n = spk_div(t, a.m_tiles, a.n_tiles);
+            const int tile = t - n * a.n_tiles;
+            ty = spk_div(tile, a.m_tiles_x, a.tiles_x); tx = tile - ty * a.tiles_x;
+        }
+    };
     const int gout = (a.cout_store + 7) >> 3;
     const int cbase = grp0 * MTOT;
     // bias of this lane's 4 channels per 16-channel block: in registers, or (kernels with the deferred epilogue, which need
@@ -311,23 +349,21 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         else return f4{bias_r[m][0], bias_r[m][1], bias_r[m][2], bias_r[m][3]};
     };
     auto unit_pixels = [&](int u, uint32_t (&po)[NQ], int& n) {
-        const int t = spk_div(u, a.m_groups, a.groups);
-        n = spk_div(t, a.m_tiles, a.n_tiles);
-        const int tile = t - n * a.n_tiles;
-        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-        const int ox0 = (tile - ty * a.tiles_x) * TW;
+        int ty, tx;
+        unit_decode(u, n, ty, tx);
+        const int ox0 = tx * TW;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int oy = ty * SPK_TH + ROWS * cw + q / CB;
             const int ox = ox0 + (q % CB) * 16 + lj;
-            po[q] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
+            po[q] = (oy < uH && ox < uW) ? (uint32_t)(oy * uW + ox) : ~0u;
         }
     };
     float res_r[HAS_RES ? NMT : 1][HAS_RES ? NQ : 1][4];
     auto residual_prefetch = [&]() {
         uint32_t po[NQ]; int n;
         unit_pixels(cur_u, po, n);
-        const float* resn = a.residual + (int64_t)n * a.cout_store * HW;
+        const float* resn = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.residual) + u_res_off) + (int64_t)n * a.cout_store * HW;
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -353,19 +389,17 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         // predicates out of the iteration loop and keeps ~20 VGPRs live across the MFMA steps, or spills them)
         int lj = lane & 15, lg = lane >> 4;
         asm volatile("" : "+v"(lj), "+v"(lg));
-        const int t = spk_div(cur_u, a.m_groups, a.groups);
-        const int n = spk_div(t, a.m_tiles, a.n_tiles);
-        const int tile = t - n * a.n_tiles;
-        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-        const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * TW;
-        char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) : nullptr;
-        char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride : nullptr;
-        const bool inside = oy0 + ROWS <= a.H && ox0 + TW <= a.W;    // wave-uniform
+        int n, ty, tx;
+        unit_decode(cur_u, n, ty, tx);
+        const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = tx * TW;
+        char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) + u_f32_off : nullptr;
+        char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride + u_spk_off : nullptr;
+        const bool inside = oy0 + ROWS <= uH && ox0 + TW <= uW;      // wave-uniform
         if (grp_full && inside) {
-            const uint32_t p0 = (uint32_t)(oy0 * a.W + ox0 + lj);
+            const uint32_t p0 = (uint32_t)(oy0 * uW + ox0 + lj);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
-                const uint32_t pq = p0 + (uint32_t)((q / CB) * a.W + (q % CB) * 16);
+                const uint32_t pq = p0 + (uint32_t)((q / CB) * uW + (q % CB) * 16);
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) {
                     const int co0 = cbase + m * 16 + lg * 4;
@@ -400,7 +434,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int oy = oy0 + q / CB, ox = ox0 + (q % CB) * 16 + lj;
-            po[q] = (oy < a.H && ox < a.W) ? (uint32_t)(oy * a.W + ox) : ~0u;
+            po[q] = (oy < uH && ox < uW) ? (uint32_t)(oy * uW + ox) : ~0u;
         }
         const bool quads = !(a.cout_store & 3);                          // whole quads of channels: one predicate per 4 stores
 #pragma unroll
@@ -463,7 +497,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     auto epi_block = [&](int b) __attribute__((always_inline)) {
         if constexpr (CAN_DEFER) {
             const int q = b / NMT, m = b - q * NMT;
-            const uint32_t s_pix = (uint32_t)((q / CB) * a.W + (q % CB) * 16);
+            const uint32_t s_pix = (uint32_t)((q / CB) * uW + (q % CB) * 16);
             const uint32_t s_off = ((uint32_t)(((cbase >> 3) + 2 * m) * 2) * HW32 + s_pix) * 16u;     // wave-uniform
             char* pb = pend_spkn + s_off;
             h4 ohi, olo;
@@ -671,14 +705,12 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             bool parked = false;
             if constexpr (CAN_DEFER) {
                 if (can_park) {
-                    const int t = spk_div(cur_u, a.m_groups, a.groups);
-                    const int n = spk_div(t, a.m_tiles, a.n_tiles);
-                    const int tile = t - n * a.n_tiles;
-                    const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
-                    const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = (tile - ty * a.tiles_x) * TW;
-                    if (oy0 + ROWS <= a.H && ox0 + TW <= a.W) {       // wave-uniform: the fast path of finish_store
-                        pend_voff = ((uint32_t)(oy0 * a.W + ox0 + lj) + (uint32_t)(lg >> 1) * 2u * HW32) * 16u + (uint32_t)(lg & 1) * 8u;
-                        pend_spkn = reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride;
+                    int n, ty, tx;
+                    unit_decode(cur_u, n, ty, tx);
+                    const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = tx * TW;
+                    if (oy0 + ROWS <= uH && ox0 + TW <= uW) {         // wave-uniform: the fast path of finish_store
+                        pend_voff = ((uint32_t)(oy0 * uW + ox0 + lj) + (uint32_t)(lg >> 1) * 2u * HW32) * 16u + (uint32_t)(lg & 1) * 8u;
+                        pend_spkn = reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride + u_spk_off;
 #pragma unroll
                         for (int m = 0; m < NMT; ++m)
 #pragma unroll
@@ -722,7 +754,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 }
 
 static int g_ring_consumers = 8;
-extern "C" int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
+FLDR_HOOK int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
 
 template <int NMT, int TERMS, bool HAS_RES, int NC, int TW>
 static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
@@ -742,7 +774,7 @@ static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
 #define RING_NARROW_COST 0.65                  // measured: 9.5 vs 14.7 us per round of 256 units (96 -> 96)
 #endif
 static int g_ring_tile_width = 0;                // 0: automatic; 16 / 32: forced
-extern "C" int fldr_debug_ring_tile_width(int v) { if (v == 0 || v == 16 || v == 32) g_ring_tile_width = v; return g_ring_tile_width; }
+FLDR_HOOK int fldr_debug_ring_tile_width(int v) { if (v == 0 || v == 16 || v == 32) g_ring_tile_width = v; return g_ring_tile_width; }
 
 static int ring_pick_tile_width(const SpkArgs& a, int N, int wgs_per_xcd_max) {
     if (g_ring_tile_width) return g_ring_tile_width;
@@ -784,4 +816,30 @@ int fldr_spk_ring_dispatch(SpkArgs& a, int N, int nmt, int terms, int wgs_per_xc
     if (nmt == 1) return ring_launch<1, 3>(a, N, wgs_per_xcd_max, s);
     if (nmt == 2) return ring_launch<2, 3>(a, N, wgs_per_xcd_max, s);
     return ring_launch<3, 3>(a, N, wgs_per_xcd_max, s);
+}
+
+// Multi-level launch: 8 x 32 tiles, 8 consumer waves; the unit geometry of spk_fill_geometry with the units of all levels.
+template <int NMT, int TERMS, bool HAS_RES>
+static int ring_launch_levels(SpkArgs& a, int n_units, int wgs_per_xcd_max, hipStream_t s) {
+    using Cfg = RingCfg<NMT, 32>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, 8, 32, true>), Cfg::LDS_BYTES, attr_done)) return e;
+    a.tiles_x = 1; a.n_tiles = 1; a.m_tiles = 0; a.m_tiles_x = 0;           // (per level: a.lv)
+    a.n_units = n_units;
+    a.units_per_xcd = (a.n_units + 7) / 8;
+    a.units_per_xcd = (a.units_per_xcd + a.groups - 1) / a.groups * a.groups;
+    a.wgs_per_xcd = a.units_per_xcd < wgs_per_xcd_max ? a.units_per_xcd : wgs_per_xcd_max;
+    a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;
+    if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
+    if (((int64_t)a.n_units + 8 * a.units_per_xcd) * a.groups >= (1ll << 32)) return FLDR_E_SHAPE;
+    a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
+    hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, 8, 32, true>), dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+int fldr_spk_ring_dispatch_levels(SpkArgs& a, int n_units, int nmt, int terms, int wgs_per_xcd_max, hipStream_t s) {
+#define RING_LV(NMT_, T_) (a.residual ? ring_launch_levels<NMT_, T_, true>(a, n_units, wgs_per_xcd_max, s) : ring_launch_levels<NMT_, T_, false>(a, n_units, wgs_per_xcd_max, s))
+    if (terms == 1) return nmt == 1 ? RING_LV(1, 1) : (nmt == 2 ? RING_LV(2, 1) : RING_LV(3, 1));
+    return nmt == 1 ? RING_LV(1, 3) : (nmt == 2 ? RING_LV(2, 3) : RING_LV(3, 3));
+#undef RING_LV
 }

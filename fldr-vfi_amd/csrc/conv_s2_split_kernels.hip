@@ -717,9 +717,9 @@ static int s2_launch(S2Args& a, int N, hipStream_t s) {
 
 // Persistent kernel: 2 workgroups per CU (LDS: all weights + two input stages), XCD-contiguous tile ranges.
 static int g_s2_xshift = -1;                     // -1: automatic (15 on wide images); >= 0: forced (0 .. 31)
-extern "C" int fldr_debug_s2_xshift(int v) { if (v >= -1 && v < S2_TW) g_s2_xshift = v; return g_s2_xshift; }
+FLDR_HOOK int fldr_debug_s2_xshift(int v) { if (v >= -1 && v < S2_TW) g_s2_xshift = v; return g_s2_xshift; }
 static int g_s2_persistent = 1;
-extern "C" int fldr_debug_s2_persistent(int v) { if (v >= 0) g_s2_persistent = v; return g_s2_persistent; }
+FLDR_HOOK int fldr_debug_s2_persistent(int v) { if (v >= 0) g_s2_persistent = v; return g_s2_persistent; }
 
 template <int MT, int NMT, int PT, bool V4>
 static int s2_launch_pers2(S2Args& a, hipStream_t s, int lds_bytes) {
@@ -737,7 +737,7 @@ static int s2_launch_pers2(S2Args& a, hipStream_t s, int lds_bytes) {
 }
 
 static int g_s2_vec4 = 1;                        // 16-byte staging loads where the geometry allows (0: always the 4-byte path)
-extern "C" int fldr_debug_s2_vec4(int v) { if (v == 0 || v == 1) g_s2_vec4 = v; return g_s2_vec4; }
+FLDR_HOOK int fldr_debug_s2_vec4(int v) { if (v == 0 || v == 1) g_s2_vec4 = v; return g_s2_vec4; }
 
 template <int MT, int NMT, int PT>
 static int s2_launch_pers(S2Args& a, int N, hipStream_t s, int lds_bytes) {

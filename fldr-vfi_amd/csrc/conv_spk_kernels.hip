@@ -29,7 +29,7 @@
 // buffer no kernel reads.
 __device__ unsigned long long fldr_spk_stamp_buf[4 * 8];
 #define KSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-extern "C" int fldr_debug_read_spk_stamps(unsigned long long* host) {
+FLDR_HOOK int fldr_debug_read_spk_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_spk_stamp_buf), sizeof(unsigned long long) * 32);
 }
 #else
@@ -38,6 +38,7 @@ extern "C" int fldr_debug_read_spk_stamps(unsigned long long* host) {
 
 #include "spk_common.h"
 
+#ifdef FLDR_TEST_HOOKS        // the barrier pipeline: round 1's kernel, kept as the bit-exact cross-check of the ring pipeline (test build only)
 template <int NMT, int TERMS, bool HAS_RES>
 __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     using Cfg = SpkCfg<NMT>;
@@ -416,6 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_spk_kernel(SpkArgs a) {
     }
 #endif
 }
+#endif  // FLDR_TEST_HOOKS
 
 // ------------------------------------------------------------------------------------------------
 // fp32 NCHW <-> SPK
@@ -570,13 +572,14 @@ extern "C" int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout
 // Persistent workgroups per XCD (32 = one per CU); fldr_debug_spk_wgs_per_xcd changes it for occupancy experiments.
 static int g_spk_wgs_per_xcd = 32;
 static int g_spk_small_units = 96;                 // launches with at most this many units use 16-channel sub-groups (-1: never)
-extern "C" int fldr_debug_spk_small_units(int v) { if (v != 0) g_spk_small_units = v; return g_spk_small_units; }
-extern "C" int fldr_debug_spk_wgs_per_xcd(int v) { if (v > 0) g_spk_wgs_per_xcd = v; return g_spk_wgs_per_xcd; }
+FLDR_HOOK int fldr_debug_spk_small_units(int v) { if (v != 0) g_spk_small_units = v; return g_spk_small_units; }
+FLDR_HOOK int fldr_debug_spk_wgs_per_xcd(int v) { if (v > 0) g_spk_wgs_per_xcd = v; return g_spk_wgs_per_xcd; }
 // Pipeline variant: 1 (default) = loader / consumer ring without per-iteration barriers (conv_ring_kernels.hip),
 // 0 = the barrier pipeline of this file.  Same arithmetic, bit-identical results.
 static int g_spk_variant = 1;
-extern "C" int fldr_debug_spk_variant(int v) { if (v >= 0) g_spk_variant = v; return g_spk_variant; }
+FLDR_HOOK int fldr_debug_spk_variant(int v) { if (v >= 0) g_spk_variant = v; return g_spk_variant; }
 
+#ifdef FLDR_TEST_HOOKS
 template <int NMT, int TERMS, bool HAS_RES>
 static int spk_launch2(SpkArgs& a, int N, hipStream_t s) {
     using Cfg = SpkCfg<NMT>;
@@ -591,6 +594,7 @@ template <int NMT, int TERMS>
 static int spk_launch(SpkArgs& a, int N, hipStream_t s) {
     return a.residual ? spk_launch2<NMT, TERMS, true>(a, N, s) : spk_launch2<NMT, TERMS, false>(a, N, s);
 }
+#endif  // FLDR_TEST_HOOKS
 
 extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->wpack && (d->out_f32 || d->out_spk) && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
@@ -615,6 +619,7 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     }
     if (csum != d->cin) return FLDR_E_SHAPE;
     for (int g = gsum; g < SPK_MAX_GROUPS; ++g) { a.grp_ptr[g] = 0ull; a.grp_bstride[g] = 0; }
+    a.n_levels = 0;
     a.wpack = d->wpack; a.bias = d->bias; a.residual = d->residual;
     a.out_f32 = d->out_f32; a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
     a.out_spk_bstride = fldr_spk_bytes(d->cout_store, d->H, d->W);
@@ -633,6 +638,9 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     }
     hipStream_t s = fldr_s(stream);
     if (g_spk_variant == 1) return fldr_spk_ring_dispatch(a, d->N, nmt, d->precision == 1 ? 1 : 3, g_spk_wgs_per_xcd, s);
+#ifndef FLDR_TEST_HOOKS
+    return FLDR_E_ARG;                                               // (unreachable: the variant switch is a test-build hook)
+#else
     if (d->precision == 1) {
         if (nmt == 1) return spk_launch<1, 1>(a, d->N, s);
         if (nmt == 2) return spk_launch<2, 1>(a, d->N, s);
@@ -641,4 +649,53 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     if (nmt == 1) return spk_launch<1, 3>(a, d->N, s);
     if (nmt == 2) return spk_launch<2, 3>(a, d->N, s);
     return spk_launch<3, 3>(a, d->N, s);
+#endif
+}
+
+// The same convolution (same weights, bias, ReLU) over SEVERAL inputs of different sizes in ONE launch of the ring pipeline:
+// rec_ctx_ds.0 / .2 over the six pyramid levels (fLDRnet.py:148-162 runs them level by level: 12 launches, ten of them too
+// small to fill the chip).  descs[l]: one sample (N = 1), one packed source of cin channels, the same wpack / bias / relu /
+// cout / cout_store / precision in every entry; residual / out_f32 / out_spk given for all entries or for none.  Units are
+// numbered level after level (largest first is best: descs[0] should be the finest level) and dealt to the persistent
+// workgroups exactly like the units of a single launch; results are the bits of n_levels separate fldr_conv2d_spk calls.
+extern "C" int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_levels, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(descs && n_levels >= 1 && n_levels <= SPK_MAX_LEVELS);
+    if (n_levels == 1) return fldr_conv2d_spk(descs, stream);
+    if (g_spk_variant != 1) return FLDR_E_ARG;                       // ring pipeline only
+    const fldr_spk_conv_desc& d0 = descs[0];
+    FLDR_CHECK_ARG(d0.wpack && (d0.out_f32 || d0.out_spk) && d0.n_src == 1 && d0.src[0] && d0.N == 1);
+    FLDR_CHECK_ARG(d0.cin > 0 && d0.cin <= SPK_MAX_GROUPS * 8 && d0.cout > 0 && d0.cout <= 96 && d0.cout_store > 0 && d0.cout_store <= d0.cout);
+    FLDR_CHECK_ARG(!d0.residual || d0.out_f32);
+    SpkArgs a;
+    const int ng = (d0.cin + 7) / 8;
+    for (int g = 0; g < SPK_MAX_GROUPS; ++g) { a.grp_ptr[g] = g < ng ? (unsigned long long)reinterpret_cast<uintptr_t>(d0.src[0]) : 0ull; a.grp_bstride[g] = 0; }
+    a.wpack = d0.wpack; a.bias = d0.bias; a.residual = d0.residual;
+    a.out_f32 = d0.out_f32; a.out_spk = reinterpret_cast<unsigned char*>(d0.out_spk);
+    a.out_spk_bstride = 0;
+    a.n_chunks = (d0.cin + 15) / 16; a.cout = d0.cout; a.cout_store = d0.cout_store;
+    a.H = d0.H; a.W = d0.W; a.relu = d0.relu;
+    int nmt, groups;
+    spk_geometry(d0.cout, nmt, groups);
+    a.groups = groups; a.pack_nmt = nmt;
+    a.n_levels = n_levels;
+    int64_t units = 0;
+    for (int l = 0; l < n_levels; ++l) {
+        const fldr_spk_conv_desc& d = descs[l];
+        FLDR_CHECK_ARG(d.n_src == 1 && d.src[0] && d.N == 1 && d.H > 0 && d.W > 0 && !d.src_up2[0] && d.src_c[0] == d0.cin);
+        FLDR_CHECK_ARG(d.wpack == d0.wpack && d.bias == d0.bias && d.cin == d0.cin && d.cout == d0.cout && d.cout_store == d0.cout_store);
+        FLDR_CHECK_ARG(d.relu == d0.relu && d.precision == d0.precision);
+        FLDR_CHECK_ARG(!d.residual == !d0.residual && !d.out_f32 == !d0.out_f32 && !d.out_spk == !d0.out_spk);
+        if ((int64_t)d.cout_store * d.H * d.W * 4 >= (1ll << 32) || fldr_spk_bytes(96, d.H, d.W) >= (1ll << 32)) return FLDR_E_SHAPE;
+        SpkArgs::SpkLevel& v = a.lv[l];
+        v.H = d.H; v.W = d.W; v.tiles_x = fldr_cdiv(d.W, SPK_TW); v.n_tiles = v.tiles_x * fldr_cdiv(d.H, SPK_TH);
+        v.unit0 = (int32_t)units; v.pad = 0; v.m_tiles_x = 0; v.pad2 = 0;
+        v.in_off = reinterpret_cast<const char*>(d.src[0]) - reinterpret_cast<const char*>(d0.src[0]);
+        v.out_spk_off = d.out_spk ? reinterpret_cast<const char*>(d.out_spk) - reinterpret_cast<const char*>(d0.out_spk) : 0;
+        v.out_f32_off = d.out_f32 ? reinterpret_cast<const char*>(d.out_f32) - reinterpret_cast<const char*>(d0.out_f32) : 0;
+        v.res_off = d.residual ? reinterpret_cast<const char*>(d.residual) - reinterpret_cast<const char*>(d0.residual) : 0;
+        units += (int64_t)v.n_tiles * groups;
+    }
+    for (int l = n_levels; l < SPK_MAX_LEVELS; ++l) { a.lv[l] = a.lv[n_levels - 1]; a.lv[l].unit0 = 0x7fffffff; }
+    if (units >= (1 << 28)) return FLDR_E_SHAPE;
+    return fldr_spk_ring_dispatch_levels(a, (int)units, nmt, (d0.precision & 1) ? 1 : 3, g_spk_wgs_per_xcd, fldr_s(stream));
 }

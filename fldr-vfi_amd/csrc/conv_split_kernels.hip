@@ -30,7 +30,7 @@
 #endif
 __device__ unsigned long long fldr_split_stamp_buf[8 * 8];
 #define SSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-extern "C" int fldr_debug_read_split_stamps(unsigned long long* host) {
+FLDR_HOOK int fldr_debug_read_split_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_split_stamp_buf), sizeof(unsigned long long) * 64);
 }
 #else

@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
 }
 
 static int g_d3_xshift = -1;                     // -1: automatic (16 on wide frames); 0 .. 31: forced
-extern "C" int fldr_debug_dec3_xshift(int v) { if (v >= -1 && v < D3_TW) g_d3_xshift = v; return g_d3_xshift; }
+FLDR_HOOK int fldr_debug_dec3_xshift(int v) { if (v >= -1 && v < D3_TW) g_d3_xshift = v; return g_d3_xshift; }
 
 extern "C" int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream) {
     FLDR_CHECK_ARG(weight && weff);

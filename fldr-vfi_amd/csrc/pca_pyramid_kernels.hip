@@ -535,7 +535,7 @@ __global__ __launch_bounds__(256, 2) void pcam_kernel(PcapArgs a, const double* 
 }
 
 static int g_pcap_variant = 0;                    // 1: fp64 matrix cores (K = 16), 0 (default): scalar-fed vector kernel
-extern "C" int fldr_debug_pca_variant(int v) { if (v == 0 || v == 1) g_pcap_variant = v; return g_pcap_variant; }
+FLDR_HOOK int fldr_debug_pca_variant(int v) { if (v == 0 || v == 1) g_pcap_variant = v; return g_pcap_variant; }
 
 extern "C" int64_t fldr_pca_table_size(int K) {
     if (K != 4 && K != 8 && K != 16) return FLDR_E_ARG;
@@ -556,7 +556,7 @@ extern "C" int fldr_pca_prepack(const double* ev, const double* mean, const doub
 }
 
 static int g_pcap_wgs = 512;                      // persistent workgroups (2 per CU: ~190 VGPRs per thread with both pixel buffers)
-extern "C" int fldr_debug_pca_workgroups(int v) { if (v > 0) g_pcap_wgs = v; return g_pcap_wgs; }
+FLDR_HOOK int fldr_debug_pca_workgroups(int v) { if (v > 0) g_pcap_wgs = v; return g_pcap_wgs; }
 
 template <int K>
 static void pcap_launch(const PcapArgs& a, int total_items, hipStream_t s) {

@@ -11,6 +11,7 @@ typedef __attribute__((address_space(1))) const void* kgptr_t;
 typedef __attribute__((address_space(3))) void* klptr_t;
 
 #define SPK_MAX_GROUPS 14                       // 112 input channels
+#define SPK_MAX_LEVELS 8                        // pyramid levels of a multi-level launch
 #define SPK_TH 8
 #define SPK_TW 32
 #define SPK_IH (SPK_TH + 2)
@@ -36,6 +37,16 @@ struct SpkArgs {
     int32_t pack_nmt;                             // 16-channel blocks per weight-pack group (>= NMT, a multiple of it: small
                                                   // launches run the NMT=1 kernel on sub-groups of an NMT=3 pack)
     int32_t n_units, units_per_xcd, wgs_per_xcd;
+    // Multi-level launch (ring kernel only; n_levels > 1): ONE sample and ONE source tensor per level, the same weights for all
+    // (rec_ctx_ds over the six pyramid levels, fLDRnet.py:148-162).  Units [lv[l].unit0, lv[l+1].unit0) belong to level l; its
+    // tensors lie at byte offsets from level 0's (grp_ptr[0] / out_spk / out_f32 / residual).  H, W, tiles_x, n_tiles, m_tiles,
+    // m_tiles_x above are unused then.
+    int32_t n_levels;
+    struct SpkLevel {
+        int32_t H, W, tiles_x, n_tiles, unit0, pad;
+        uint32_t m_tiles_x, pad2;
+        int64_t in_off, out_spk_off, out_f32_off, res_off;
+    } lv[SPK_MAX_LEVELS];
     uint32_t m_groups, m_tiles, m_tiles_x;        // floor(2^32 / d) + 1: u / d == umulhi(u, m) for u * d < 2^32 (d > 1)
 };
 
@@ -128,3 +139,5 @@ static inline int spk_fill_geometry(SpkArgs& a, int N, int wgs_per_xcd_max, int 
 
 // conv_ring_kernels.hip: the loader / consumer ring pipeline (nmt in {1,2,3}, terms in {1,3})
 int fldr_spk_ring_dispatch(SpkArgs& a, int N, int nmt, int terms, int wgs_per_xcd_max, hipStream_t s);
+// ... for a multi-level launch (a.n_levels > 1, a.lv filled, n_units = the sum over the levels)
+int fldr_spk_ring_dispatch_levels(SpkArgs& a, int n_units, int nmt, int terms, int wgs_per_xcd_max, hipStream_t s);

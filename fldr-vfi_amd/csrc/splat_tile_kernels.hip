@@ -176,6 +176,7 @@ __global__ __launch_bounds__(64 * ST_UP_WAVES) void splat_bounds_up_kernel(const
     }
 }
 
+#ifdef FLDR_TEST_HOOKS        // the LDS-f32-atomic tile kernel (ds_add_f32: 80 ns per wave-instruction): measured and retired, test build only
 // mode: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ 1 normalisation accumulator
 // when MODE >= 1); channel group = blockIdx.z % groups.
 template <int MODE, int CB, int TW, int TH>
@@ -324,6 +325,8 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
     }
 }
 
+#endif  // FLDR_TEST_HOOKS
+
 // ------------------------------------------------------------------------------------------------
 // Band splat: destination-owned, NO atomics at all.
 //
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
 #ifdef ST_STAMPS
 __device__ unsigned long long st_stamp_buf[16];
 #define TSTAMP(var) unsigned long long var; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
-extern "C" int fldr_debug_read_st_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(st_stamp_buf), sizeof(unsigned long long) * 16); }
+FLDR_HOOK int fldr_debug_read_st_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(st_stamp_buf), sizeof(unsigned long long) * 16); }
 #else
 #define TSTAMP(var)
 #endif
@@ -769,6 +772,7 @@ extern "C" int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W) {
     return (int64_t)N * nsb * (ST_SB_BLOCKS + 1) * 4;
 }
 
+#ifdef FLDR_TEST_HOOKS
 template <int MODE>
 static void splat_tile_launch(const float* img, int64_t ibs, int64_t ics, const float* flow, const float* metric, const float* blk, const float* sbt,
                               float* out, int N, int C, int H, int W, int nsb_x, int nsb, hipStream_t s) {
@@ -781,10 +785,11 @@ static void splat_tile_launch(const float* img, int64_t ibs, int64_t ics, const 
         hipLaunchKernelGGL((splat_tile_kernel<MODE, 12, 64, 16>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
     }
 }
+#endif  // FLDR_TEST_HOOKS
 
 // FunctionSoftsplat (softSplat.py:320-352) end to end, destination-owned.  ws: fldr_softsplat_tile_ws_floats floats.
 static int g_splat_tile_variant = 1;     // 0: LDS-atomic tiles, 1: claim-and-add bands
-extern "C" int fldr_debug_splat_tile_variant(int v) { if (v == 0 || v == 1) g_splat_tile_variant = v; return g_splat_tile_variant; }
+FLDR_HOOK int fldr_debug_splat_tile_variant(int v) { if (v == 0 || v == 1) g_splat_tile_variant = v; return g_splat_tile_variant; }
 
 extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
                                            const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
@@ -818,6 +823,7 @@ static int splat_tile_run(const float* img, int64_t img_bstride, int64_t img_cst
         }
         FLDR_LAUNCH_RET();
     }
+#ifdef FLDR_TEST_HOOKS
     switch (mode) {
         case 0: splat_tile_launch<0>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
         case 1: splat_tile_launch<1>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
@@ -825,6 +831,9 @@ static int splat_tile_run(const float* img, int64_t img_bstride, int64_t img_cst
         default: splat_tile_launch<3>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
     }
     FLDR_LAUNCH_RET();
+#else
+    return FLDR_E_ARG;                                               // (unreachable: the variant switch is a test-build hook)
+#endif
 }
 
 extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,

@@ -145,12 +145,20 @@ class DCTXVFInet(nn.Module):
                                         self.params, a, self.pca_means[i8], self.EVs[i8], self.mean_vecs[i8], want_spk=spk)
             pcas, pcas_p = r if spk else (r, [None] * n_levels)
             feats = []
+            pv, pp = [], []
             for i in range(n_levels):
                 h, w = x_l[i].shape[3], x_l[i].shape[4]
-                pca = pcas[i].view(B, nch, h // 8, w // 8)
+                pv.append(pcas[i].view(B, nch, h // 8, w // 8))
                 # [1, 96B, h, w] packed == [B, 96, h, w] packed (12 whole groups per sample)
-                pca_p = fldr_hip.Spk(pcas_p[i].buf, (B, nch, h // 8, w // 8)) if spk else None
-                feats.append(self._extract_features(pca, pca_p) if a.ref_feat_extrac else (pca, pca_p))
+                pp.append(fldr_hip.Spk(pcas_p[i].buf, (B, nch, h // 8, w // 8)) if spk else None)
+            if a.ref_feat_extrac and spk and B == 1 and fldr_hip.LEVEL_BATCH and fldr_hip.spk_variant() == 1:
+                # rec_ctx_ds(x) + x of ALL levels in two launches (the weights are shared, the levels independent: fLDRnet.py:148-162)
+                c0, c2 = self.rec_ctx_ds[0], self.rec_ctx_ds[2]
+                ys = fldr_hip.conv2d_spk_levels(pp, c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
+                feats = fldr_hip.conv2d_spk_levels(ys, c2.weight, c2.bias, relu=True, residuals=pv, want_f32=True, want_spk=True)
+            else:
+                for i in range(n_levels):
+                    feats.append(self._extract_features(pv[i], pp[i]) if a.ref_feat_extrac else (pv[i], pp[i]))
             flow = None
             for level in range(a.S_tst, -1, -1):                                                       # :210-218
                 flow = self.vfinet.estimate_flow(feats[level], flow)

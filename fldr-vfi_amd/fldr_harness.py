@@ -220,10 +220,11 @@ def synthetic_pair(H, W, seed=0, quadrant=False, device="cpu"):
     return torch.stack([u8(I0[0]), u8(I1[0])], 0).to(device)
 
 
-def synthetic_pair_varying(H, W, seed=0, device="cpu"):
+def synthetic_pair_varying(H, W, seed=0, device="cpu", zoom=1.012, rot_deg=0.25, shift=(5.0, 3.0)):
     """The same texture under a smoothly VARYING motion: I1 is I0 seen through a 1.2 % zoom about the frame centre plus a
-    0.25 degree rotation and a (5, 3) px shift — displacements of up to ~30 px at the corners of a 4K frame whose x and y
-    components change from pixel to pixel, as camera motion in natural video does.  (A global shift, synthetic_pair's
+    0.25 degree rotation and a (5, 3) px shift (defaults) — displacements of up to ~30 px at the corners of a 4K frame whose x
+    and y components change from pixel to pixel, as camera motion in natural video does; larger zoom / rot_deg for stronger
+    non-rigid motion (2.5 % / 0.8 degrees: ~85 px at the corners, sources of one row spread over a dozen target rows).  (A global shift, synthetic_pair's
     default, is the easiest case for the scatter kernels: every row of sources lands on one row of targets.)"""
     import math
     g = torch.Generator().manual_seed(seed)
@@ -238,10 +239,10 @@ def synthetic_pair_varying(H, W, seed=0, device="cpu"):
     base = (base - base.amin()) / (base.amax() - base.amin())
     I0 = base[..., 64:H + 64, 64:W + 64]
     ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32), torch.arange(W, dtype=torch.float32), indexing="ij")
-    cy, cx, z, a = (H - 1) / 2, (W - 1) / 2, 1.012, math.radians(0.25)
+    cy, cx, z, a = (H - 1) / 2, (W - 1) / 2, zoom, math.radians(rot_deg)
     dx, dy = xs - cx, ys - cy
-    sx = cx + z * (math.cos(a) * dx - math.sin(a) * dy) + 5.0 + 64
-    sy = cy + z * (math.sin(a) * dx + math.cos(a) * dy) + 3.0 + 64
+    sx = cx + z * (math.cos(a) * dx - math.sin(a) * dy) + shift[0] + 64
+    sy = cy + z * (math.sin(a) * dx + math.cos(a) * dy) + shift[1] + 64
     grid = torch.stack([sx / (Wb - 1) * 2 - 1, sy / (Hb - 1) * 2 - 1], -1).unsqueeze(0)
     I1 = F.grid_sample(base, grid, mode="bilinear", padding_mode="border", align_corners=True)
     u8 = lambda t: (t.clamp(0, 1) * 255).round().to(torch.uint8)

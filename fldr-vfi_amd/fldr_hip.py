@@ -112,6 +112,8 @@ _SIGNATURES = {
     "fldr_splat_bounds_upsampled": (ctypes.c_int, [_c_float_p, ctypes.c_int64, _c_float_p, ctypes.c_int, ctypes.c_float, _c_float_p]
                                     + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_debug_corr_variant": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_corr_chunk": (ctypes.c_int, [ctypes.c_int]),
     "fldr_softsplat_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -146,6 +148,7 @@ _SIGNATURES = {
     "fldr_conv_spk_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
     "fldr_conv_spk_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_spk": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_void_p]),
+    "fldr_conv2d_spk_levels": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_int, ctypes.c_void_p]),
     "fldr_debug_spk_wgs_per_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_range_status": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_small_units": (ctypes.c_int, [ctypes.c_int]),
@@ -169,30 +172,78 @@ _SIGNATURES = {
                            + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
 }
 
-EXPORTS = tuple(_SIGNATURES)
+# The integration ABI (include/fldr_hip.h: what libfldr_hip.so exports) and the tuning / cross-check hooks that only the test
+# build libfldr_hip_test.so has (include/fldr_hip_test_hooks.h).
+EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_"))
+HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_"))
+TEST_LIB_PATH = os.path.join(_HERE, "libfldr_hip_test.so")
 _lib = None
+_hooks_lib = None
+
+
+def _load(path, want_hooks):
+    if not os.path.exists(path):
+        raise ImportError("%s is missing — build it with `make -C fldr-vfi_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
+                          "g.build()'`). There is no CPU/eager fallback." % path)
+    l = ctypes.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError:
+            # hooks exist in the test build only; an experimental / older build selected with FLDR_LIB may lack newer entry points
+            if (name in HOOKS and not want_hooks) or os.environ.get("FLDR_LIB"):
+                continue
+            raise
+        fn.restype = res
+        fn.argtypes = args
+    return l
 
 
 def lib():
-    """The loaded library; raises (never falls back) when it has not been built."""
+    """The loaded PRODUCT library; raises (never falls back) when it has not been built.  Inside `with test_hooks():` the test
+    build (the same kernels + the fldr_debug_* hooks and the retired cross-check kernels)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("libfldr_hip.so is missing at %s — build it with `make -C fldr-vfi_amd/csrc` "
-                              "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU/eager fallback."
-                              % LIB_PATH)
-        l = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype = res
-            fn.argtypes = args
-        for env, hook in (("FLDR_RING_CONSUMERS", "fldr_debug_ring_consumers"), ("FLDR_SPK_VARIANT", "fldr_debug_spk_variant"),
-                          ("FLDR_PCA_WORKGROUPS", "fldr_debug_pca_workgroups"), ("FLDR_PCA_VARIANT", "fldr_debug_pca_variant"),
-                          ("FLDR_RING_TILE_WIDTH", "fldr_debug_ring_tile_width"), ("FLDR_S2_VEC4", "fldr_debug_s2_vec4")):   # tuning hooks from the environment (A/B runs)
-            if os.environ.get(env):
-                getattr(l, hook)(int(os.environ[env]))
-        _lib = l
+        _lib = _load(LIB_PATH, want_hooks=False)
     return _lib
+
+
+class test_hooks:
+    """Context manager for tests / tools: route every call of this module to libfldr_hip_test.so, whose fldr_debug_* hooks select
+    kernel variants and tuning values.  Environment hooks (FLDR_RING_CONSUMERS, FLDR_SPK_VARIANT, FLDR_PCA_WORKGROUPS,
+    FLDR_PCA_VARIANT, FLDR_RING_TILE_WIDTH, FLDR_S2_VEC4) are applied when the test build is entered."""
+
+    def __enter__(self):
+        global _lib, _hooks_lib
+        if _hooks_lib is None:
+            _hooks_lib = _load(os.environ.get("FLDR_LIB") or TEST_LIB_PATH, want_hooks=True)
+            for env, hook in (("FLDR_RING_CONSUMERS", "fldr_debug_ring_consumers"), ("FLDR_SPK_VARIANT", "fldr_debug_spk_variant"),
+                              ("FLDR_PCA_WORKGROUPS", "fldr_debug_pca_workgroups"), ("FLDR_PCA_VARIANT", "fldr_debug_pca_variant"),
+                              ("FLDR_RING_TILE_WIDTH", "fldr_debug_ring_tile_width"), ("FLDR_S2_VEC4", "fldr_debug_s2_vec4")):
+                if os.environ.get(env) and hasattr(_hooks_lib, hook):
+                    getattr(_hooks_lib, hook)(int(os.environ[env]))
+        self._prev = _lib
+        _lib = _hooks_lib
+        return _hooks_lib
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
+
+
+def enter_test_hooks():
+    """tools/: switch this process to the test build for good (idempotent)."""
+    if _lib is None or _lib is not _hooks_lib:
+        test_hooks().__enter__()
+    return _lib
+
+
+def spk_variant():
+    """Pipeline of fldr_conv2d_spk: 1 = loader / consumer ring (the only one in the product library), 0 = barrier pipeline
+    (selectable in the test build)."""
+    fn = getattr(lib(), "fldr_debug_spk_variant", None)
+    return 1 if fn is None else fn(-1)
 
 
 class FldrError(RuntimeError):
@@ -303,6 +354,8 @@ SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (defau
 # right behind their producer; measured 408 vs 419 pairs/s: the second launch's repeated flow evaluation costs more than the
 # Infinity-Cache hits give)
 PREP_SPLIT = os.environ.get("FLDR_PREP_SPLIT", "0") == "1"
+# rec_ctx_ds of all pyramid levels in two launches (fldr_conv2d_spk_levels) instead of two per level (FLDR_LEVEL_BATCH=0)
+LEVEL_BATCH = os.environ.get("FLDR_LEVEL_BATCH", "1") != "0"
 
 
 # Bounds table of the level-0 image splats: "lowres" (default) = from the low-resolution flow the upsampled flow_t is made of
@@ -1005,6 +1058,40 @@ def conv2d_spk(srcs, weight, bias, relu=False, residual=None, cout_store=None, u
     if want_f32 and want_spk:
         return out32, outp
     return outp if want_spk else out32
+
+
+def conv2d_spk_levels(srcs, weight, bias, relu=False, residuals=None, want_f32=True, want_spk=False, precision=None):
+    """The same 3x3 convolution over a LIST of one-sample packed tensors of different sizes (the pyramid levels) in ONE launch
+    (fldr_conv2d_spk_levels).  -> list of fp32 tensors, of Spk tensors, or of (fp32, Spk): the bits of per-level conv2d_spk calls."""
+    cout, cin, k, _ = weight.shape
+    assert k == 3 and 1 <= len(srcs) <= 8
+    packed = [spk_pack(x) for x in srcs]
+    descs = (SpkConvDesc * len(packed))()
+    wp = conv_spk_prepack(weight)
+    prec = precision or CONV_PRECISION
+    outs, keep = [], []
+    for l, sp in enumerate(packed):
+        n, c, h, w = sp.shape
+        assert n == 1 and c == cin
+        d = descs[l]
+        d.src[0], d.src_bstride[0], d.src_c[0], d.src_up2[0], d.n_src = sp.ptr, 0, c, 0, 1
+        d.wpack = wp.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        res = residuals[l] if residuals is not None else None
+        o32 = torch.empty(1, cout, h, w, device=sp.device, dtype=torch.float32) if (want_f32 or res is not None) else None
+        osp = _spk_alloc(1, cout, h, w, sp.device) if want_spk else None
+        if res is not None:
+            res = res.contiguous()
+            assert res.shape == o32.shape
+            keep.append(res)
+            d.residual = res.data_ptr()
+        d.out_f32 = o32.data_ptr() if o32 is not None else None
+        d.out_spk = osp.buf.data_ptr() if osp is not None else None
+        d.N, d.cin, d.cout, d.cout_store, d.H, d.W = 1, cin, cout, cout, h, w
+        d.relu, d.precision = int(bool(relu)), (1 if prec == "fp16" else 0)
+        outs.append((o32, osp) if (want_f32 and want_spk) else (osp if want_spk else o32))
+    _check(lib().fldr_conv2d_spk_levels(descs, len(packed), _stream()), "fldr_conv2d_spk_levels")
+    return outs
 
 
 def synth_tail(refine, cands, t, T_param, out_dtype=torch.float64):

@@ -198,7 +198,7 @@ int fldr_pca_project_stream(const float* planes, const double* ev, const double*
  * fldr_pca_prepack (fldr_pca_table_size(K) doubles: coefficients pixel-major, mean, meanvec and its reciprocals);
  * minmax_ws: 32 * n_levels doubles (every bound on a 128-byte line of its own: the reduction is hardware fp64 atomics at the
  * L2), on completion min of level l at [32 l], max at [32 l + 16].  n_levels <= 8; K in {4, 8, 16}.  K = 16 can run on the
- * fp64 matrix cores instead (fldr_debug_pca_variant(1)): same arithmetic, pixels summed in another order — equal to the
+ * fp64 matrix cores instead (the test build's pca-variant hook, include/fldr_hip_test_hooks.h): same arithmetic, pixels summed in another order — equal to the
  * per-level kernels to fp64 rounding, not bit for bit; measured no faster, so not the default. */
 typedef struct fldr_pca_level {
     const float* planes;       /* [P, H, W] fp32, 16-byte aligned; H, W multiples of 8 */
@@ -210,8 +210,6 @@ int64_t fldr_pca_table_size(int K);
 int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K, fldr_stream_t stream);
 int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K, double* minmax_ws,
                              fldr_stream_t stream);
-int fldr_debug_pca_variant(int v);                                /* K = 16: 0 (default) the scalar-fed vector kernel (bit-identical to the per-level kernels), 1 fp64 matrix cores; other: query */
-int fldr_debug_pca_workgroups(int v);                             /* tuning hook: persistent workgroups of the two pyramid passes (default 512); 0: query */
 
 /* ------------------------------------------------------------------------------------------
  * Gathers and resizes — replace DCTVFInet.bwarp and the F.interpolate calls of fLDRnet.py.
@@ -321,10 +319,6 @@ int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 int64_t fldr_conv_s2_prepack_size(int cout, int cin);
 int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
-int fldr_debug_s2_persistent(int v);                                /* tuning hook: 1 (default) persistent-workgroup kernel where the weights fit, 0 per-tile kernel; < 0 query */
-int fldr_debug_s2_xshift(int v);                                  /* tuning hook: left shift (output columns) of the persistent stride-2 kernel's tile grid; -1 (default): 15 on wide images */
-int fldr_debug_s2_vec4(int v);                                   /* tuning hook: 1 (default) 16-byte staging loads in the persistent stride-2 encoder where the geometry allows, 0 never; other: query.  Bit-identical results */
-int fldr_debug_dec3_xshift(int v);                                /* tuning hook: left shift (low-resolution columns) of fldr_dec3_synth's tile grid; -1 (default): 16 on wide frames */
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.
  * A logical [N,C,H,W] fp32 tensor is stored as [N][G=ceil(C/8)][hi,lo][H*W][8 x fp16] (x = hi + lo, 22 significant
@@ -355,18 +349,17 @@ int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fld
 int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
 int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
+/* The same convolution (shared wpack / bias / relu / channel counts / precision) over n_levels (<= 8) inputs of different sizes in ONE
+ * launch of the ring pipeline — rec_ctx_ds over the pyramid levels (fLDRnet.py:148-162 runs it level by level).  Every entry:
+ * N = 1, one packed source; residual / out_f32 / out_spk for all entries or none.  Results are the bits of n_levels separate
+ * fldr_conv2d_spk calls. */
+int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_levels, fldr_stream_t stream);
 int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc — binding self-check */
 /* Range status of the fp16 hi/lo splits behind the split-precision convolutions (fp32-equivalent for |x| <= 65504; up to
  * 131008 the excess is kept to fp16 precision; beyond that, and for NaN inputs, values SATURATE to a finite number —
  * never inf / NaN out of finite inputs): 1 if that happened on
  * the current device since the last reset, 0 if not, negative on a HIP error.  Synchronises the device. */
 int fldr_range_status(int reset);
-int fldr_debug_spk_small_units(int v);                              /* tuning hook: launches of <= v units run as 16-channel sub-groups (default 96; -1: never; 0: query) */
-int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
-int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */
-int fldr_debug_ring_consumers(int v);                              /* tuning hook of the ring pipeline: 8 (default; two consumer waves per SIMD) or 4 consumer waves; other: query */
-int fldr_debug_ring_tile_width(int v);                             /* tuning hook of the ring pipeline: 0 (default) automatic per launch, 16 / 32 forced; other: query.  Bit-identical results */
-int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */
 
 /* ------------------------------------------------------------------------------------------
  * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.

@@ -1,0 +1,38 @@
+/* Tuning and cross-check hooks of libfldr_hip_test.so (the build with -DFLDR_TEST_HOOKS; `make -C fldr-vfi_amd/csrc hooks`).
+ * NOT part of the integration ABI: the product library libfldr_hip.so exports none of these, and the retired kernel generations
+ * some of them select (the barrier-pipeline 3x3 convolution, the LDS-f32-atomic tile splat) are not even compiled into it.
+ * Used by tests/ and tools/ through fldr_hip.test_hooks(). */
+#ifndef FLDR_HIP_TEST_HOOKS_H
+#define FLDR_HIP_TEST_HOOKS_H
+#include "fldr_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int fldr_debug_pca_variant(int v);                                /* K = 16: 0 (default) the scalar-fed vector kernel (bit-identical to the per-level kernels), 1 fp64 matrix cores; other: query */
+int fldr_debug_pca_workgroups(int v);                             /* tuning hook: persistent workgroups of the two pyramid passes (default 512); 0: query */
+int fldr_debug_s2_persistent(int v);                                /* tuning hook: 1 (default) persistent-workgroup kernel where the weights fit, 0 per-tile kernel; < 0 query */
+int fldr_debug_s2_xshift(int v);                                  /* tuning hook: left shift (output columns) of the persistent stride-2 kernel's tile grid; -1 (default): 15 on wide images */
+int fldr_debug_s2_vec4(int v);                                   /* tuning hook: 1 (default) 16-byte staging loads in the persistent stride-2 encoder where the geometry allows, 0 never; other: query.  Bit-identical results */
+int fldr_debug_dec3_xshift(int v);                                /* tuning hook: left shift (low-resolution columns) of fldr_dec3_synth's tile grid; -1 (default): 16 on wide frames */
+int fldr_debug_spk_small_units(int v);                              /* tuning hook: launches of <= v units run as 16-channel sub-groups (default 96; -1: never; 0: query) */
+int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
+int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */
+int fldr_debug_ring_consumers(int v);                              /* tuning hook of the ring pipeline: 8 (default; two consumer waves per SIMD) or 4 consumer waves; other: query */
+int fldr_debug_corr_variant(int v);                                /* cost volume staging: 1 (default) LDS-DMA double buffer where W % 4 == 0, 0 synchronous; other: query.  Bit-identical results */
+int fldr_debug_corr_chunk(int v);                                  /* channels per staged chunk of the LDS-DMA cost-volume kernel: 8 (default) or 16; other: query */
+int fldr_debug_ring_tile_width(int v);                             /* tuning hook of the ring pipeline: 0 (default) automatic per launch, 16 / 32 forced; other: query.  Bit-identical results */
+int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */
+int fldr_debug_splat_tile_variant(int v);                          /* fldr_softsplat_tile: 1 (default) claim-and-add bands, 0 the LDS-f32-atomic tiles; other: query */
+int fldr_debug_pca_variant(int v);                                 /* fldr_pca_project_pyramid: 0 (default) vector fp64 kernel, 1 fp64 matrix-core kernel; other: query */
+int fldr_debug_pca_workgroups(int v);                              /* persistent workgroups of the pyramid PCA (0: query) */
+int fldr_debug_s2_persistent(int v);                               /* stride-2 encoders: 1 (default) persistent kernel, 0 per-tile kernel */
+int fldr_debug_s2_xshift(int v);                                   /* tile-grid shift of the persistent stride-2 kernel (output columns; -1: default) */
+int fldr_debug_s2_vec4(int v);                                     /* 16-byte staging loads of the persistent stride-2 kernel: 1 (default) / 0 */
+int fldr_debug_dec3_xshift(int v);                                 /* tile-grid shift of dec3_synth (low-resolution columns; -1: default) */
+int fldr_debug_conv_occupancy(int* out4);                          /* occupancy query of the fp32-MFMA convolution kernels */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

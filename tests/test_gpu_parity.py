@@ -46,6 +46,14 @@ def model(dev):
     return m, a
 
 
+@pytest.fixture
+def hooks(hip):
+    """Tests that switch kernel variants / tuning values run on the TEST build (libfldr_hip_test.so: the product kernels + the
+    fldr_debug_* hooks and the retired cross-check kernels); everything else runs on the product library."""
+    with hip.test_hooks() as L:
+        yield L
+
+
 def _gen(seed):
     return torch.Generator().manual_seed(seed)
 
@@ -188,7 +196,7 @@ def test_pca_stream_equals_two_pass(hip, dev, model):
 
 
 @pytest.mark.parametrize("K", [16, 8, 4])
-def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K):
+def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K, hooks):
     """fldr_pca_project_pyramid, vector kernel (all levels in two launches, pixel-major table, Markstein quotients, no fp64
     intermediate) against the per-level one-pass kernels of fldr_pca_project_stream: fp32 output, split-packed twin and
     min / max are the same bits at every level, including levels of a few blocks and an odd number of planes."""
@@ -209,7 +217,7 @@ def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K):
     assert all(torch.equal(a.buf, b.buf) for a, b in zip(only_spk, osp))
 
 
-def test_pca_pyramid_matrix_core_kernel(hip, oracle, dev, model):
+def test_pca_pyramid_matrix_core_kernel(hip, oracle, dev, model, hooks):
     """The opt-in K = 16 pyramid kernel on the fp64 matrix cores (v_mfma_f64_16x16x4_f64; pixels summed in the matrix instruction's order) against the
     per-level vector kernels and the oracle: min / max to 1e-13 relative, the fp32 casts equal except where an fp64 rounding
     difference crosses an fp32 rounding boundary (<= 1 ulp of 1.0, < 0.1 % of the elements), the packed twin = the pack of
@@ -244,7 +252,7 @@ def test_pca_pyramid_matrix_core_kernel(hip, oracle, dev, model):
                                    (1, [64, 32], [1, 0], 32, None, 24, 40, True, False), (1, [32, 16], [1, 0], 16, None, 48, 80, True, False),
                                    (1, [96], [0], 96, None, 72, 120, True, True), (1, [96], [0], 96, None, 136, 240, True, False),
                                    (2, [96], [0], 48, None, 136, 240, True, False), (1, [48, 48, 4], [0, 0, 0], 96, None, 136, 250, True, True)])
-def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape):
+def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape, hooks):
     """The persistent split-packed convolution (fldr_conv2d_spk) against the register-staged split convolution
     (fldr_conv2d_split): same hi/lo split, same MFMA order => bit-identical fp32 output; its packed output equals
     fldr_spk_pack of that output; a chain through the packed tensor equals the chain through fp32."""
@@ -281,6 +289,29 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape):
             assert torch.equal(hip.conv2d([ref[:, half:]], w3, None, precision="split"), hip.conv2d_spk([gp.narrow(half, half)], w3, None))
 
 
+@pytest.mark.parametrize("case", [(96, 96, True, True), (96, 96, True, False), (48, 16, False, False), (64, 40, True, True)])
+def test_multi_level_conv_launch(hip, dev, case):
+    """fldr_conv2d_spk_levels (rec_ctx_ds over the pyramid levels in one launch, fLDRnet.py:148-162): the bits of the per-level
+    launches — fp32 and packed outputs, with and without the residual — for level sizes from one partial tile to several rounds
+    of workgroups, not multiples of the 8 x 32 tile."""
+    cin, cout, relu, res = case
+    g = _gen(77)
+    sizes = [(72, 120), (36, 60), (18, 30), (9, 15), (5, 33), (1, 1)]
+    xs = [torch.randn(1, cin, h, w, generator=g).to(dev) for h, w in sizes]
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 20).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    rs = [torch.randn(1, cout, h, w, generator=g).to(dev) for h, w in sizes] if res else None
+    got = hip.conv2d_spk_levels(xs, wt, b, relu=relu, residuals=rs, want_f32=True, want_spk=True)
+    for l, x in enumerate(xs):
+        r32, rsp = hip.conv2d_spk([x], wt, b, relu=relu, residual=rs[l] if res else None, want_f32=True, want_spk=True)
+        assert torch.equal(got[l][0], r32), (l, sizes[l])
+        assert torch.equal(got[l][1].buf, rsp.buf), (l, sizes[l])
+    only = hip.conv2d_spk_levels([o[1] for o in got], wt[:, :cout] if cout <= cin else (torch.randn(cout, cout, 3, 3, generator=g) / 20).to(dev), None,
+                                 want_f32=False, want_spk=True) if cout % 8 == 0 else None      # chained through the packed outputs
+    if only is not None:
+        assert all(o.shape == (1, cout, h, w) for o, (h, w) in zip(only, sizes))
+
+
 @pytest.mark.parametrize("shape", [([3, 3, 2, 5], 16, 40, 72, 1), ([16], 32, 34, 70, 2), ([32], 64, 48, 64, 1), ([26], 16, 50, 38, 1)])
 def test_stride2_split_conv_is_fp32_equivalent(hip, dev, shape):
     """The 3 x fp16-split stride-2 4x4 convolution (UNet encoders) against an fp64 reference: error at the level of the exact
@@ -303,7 +334,7 @@ def test_stride2_split_conv_is_fp32_equivalent(hip, dev, shape):
 
 @pytest.mark.parametrize("shape", [([3, 3, 2, 5], 16, 40, 72, 1), ([16], 32, 34, 70, 2), ([26], 16, 50, 38, 3), ([5], 16, 18, 66, 1),
                                    ([4], 1, 34, 64, 1), ([1, 3], 17, 10, 66, 2), ([2, 1], 5, 130, 6, 1), ([3, 2], 16, 20, 600, 1)])
-def test_stride2_persistent_kernel_bit_identical_to_per_tile(hip, dev, shape):
+def test_stride2_persistent_kernel_bit_identical_to_per_tile(hip, dev, shape, hooks):
     """The persistent stride-2 kernel (weights resident in LDS, inputs requested two iterations ahead) against the per-tile
     kernel it replaces for enc1 / enc2: same operand layout and MFMA order => identical fp32 and split-packed outputs;
     partial tiles, several samples, multi-source concatenation."""
@@ -555,8 +586,8 @@ def test_splat_known_answers(hip, dev):
 # ---------------------------------------------------------------------------------------------------
 # cost volume
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("shape", [(2, 16, 20, 28), (1, 81, 13, 45), (2, 196, 9, 15), (1, 3, 64, 96)])
-def test_correlation_matches_oracle(hip, oracle, dev, shape):
+@pytest.mark.parametrize("shape", [(2, 16, 20, 28), (1, 81, 13, 45), (2, 196, 9, 15), (1, 3, 64, 96), (1, 37, 40, 100)])
+def test_correlation_matches_oracle(hip, oracle, dev, shape, hooks):
     from OpticalFlow import correlation
     g = _gen(4)
     a = torch.randn(*shape, generator=g)
@@ -566,6 +597,18 @@ def test_correlation_matches_oracle(hip, oracle, dev, shape):
     out2 = correlation.ModuleCorrelation()(a.to(dev), a.to(dev))
     _cmp(out2[:, 40], (a * a).mean(1), atol=1e-5, what="centre channel = mean square")
     assert out2[0, 0, 0, 0].item() == 0.0                                           # zero padding
+    # the three stagings (LDS-DMA double buffer with 8- / 16-channel chunks where W % 4 == 0; synchronous otherwise) give the same bits
+    L = hip.lib()
+    try:
+        outs = []
+        for variant, cc in ((0, 8), (1, 8), (1, 16)):
+            L.fldr_debug_corr_variant(variant)
+            L.fldr_debug_corr_chunk(cc)
+            outs.append(hip.correlation_fwd(a.to(dev), b.to(dev)))
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    finally:
+        L.fldr_debug_corr_variant(1)
+        L.fldr_debug_corr_chunk(8)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -898,7 +941,7 @@ def test_pwcnet_forward_runs_on_the_correlation_kernel(hip, oracle, dev):
     _cmp(orig(f.to(dev), s.to(dev)), oracle.correlation(f, s), atol=1e-5, rtol=1e-5, what="in-network cost volume")
 
 
-def test_fused_dec3_synth_matches_unfused(hip, dev):
+def test_fused_dec3_synth_matches_unfused(hip, dev, hooks):
     """dec3-on-nearest-x2 as four 2x2 phase convolutions + fp64 tail == 3x3 conv kernel + fldr_synth_tail."""
     g = _gen(12)
     N, h, w = 2, 20, 38
@@ -1131,7 +1174,7 @@ def test_gpu_ssim_y_matches_oracle(hip, oracle, dev, size):
             hip.ssim_y_u8(preds[:, :, :6].contiguous().to(dev), tgts[:, :, :6].contiguous().to(dev))
 
 
-def test_odd_shape_stress_of_kernel_variants(hip, dev, capsys):
+def test_odd_shape_stress_of_kernel_variants(hip, dev, capsys, hooks):
     """tools/stress_shapes.py: ~190 random odd shapes (tiny / partial tiles, several samples, multi-source, odd channel
     counts) of every kernel that has a variant hook or an unfused counterpart — persistent vs per-tile stride-2 conv,
     split-packed vs register-staged 3x3 conv under both unit policies, band vs strip splat, fused level-0 prep vs the

@@ -22,6 +22,19 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), "libfldr_hip.so does not export " + name
     assert declared == set(fldr_hip.EXPORTS), (declared ^ set(fldr_hip.EXPORTS))
+    # the product library exports the integration ABI and nothing else: no tuning / cross-check hook
+    import subprocess
+    syms = subprocess.run(["nm", "-D", "--defined-only", fldr_hip.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\b(fldr_[a-z0-9_]+)\b", syms))
+    assert not [n for n in exported if n.startswith("fldr_debug_")], sorted(exported)
+    assert exported == declared, sorted(exported ^ declared)
+    # ... the TEST build adds exactly the hooks of include/fldr_hip_test_hooks.h (minus those of the stamp builds)
+    hooks_hdr = open(os.path.join(ROOT, "include", "fldr_hip_test_hooks.h")).read()
+    hooks_decl = set(re.findall(r"\b(fldr_debug_[a-z0-9_]+)\s*\(", hooks_hdr))
+    tsyms = subprocess.run(["nm", "-D", "--defined-only", fldr_hip.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
+    texported = set(re.findall(r"\b(fldr_[a-z0-9_]+)\b", tsyms))
+    assert declared <= texported and texported - declared <= hooks_decl, sorted(texported - declared - hooks_decl)
+    assert set(fldr_hip.HOOKS) <= texported, sorted(set(fldr_hip.HOOKS) - texported)
     assert fldr_hip.lib().fldr_version() == 101
     assert fldr_hip.lib().fldr_error_string(-2) == b"fldr: shape constraint violated"
 

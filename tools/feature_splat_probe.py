@@ -1,6 +1,7 @@
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
+hip.enter_test_hooks()          # variant / tuning hooks: the test build (libfldr_hip_test.so)
 dev = torch.device("cuda:0"); torch.manual_seed(0); L = hip.lib()
 def timeit(fn, n=20):
     for i in range(3): fn(i)

@@ -14,6 +14,7 @@ tools/build_lib_variant.sh or tools/stamps/build_variant.sh).  One script instea
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
+hip.enter_test_hooks()          # variant / tuning hooks: the test build (libfldr_hip_test.so)
 dev = torch.device("cuda:0"); torch.manual_seed(0); L = hip.lib()
 
 
@@ -121,6 +122,20 @@ def gather():
             tg = timeit(lambda i: hip.softsplat_gather([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax"))
             ts = timeit(lambda i: (hip.softsplat_fused(f1, up[:, :2], None, "softmax", want_spk=True), hip.softsplat_fused(f0, up[:, 2:], None, "softmax", want_spk=True)))
             print("%3dx%3d flow ~%4.1f px: gather %.1f us, scatter+finish %.1f us" % (h, w, amp, tg, ts), flush=True)
+
+
+def corr():
+    """PWC cost volume at the decoder shapes of a 4K pair (N = 2: both directions): synchronous staging vs the LDS-DMA double buffer
+    with 8- / 16-channel chunks; algorithmic bytes (2 C planes in, 81 out) over the launch time against 8 TB/s."""
+    for (n, c, h, w) in [(2, 196, 34, 60), (2, 128, 68, 120), (2, 96, 136, 240), (2, 64, 272, 480), (2, 32, 544, 960)]:
+        a = [torch.randn(n, c, h, w, device=dev) for _ in range(3)]; b = [torch.randn(n, c, h, w, device=dev) for _ in range(3)]
+        t = []
+        for variant, cc in ((0, 8), (1, 8), (1, 16)):
+            L.fldr_debug_corr_variant(variant); L.fldr_debug_corr_chunk(cc)
+            t.append(timeit(lambda i: hip.correlation_fwd(a[i % 3], b[i % 3]), 30))
+        mb = n * h * w * (2 * c + 81) * 4 / 1e6
+        print("%3d ch @%4dx%4d (%6.1f MB): sync %.1f us, dma8 %.1f us (%.2f of 8 TB/s), dma16 %.1f us" % (c, h, w, mb, t[0], t[1], mb / t[1] / 8.0, t[2]), flush=True)
+    L.fldr_debug_corr_variant(1); L.fldr_debug_corr_chunk(8)
 
 
 if __name__ == "__main__":

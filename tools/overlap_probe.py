@@ -3,6 +3,7 @@ each alone and both together (ring conv with 8 / 4 consumer waves, i.e. 3 / 2 wa
 import os, sys, time, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
+hip.enter_test_hooks()          # variant / tuning hooks: the test build (libfldr_hip_test.so)
 dev = torch.device("cuda:0"); torch.manual_seed(0); L = hip.lib()
 H, W = 2304, 3840
 x = torch.rand(1, 96, 288, 480, device=dev); xp = hip.spk_pack(x); wt = torch.randn(96, 96, 3, 3, device=dev) / 30

@@ -3,6 +3,7 @@ identity), band splat vs strip splat (summation order only), fused level-0 prep 
 import os, sys, random, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
+hip.enter_test_hooks()          # variant / tuning hooks: the test build (libfldr_hip_test.so)
 dev = torch.device("cuda:0")
 random.seed(0); torch.manual_seed(0)
 bad = 0
