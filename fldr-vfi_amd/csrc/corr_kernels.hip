@@ -118,7 +118,9 @@ typedef __attribute__((address_space(1))) const void* corr_gptr_t;
 typedef __attribute__((address_space(3))) void* corr_lptr_t;
 __device__ __attribute__((aligned(16))) float corr_zero_block[4];
 
+#ifndef CORR_NLOAD
 #define CORR_NLOAD 3                   // loader waves (one wave issuing all 28 DMAs of a chunk took 2 us per chunk: the compute waves need 1)
+#endif
 template <int CC>
 __global__ __launch_bounds__(64 * (9 + CORR_NLOAD)) void correlation_dma_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                               float* __restrict__ out, int C, int H, int W) {

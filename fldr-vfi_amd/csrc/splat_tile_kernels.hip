@@ -127,31 +127,41 @@ __global__ __launch_bounds__(64 * ST_UP_WAVES) void splat_bounds_up_kernel(const
     const float* px = lo + (int64_t)n * lo_bstride;
     const float* py = px + (int64_t)h * w;
     float sxmin = INF, sxmax = -INF, symin = INF, symax = -INF;
+    // Footprint of a block: at most ST_BH + 1 rows and ST_BW + 2 columns when upsampling (H >= h, W >= w: host-checked).  The
+    // loads of ALL FOUR blocks of the wave go out first, from clamped indices instead of loop bounds (a repeated pixel does not
+    // change a minimum; blocks outside the image read block 0's footprint and are discarded): with data-dependent loop bounds, or
+    // with the blocks one after the other, every round waited for its own loads.  (A workgroup still needs ~10 us whatever
+    // its footprint — sixteen waves, four shuffle reductions each, one barrier — see the lane-per-block kernel below.)
+    constexpr int NBW = ST_SB_BLOCKS / ST_UP_WAVES, NV = (ST_BH + 1) * 2;
+    float vx[NBW][NV], vy[NBW][NV];
+    bool live[NBW];
 #pragma unroll
-    for (int j = 0; j < ST_SB_BLOCKS / ST_UP_WAVES; ++j) {
+    for (int j = 0; j < NBW; ++j) {
         const int b = wv + j * ST_UP_WAVES;                             // block of the super-block (wave-uniform)
-        const int X0 = ((sb % nsb_x) * ST_SBX + b % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + b / ST_SBX) * ST_BH;
-        float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
-        if (X0 < W && Y0 < H) {                                         // wave-uniform
-            int c0, c1, r0, r1, d0, d1; float l;
-            fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
-            fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
-            // footprint: at most ST_BH + 1 rows and ST_BW + 2 columns when upsampling (H >= h, W >= w: host-checked).  Clamped indices
-            // instead of loop bounds (a repeated pixel does not change a minimum): all 2 * 5 * 2 loads are independent and issued
-            // back to back — with data-dependent loop bounds every iteration waited for its own loads.
-            float vx[(ST_BH + 1) * 2], vy[(ST_BH + 1) * 2];
+        int X0 = ((sb % nsb_x) * ST_SBX + b % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + b / ST_SBX) * ST_BH;
+        live[j] = X0 < W && Y0 < H;
+        if (!live[j]) { X0 = 0; Y0 = 0; }
+        int c0, c1, r0, r1, d0, d1; float l;
+        fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
+        fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
 #pragma unroll
-            for (int k = 0; k < ST_BH + 1; ++k) {
-                const int r = min(r0 + k, r1);
+        for (int k = 0; k < ST_BH + 1; ++k) {
+            const int r = min(r0 + k, r1);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int c = min(c0 + lane + 64 * j, c1);
-                    vx[k * 2 + j] = px[(int64_t)r * w + c]; vy[k * 2 + j] = py[(int64_t)r * w + c];
-                }
+            for (int i = 0; i < 2; ++i) {
+                const int c = min(c0 + lane + 64 * i, c1);
+                vx[j][k * 2 + i] = px[(int64_t)r * w + c]; vy[j][k * 2 + i] = py[(int64_t)r * w + c];
             }
+        }
+    }
 #pragma unroll
-            for (int k = 0; k < (ST_BH + 1) * 2; ++k) {
-                const float ax = (scale * vx[k]) * mul, ay = (scale * vy[k]) * mul;
+    for (int j = 0; j < NBW; ++j) {
+        const int b = wv + j * ST_UP_WAVES;
+        float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
+        if (live[j]) {                                                  // wave-uniform
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const float ax = (scale * vx[j][k]) * mul, ay = (scale * vy[j][k]) * mul;
                 xmin = fminf(xmin, ax); xmax = fmaxf(xmax, ax); ymin = fminf(ymin, ay); ymax = fmaxf(ymax, ay);
             }
 #pragma unroll
@@ -174,6 +184,62 @@ __global__ __launch_bounds__(64 * ST_UP_WAVES) void splat_bounds_up_kernel(const
         }
         *reinterpret_cast<float4*>(sbt + ((int64_t)tab * nsb + sb) * 4) = make_float4(sxmin, sxmax, symin, symax);
     }
+}
+
+// The same table with ONE LANE per block and one wave per super-block (no LDS, no barrier): the better shape when the
+// upsampling factor is large — a x8 block's footprint is 10 x 2 low-resolution pixels, a 20-iteration loop per lane: 7.7 us for
+// the level-0 pair of a 4K frame, where the workgroup-per-super-block kernel above needs 20-45 us (one 1024-thread workgroup
+// per CU at a time, ~10 us each whatever the footprint).  For x2 (99 iterations per lane: 12-22 us) the kernel above wins.
+__global__ __launch_bounds__(64) void splat_bounds_up_lane_kernel(const float* __restrict__ lo, int64_t lo_bstride, const float* __restrict__ tv,
+                                                                  int smode, float mul, float* __restrict__ blk, float* __restrict__ sbt,
+                                                                  int h, int w, int H, int W, float sy, float sx, int nsb_x, int nsb,
+                                                                  int pair, int N) {
+#pragma clang fp contract(off)
+    const int sb = blockIdx.x, lane = threadIdx.x;
+    int n = blockIdx.y;
+    const int tab = n;                                                  // table sample
+    if (pair) {
+        const int k = n / N;
+        n -= k * N;
+        const bool second_half = (pair == 1) == (k == 0);             // channels 2-3 (flow_01)
+        lo += second_half ? 2 * (int64_t)h * w : 0;
+        smode = pair == 1 ? (k == 0 ? 1 : 2) : 0;
+    }
+    const int X0 = ((sb % nsb_x) * ST_SBX + lane % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + lane / ST_SBX) * ST_BH;
+    const float INF = __builtin_inff();
+    float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
+    if (X0 < W && Y0 < H) {
+        const float scale = smode == 0 ? 1.0f : (smode == 1 ? tv[n] : 1.0f - tv[n]);
+        int c0, c1, r0, r1, d0, d1; float l;
+        fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
+        fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
+        const float* px = lo + (int64_t)n * lo_bstride;
+        const float* py = px + (int64_t)h * w;
+        for (int r = r0; r <= r1; ++r)
+            for (int c = c0; c <= c1; ++c) {
+                const float vx = (scale * px[(int64_t)r * w + c]) * mul, vy = (scale * py[(int64_t)r * w + c]) * mul;
+                xmin = fminf(xmin, vx); xmax = fmaxf(xmax, vx); ymin = fminf(ymin, vy); ymax = fmaxf(ymax, vy);
+            }
+        const float ex = fmaxf(fabsf(xmin), fabsf(xmax)) * 2.0e-6f, ey = fmaxf(fabsf(ymin), fabsf(ymax)) * 2.0e-6f;
+        xmin -= ex; xmax += ex; ymin -= ey; ymax += ey;
+    }
+    *reinterpret_cast<float4*>(blk + (((int64_t)tab * nsb + sb) * ST_SB_BLOCKS + lane) * 4) = make_float4(xmin, xmax, ymin, ymax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
+        ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
+    }
+    if (lane == 0) *reinterpret_cast<float4*>(sbt + ((int64_t)tab * nsb + sb) * 4) = make_float4(xmin, xmax, ymin, ymax);
+}
+
+// which of the two: the lane-per-block kernel from x4 upwards
+static void splat_bounds_up_launch(const float* lo, int64_t lo_bstride, const float* t, int smode, float mul, float* blk, float* sbt,
+                                   int h, int w, int H, int W, int nsb_x, int nsb, int pair, int N, int samples, hipStream_t s) {
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    if ((int64_t)W >= 4 * (int64_t)w)
+        hipLaunchKernelGGL(splat_bounds_up_lane_kernel, dim3(nsb, samples), dim3(64), 0, s, lo, lo_bstride, t, smode, mul, blk, sbt, h, w, H, W, sy, sx, nsb_x, nsb, pair, N);
+    else
+        hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, samples), dim3(64 * ST_UP_WAVES), 0, s, lo, lo_bstride, t, smode, mul, blk, sbt, h, w, H, W, sy, sx, nsb_x, nsb, pair, N);
 }
 
 #ifdef FLDR_TEST_HOOKS        // the LDS-f32-atomic tile kernel (ds_add_f32: 80 ns per wave-instruction): measured and retired, test build only
@@ -854,8 +920,7 @@ extern "C" int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstr
     const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
     float* blk = ws;
     float* sbt = ws + (int64_t)N * nsb * ST_SB_BLOCKS * 4;
-    hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, N), dim3(64 * ST_UP_WAVES), 0, fldr_s(stream), flow_lo, lo_bstride, t, scale_mode, mul, blk, sbt,
-                       h, w, H, W, (float)h / (float)H, (float)w / (float)W, nsb_x, nsb, 0, N);
+    splat_bounds_up_launch(flow_lo, lo_bstride, t, scale_mode, mul, blk, sbt, h, w, H, W, nsb_x, nsb, 0, N, N, fldr_s(stream));
     FLDR_LAUNCH_RET();
 }
 
@@ -872,8 +937,7 @@ extern "C" int fldr_splat_bounds_upsampled_pair(const float* flow_l, int64_t lo_
     const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
     float* blk = ws;
     float* sbt = ws + (int64_t)2 * N * nsb * ST_SB_BLOCKS * 4;
-    hipLaunchKernelGGL(splat_bounds_up_kernel, dim3(nsb, 2 * N), dim3(64 * ST_UP_WAVES), 0, fldr_s(stream), flow_l, lo_bstride ? lo_bstride : 4 * (int64_t)h * w, t, 0,
-                       mul, blk, sbt, h, w, H, W, (float)h / (float)H, (float)w / (float)W, nsb_x, nsb, pair, N);
+    splat_bounds_up_launch(flow_l, lo_bstride ? lo_bstride : 4 * (int64_t)h * w, t, 0, mul, blk, sbt, h, w, H, W, nsb_x, nsb, pair, N, 2 * N, fldr_s(stream));
     FLDR_LAUNCH_RET();
 }
 
