@@ -624,6 +624,250 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     fldr_note_range(range_bad);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Persistent kernel on a SPLIT-PACKED source (round 3; enc2 reading enc1's packed twin: enc1 then writes no fp32 copy of its
+// 16 half-resolution planes, -141 MB per 4K forward).  Same LDS image, weight pack, MFMA order and epilogue as the kernel above;
+// what changes is the staging: a packed pixel is 16 bytes = the hi (or lo) halves of 8 channels, i.e. of TWO 4-channel chunks, so
+// the pipeline runs in group iterations — {MFMA phases of chunks 2g and 2g+1 from the two LDS stages; barrier; write the next
+// group's 8 channels into both stages from registers; request the group after that; barrier} — with one register set in flight
+// (the loads of a group have the two MFMA phases of the previous one to land).  An item is one (row pair, column): four 16-byte
+// loads (hi / lo x two rows), sixteen dwords written (8 channels x hi / lo, each dword = the two rows' halves, picked by
+// v_perm_b32): no conversion work at all — the operands are the producer's hi / lo halves (the split this kernel's fp32-source
+// twin would derive from hi + lo, except where lo was rounded up to a whole ulp of hi: same value, other split), so the results
+// agree with it to fp32 accumulation rounding.  cin % 8 == 0, one source.
+// ------------------------------------------------------------------------------------------------
+template <int MT, int NMT, int PT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv4x4s2_pers_spk_kernel(S2Args a) {
+    using Cfg = S2Cfg<MT, NMT>;
+    constexpr int KL = Cfg::KL, STEPS = Cfg::STEPS, IWHP = Cfg::IWHP, KIND = Cfg::KIND, CHS = Cfg::CHS;
+    constexpr int TPR = S2_TW / MT, RPW = PT / TPR;
+    static_assert(4 * RPW == S2_TH, "tile height");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int lj = lane & (MT - 1), lg = lane / MT;
+    const int n_chunks = a.cin / S2_CC, n_groups = a.cin / 8;                 // cin % 8 == 0 (host-checked)
+    unsigned char* const wall = smem;                                         // [chunk][W_BYTES]
+    unsigned char* const xst = smem + n_chunks * Cfg::W_BYTES;                // two input stages of X_DW dwords
+    unsigned char* const xs0 = xst;
+    unsigned char* const xs1 = xst + Cfg::X_DW * 4;
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int total_tiles = a.N * a.n_tiles;
+    const int t_end = min((xcd + 1) * a.tiles_per_xcd, total_tiles);
+    const int t_first = xcd * a.tiles_per_xcd + slot;
+    if (t_first >= t_end) return;                                             // workgroup-uniform
+    const int my_tiles = (t_end - t_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_tiles * n_groups;                                    // group iterations
+
+    // ---- weights: everything, once ----
+    {
+        const unsigned char* g = reinterpret_cast<const unsigned char*>(a.wpack + S2_HDR);
+        const int wbytes = n_chunks * Cfg::W_BYTES;                           // multiple of 1 KB
+        for (int piece = wave * 64; piece * 16 < wbytes; piece += 256)        // wave-uniform
+            __builtin_amdgcn_global_load_lds((s2_gptr_t)(g + (piece + lane) * 16), (s2_lptr_t)(wall + piece * 16), 16, 0, 0);
+    }
+
+    // ---- staging geometry: item e = thread + 256 i -> (row pair, column) of the 9 x 66 window ----
+    constexpr int NIT = (S2_RP * S2_IW + 255) / 256;                          // 3
+    int l_dw[NIT], it_pr2[NIT], it_x[NIT];
+#pragma unroll
+    for (int i = 0; i < NIT; ++i) {
+        const int e = tid + 256 * i;
+        const int pr = e / S2_IW, x = e % S2_IW;
+        it_pr2[i] = 2 * pr; it_x[i] = x;
+        l_dw[i] = e < S2_RP * S2_IW ? (pr * 2 + (x & 1)) * IWHP + (x >> 1) : -1;
+    }
+    const int64_t HWi = (int64_t)a.Hin * a.Win;
+    const int64_t src_b = a.src_bstride[0];                                   // BYTES between samples of the packed source
+    const unsigned char* const src0 = reinterpret_cast<const unsigned char*>(a.src[0]);
+    uint32_t voff0[NIT], voff1[NIT];                                          // byte offsets of the item's two pixels inside a (group, kind) plane
+    uint32_t vmask[NIT];                                                      // 0x0000FFFF: row 0 inside the image, 0xFFFF0000: row 1
+    int iss_k = 0, iss_g = 0, iss_n = 0;
+    auto issue_geometry = [&]() __attribute__((always_inline)) {
+        const int t = t_first + iss_k * a.wgs_per_xcd;
+        iss_n = t / a.n_tiles;
+        const int tile = t - iss_n * a.n_tiles;
+        const int ty = tile / a.tiles_x;
+        const int iy0 = ty * S2_TH * 2 - 1, ix0 = ((tile - ty * a.tiles_x) * S2_TW - a.x_shift) * 2 - 1;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            const int gy0 = iy0 + it_pr2[i], gy1 = gy0 + 1, gx = ix0 + it_x[i];
+            const bool okx = l_dw[i] >= 0 && gx >= 0 && gx < a.Win;
+            const bool ok0 = okx && gy0 >= 0 && gy0 < a.Hin, ok1 = okx && gy1 >= 0 && gy1 < a.Hin;
+            vmask[i] = (ok0 ? 0x0000FFFFu : 0u) | (ok1 ? 0xFFFF0000u : 0u);
+            const int cx = okx ? gx : 0;
+            voff0[i] = (uint32_t)(min(max(gy0, 0), a.Hin - 1) * a.Win + cx) * 16u;
+            voff1[i] = (uint32_t)(min(max(gy1, 0), a.Hin - 1) * a.Win + cx) * 16u;
+        }
+    };
+    // request the 8 channels of the issue side's (tile, group) and step the issue side (past the end: the last tile again)
+    s2_i4 R[NIT][4];                                                          // [item][hi row 0, hi row 1, lo row 0, lo row 1]
+    uint32_t Rmask[NIT];
+    auto issue_loads = [&]() __attribute__((always_inline)) {
+        const auto* gh = (const __attribute__((address_space(1))) char*)(src0 + (int64_t)iss_n * src_b + (int64_t)(iss_g * 2) * HWi * 16);
+        const auto* gl = gh + HWi * 16;
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            R[i][0] = *reinterpret_cast<const __attribute__((address_space(1))) s2_i4*>(gh + voff0[i]);
+            R[i][1] = *reinterpret_cast<const __attribute__((address_space(1))) s2_i4*>(gh + voff1[i]);
+            R[i][2] = *reinterpret_cast<const __attribute__((address_space(1))) s2_i4*>(gl + voff0[i]);
+            R[i][3] = *reinterpret_cast<const __attribute__((address_space(1))) s2_i4*>(gl + voff1[i]);
+            Rmask[i] = vmask[i];
+        }
+        if (++iss_g == n_groups) { iss_g = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }
+    };
+    // the register set -> both LDS stages: channel c of the group goes to plane c & 3 of stage c >> 2
+    auto store_inputs = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) {
+            if (l_dw[i] < 0) continue;
+#pragma unroll
+            for (int kind = 0; kind < 2; ++kind) {
+                const s2_i4 r0 = R[i][2 * kind], r1 = R[i][2 * kind + 1];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    // halves c of the two rows: dword c >> 1, low half for even c (bytes 1:0), high half for odd c (bytes 3:2)
+                    const uint32_t v = __builtin_amdgcn_perm((uint32_t)r1[c >> 1], (uint32_t)r0[c >> 1], (c & 1) ? 0x07060302u : 0x05040100u) & Rmask[i];
+                    uint32_t* dst = reinterpret_cast<uint32_t*>((c >> 2) ? xs1 : xs0) + (c & 3) * CHS + kind * KIND + l_dw[i];
+                    *dst = v;
+                }
+            }
+        }
+    };
+
+    // ---- operand geometry, accumulators, bias, MFMA phase, epilogue: as in conv4x4s2_pers_kernel ----
+    const int cps = KL / 2;
+    const int b_ch = cps == 2 ? (lg >> 1) : 0;
+    const int b_rp = cps == 2 ? (lg & 1) : lg;
+    int boff[PT];
+#pragma unroll
+    for (int p = 0; p < PT; ++p) {
+        const int r = wave * RPW + p / TPR, xl = (p % TPR) * MT + lj;
+        boff[p] = b_ch * CHS + ((r + b_rp) * 2) * IWHP + xl;
+    }
+    typedef typename std::conditional<MT == 32, s2_f16, s2_f4>::type acc_t;
+    constexpr int NR = MT == 32 ? 16 : 4;
+    acc_t acc[NMT][PT];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int p = 0; p < PT; ++p)
+#pragma unroll
+            for (int r = 0; r < NR; ++r) acc[m][p][r] = 0.0f;
+    const float inv_scale = a.wpack[0];
+    const int64_t HWo = (int64_t)a.Hout * a.Wout;
+    int cur_k = 0, cur_g = 0;
+    float bias_r[NMT][NR];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg : m * 16 + lg * 4 + r;
+            bias_r[m][r] = a.bias ? a.bias[co < a.cout ? co : a.cout - 1] : 0.0f;
+        }
+    bool range_bad = false;
+    auto mfma_phase = [&](const unsigned char* xs, int ch) __attribute__((always_inline)) {
+        const int* xin = reinterpret_cast<const int*>(xs);
+        const unsigned char* win = wall + ch * Cfg::W_BYTES + lane * 16;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            s2_h8 ah[NMT], al[NMT];
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                ah[m] = *reinterpret_cast<const s2_h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+                al[m] = *reinterpret_cast<const s2_h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            }
+            const int cbase = s * cps * CHS;
+#pragma unroll
+            for (int p = 0; p < PT; ++p) {
+                const int* q = xin + cbase + boff[p];
+                s2_i4 bhi, blo;
+                bhi[0] = q[0]; bhi[1] = q[1]; bhi[2] = q[IWHP]; bhi[3] = q[IWHP + 1];
+                blo[0] = q[KIND]; blo[1] = q[KIND + 1]; blo[2] = q[KIND + IWHP]; blo[3] = q[KIND + IWHP + 1];
+                const s2_h8 bh = __builtin_bit_cast(s2_h8, bhi), bl = __builtin_bit_cast(s2_h8, blo);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) {
+                    if constexpr (MT == 32) {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m][p], 0, 0, 0);
+                    } else {
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bh, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[m], bl, acc[m][p], 0, 0, 0);
+                        acc[m][p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[m], bh, acc[m][p], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    };
+    auto epilogue = [&]() __attribute__((always_inline)) {
+        const int t = t_first + cur_k * a.wgs_per_xcd;
+        const int n = t / a.n_tiles, tile = t - n * a.n_tiles;
+        const int ty = tile / a.tiles_x;
+        const int oy0 = ty * S2_TH, ox0 = (tile - ty * a.tiles_x) * S2_TW - a.x_shift;
+        float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
+        unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
+        const int lk = lg;
+#pragma unroll
+        for (int p = 0; p < PT; ++p) {
+            const int oy = oy0 + wave * RPW + p / TPR;
+            const int ox = ox0 + (p % TPR) * MT + lj;
+            const bool pix_ok = oy < a.Hout && ox >= 0 && ox < a.Wout;
+            const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                float vv[NR];
+#pragma unroll
+                for (int r = 0; r < NR; ++r) {
+                    const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk : m * 16 + lk * 4 + r;
+                    float v = acc[m][p][r] * inv_scale + bias_r[m][r];
+                    if (a.relu) v = fmaxf(v, 0.0f);
+                    vv[r] = v;
+                    acc[m][p][r] = 0.0f;
+                    if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+                }
+                if (spkn) {
+                    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int r0 = 0; r0 < NR; r0 += 4) {
+                        const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
+                        h4 hi, lo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                            _Float16 h_, l_;
+                            fldr_split_hl(x, h_, l_, range_bad);
+                            hi[r] = h_; lo[r] = l_;
+                        }
+                        if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {
+                            unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
+                            *reinterpret_cast<h4*>(q) = hi;
+                            *reinterpret_cast<h4*>(q + HWo * 16) = lo;
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- pipeline ----
+    issue_geometry();
+    issue_loads();                                                            // group iteration 0
+    store_inputs();
+    issue_loads();                                                            // group iteration 1 (or the last tile again)
+    __syncthreads();                                                          // (drains the weight DMA too)
+    for (int j = 0; j < total; ++j) {
+        mfma_phase(xs0, 2 * cur_g);
+        mfma_phase(xs1, 2 * cur_g + 1);
+        __syncthreads();                                                      // both stages consumed by everybody
+        const bool tile_done = cur_g == n_groups - 1;
+        if (j + 1 < total) { store_inputs(); issue_loads(); }                 // group j + 1 into the stages; request group j + 2
+        if (tile_done) { epilogue(); cur_g = 0; ++cur_k; } else ++cur_g;
+        __syncthreads();
+    }
+    fldr_note_range(range_bad);
+}
+
 int fldr_range_read_s2(int reset) { return fldr_tu_range_read(reset); }
 
 // ------------------------------------------------------------------------------------------------
@@ -797,4 +1041,44 @@ extern "C" int fldr_conv2d_s2_split(const fldr_conv_desc* d, fldr_stream_t strea
     if (mt == 16) return s2_launch<16, 1, 4>(a, d->N, s);
     if (nmt == 1) return s2_launch<32, 1, 2>(a, d->N, s);
     return s2_launch<32, 2, 2>(a, d->N, s);
+}
+
+// The stride-2 4x4 convolution on a split-packed source (fldr_conv2d_s2_split's arithmetic and outputs; d->src[0] = the packed
+// tensor, d->src_c[0] = cin with cin % 8 == 0, d->src_bstride[0] in BYTES (0 for N = 1); d->wpack from fldr_conv_s2_prepack).
+// Persistent kernel only: cin <= 64 and every chunk's weights in LDS; FLDR_E_SHAPE otherwise.
+template <int MT, int NMT, int PT>
+static int s2_launch_pers_spk(S2Args& a, int N, hipStream_t s, int lds_bytes) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv4x4s2_pers_spk_kernel<MT, NMT, PT>), lds_bytes, attr_done)) return e;
+    a.x_shift = 0;                                                            // (pixels are 16-byte records: every window start is aligned)
+    a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
+    a.n_tiles = a.tiles_x * fldr_cdiv(a.Hout, S2_TH);
+    a.N = N;
+    const int64_t total = (int64_t)N * a.n_tiles;
+    if (total >= (1ll << 30)) return FLDR_E_SHAPE;
+    a.tiles_per_xcd = (int)((total + 7) / 8);
+    a.wgs_per_xcd = a.tiles_per_xcd < 64 ? a.tiles_per_xcd : 64;
+    hipLaunchKernelGGL((conv4x4s2_pers_spk_kernel<MT, NMT, PT>), dim3(8 * a.wgs_per_xcd), dim3(256), lds_bytes, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_conv2d_s2_spk(const fldr_conv_desc* d, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d && d->wpack && (d->out || d->out_spk) && d->n_src == 1 && d->src[0] && !d->src_up2[0] && !d->residual);
+    FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= 64 && (d->cin & 7) == 0 && d->src_c[0] == d->cin && d->cout > 0 && d->cout <= 64);
+    FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->ksize == 4 && d->stride == 2);
+    if (d->Hout != (d->Hin + 2 - 4) / 2 + 1 || d->Wout != (d->Win + 2 - 4) / 2 + 1) return FLDR_E_SHAPE;
+    if ((int64_t)d->Hin * d->Win * 16 >= (1ll << 32)) return FLDR_E_SHAPE;
+    S2Args a;
+    for (int s = 0; s < FLDR_CONV_MAX_SRC; ++s) { a.src[s] = nullptr; a.src_bstride[s] = 0; a.src_cstride[s] = 0; a.src_cbegin[s] = 0; }
+    a.src[0] = d->src[0]; a.src_bstride[0] = d->src_bstride[0]; a.src_cbegin[FLDR_CONV_MAX_SRC] = d->cin; a.n_src = 1;
+    a.wpack = d->wpack; a.bias = d->bias; a.out = d->out; a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
+    a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
+    a.Hin = d->Hin; a.Win = d->Win; a.Hout = d->Hout; a.Wout = d->Wout; a.relu = d->relu; a.tiles_x = 0;
+    int mt, nmt;
+    s2_geometry(d->cout, mt, nmt);
+    const int n_chunks = d->cin / S2_CC;
+    hipStream_t s = fldr_s(stream);
+    if (mt == 16) { const int lds = n_chunks * S2Cfg<16, 1>::W_BYTES + 2 * S2Cfg<16, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<16, 1, 4>(a, d->N, s, lds); }
+    else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds); }
+    return FLDR_E_SHAPE;
 }

@@ -53,6 +53,7 @@ struct SaArgs {
     SaProblem p[2];
     int N, C, H, W, groups, nsb_x, nsb;
     int whole;                                    // 1: no bounds tables, every tile walks the whole map
+    int gpw;                                      // channel groups per workgroup (1 or `groups`)
     int tiles_x, st_y, n_st, total, per_xcd;      // tiles per row, super-tile rows, super-tiles per (problem, sample, group), all work items, items per XCD
 };
 
@@ -89,13 +90,15 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
     if ((int)(blockIdx.x >> 3) >= a.per_xcd || lin >= a.total) return;           // workgroup-uniform
     const int zi = lin / a.n_st, st = lin - zi * a.n_st;
     const int sty = st / a.tiles_x, stx = st - sty * a.tiles_x;
-    const int per_prob = a.N * a.groups;
+    // (a.gpw channel groups per workgroup: 1, or all of them — then the candidate search and the tile plans serve every group)
+    const int wg_groups = a.groups / a.gpw;                             // group slots in the work-item index
+    const int per_prob = a.N * wg_groups;
     const int prob = zi / per_prob;
     const int rem = zi - prob * per_prob;
-    const int n = rem / a.groups, grp = rem - n * a.groups;
+    const int n = rem / wg_groups, grp0 = (rem - n * wg_groups) * a.gpw;
     const SaProblem& P = a.p[prob];
     const int C = a.C, H = a.H, W = a.W, nsb_x = a.nsb_x, nsb = a.nsb;
-    const int cbase = grp * CB;
+    int cbase = grp0 * CB;                                              // first channel of the group being accumulated
     const int tx0 = stx * TW, sy0 = sty * (K * TH);
     const int64_t HW = (int64_t)H * W;
     const float ftx0 = (float)tx0, ftx1 = (float)(tx0 + TW - 1), fsy0 = (float)sy0, fsy1 = (float)(min(sy0 + K * TH, H) - 1);
@@ -281,7 +284,7 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
         }
     };
     // finish and write tile (tx0, fy0): (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349); the cells are left zeroed
-    auto finish = [&](int fy0) __attribute__((always_inline)) {
+    auto finish = [&](int fy0, int cbase) __attribute__((always_inline)) {
         for (int i = tid; i < CELLS; i += 256) {
             const int x = tx0 + i % TW, y = fy0 + i / TW;
             float norm = 1.0f;
@@ -323,14 +326,21 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
         }
     };
 
+    // units of this workgroup: (tile k, group g) in k-major order; a unit's first loads go out before the previous unit is written
     SaBuf<CB, U> b0, b1;
-    plan_tile(0);
-    if (n_chunks > 0) load_iter(b0, 0);
+    const int n_units = K * a.gpw;
+    auto begin_unit = [&](int u) __attribute__((always_inline)) {
+        const int k = u / a.gpw;
+        cbase = (grp0 + (u - k * a.gpw)) * CB;
+        plan_tile(k);
+        if (n_chunks > 0) load_iter(b0, 0);
+    };
+    begin_unit(0);
 #pragma unroll 1
-    for (int k = 0; k < K; ++k) {
-        const int cur_y0 = ty0;
+    for (int u = 0; u < n_units; ++u) {
+        const int cur_y0 = ty0, cur_cbase = cbase;
         if (cur_y0 >= H) break;                                         // workgroup-uniform
-        // tile k: its first iteration's loads are already in flight in b0
+        // this unit's first iteration's loads are already in flight in b0
         for (int k0 = 0; k0 < n_chunks; k0 += 2 * U) {
             const bool more = k0 + U < n_chunks;
             if (more) load_iter(b1, k0 + U);
@@ -339,11 +349,10 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
             if (k0 + 2 * U < n_chunks) load_iter(b0, k0 + 2 * U);
             process(b1);
         }
-        // the next tile's first loads go out before this tile is written
-        const bool next = k + 1 < K && sy0 + (k + 1) * TH < H;
-        if (next) { plan_tile(k + 1); if (n_chunks > 0) load_iter(b0, 0); }
+        const bool next = u + 1 < n_units && sy0 + ((u + 1) / a.gpw) * TH < H;
+        if (next) begin_unit(u + 1);
         __syncthreads();
-        finish(cur_y0);
+        finish(cur_y0, cur_cbase);
         if (!next) break;
         __syncthreads();
     }
@@ -351,6 +360,12 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
 }
 
 int fldr_range_read_acc64(int reset) { return fldr_tu_range_read(reset); }
+
+#ifndef SA_FOLD_MIN_TILES
+#define SA_FOLD_MIN_TILES 512
+#endif
+static int g_sa_group_fold = 0;          // measured at 288x480x48, both directions: 72.6 us folded vs 67.1 (1080 workgroups on 1024 slots: a second, nearly empty round)
+FLDR_HOOK int fldr_debug_splat_group_fold(int v) { if (v == 0 || v == 1) g_sa_group_fold = v; return g_sa_group_fold; }
 
 template <int MODE, int CB, int TW, int TH, int K, int U>
 static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
@@ -362,7 +377,7 @@ static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
     a.tiles_x = fldr_cdiv(a.W, TW);
     a.st_y = fldr_cdiv(a.H, K * TH);
     a.n_st = a.tiles_x * a.st_y;
-    const int64_t total = (int64_t)nprob * a.N * a.groups * a.n_st;
+    const int64_t total = (int64_t)nprob * a.N * (a.groups / a.gpw) * a.n_st;
     if (total > (1ll << 30)) return FLDR_E_SHAPE;
     a.total = (int)total;
     a.per_xcd = (a.total + 7) / 8;
@@ -375,8 +390,12 @@ static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
 // channels (two packed groups), 32 x 8 tiles (35 KB: four workgroups per CU), one pixel per thread in flight.
 template <int MODE>
 static int sa_launch(SaArgs& a, int nprob, hipStream_t s) {
-    if (a.C <= 3) { a.groups = 1; return sa_launch2<MODE, 3, SA_IMG_TW, SA_IMG_TH, SA_IMG_K, SA_IMG_U>(a, nprob, s); }
+    if (a.C <= 3) { a.groups = 1; a.gpw = 1; return sa_launch2<MODE, 3, SA_IMG_TW, SA_IMG_TH, SA_IMG_K, SA_IMG_U>(a, nprob, s); }
     a.groups = fldr_cdiv(a.C, 16);
+    // optionally (test-build hook; off: see g_sa_group_fold) all channel groups of a tile in ONE workgroup: one candidate search, the
+    // flow of a source pixel fetched by one workgroup instead of `groups`
+    const int64_t tiles = (int64_t)nprob * a.N * fldr_cdiv(a.W, SA_FEAT_TW) * fldr_cdiv(a.H, SA_FEAT_TH * SA_FEAT_K);
+    a.gpw = (g_sa_group_fold && tiles >= SA_FOLD_MIN_TILES) ? a.groups : 1;
     return sa_launch2<MODE, 16, SA_FEAT_TW, SA_FEAT_TH, SA_FEAT_K, SA_FEAT_U>(a, nprob, s);
 }
 

@@ -394,8 +394,13 @@ class PCARefineUNet(nn.Module):
             # the encoders (exact fp32-MFMA stride-2 kernels) emit the split-packed twins the decoder reads; decoder
             # activations only exist split-packed
             cs = fldr_hip.conv2d_spk
-            enc1, enc1p = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True, want_spk=True)
-            enc2, enc2p = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True, want_spk=True)
+            if fldr_hip.s2_spk_ok(self.enc2.weight):
+                # enc2 reads enc1's PACKED output: enc1 writes no fp32 copy of its 16 half-resolution planes (141 MB at 4K)
+                enc1p = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True, want_f32=False, want_spk=True)
+                enc2, enc2p = fldr_hip.conv2d_s2_spk(enc1p, self.enc2.weight, self.enc2.bias, relu=True, want_f32=True, want_spk=True)
+            else:
+                enc1, enc1p = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True, want_spk=True)
+                enc2, enc2p = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True, want_spk=True)
             out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)
             out = cs([out], self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
             out = cs([out, enc2p], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)

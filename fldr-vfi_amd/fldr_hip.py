@@ -113,6 +113,7 @@ _SIGNATURES = {
                                     + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_correlation_fwd": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_debug_corr_variant": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_splat_group_fold": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_corr_chunk": (ctypes.c_int, [ctypes.c_int]),
     "fldr_softsplat_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -139,6 +140,7 @@ _SIGNATURES = {
     "fldr_conv_s2_prepack_size": (ctypes.c_int64, [ctypes.c_int] * 2),
     "fldr_conv_s2_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_s2_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_conv2d_s2_spk": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_debug_s2_persistent": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_s2_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_dec3_xshift": (ctypes.c_int, [ctypes.c_int]),
@@ -1058,6 +1060,42 @@ def conv2d_spk(srcs, weight, bias, relu=False, residual=None, cout_store=None, u
     if want_f32 and want_spk:
         return out32, outp
     return outp if want_spk else out32
+
+
+def conv2d_s2_spk(src, weight, bias, relu=False, want_f32=True, want_spk=False):
+    """The stride-2 4x4 convolution on ONE split-packed source (fldr_conv2d_s2_spk: an encoder reading the previous encoder's packed
+    output, whose fp32 copy then need not exist).  -> fp32, Spk or (fp32, Spk); equal to conv2d(..., stride=2) on the unpacked
+    values up to fp32 accumulation rounding.  Raises FldrError (shape) where the persistent kernel does not apply: check s2_spk_ok first."""
+    cout, cin, k, _ = weight.shape
+    assert k == 4 and isinstance(src, Spk) and src.shape[1] == cin
+    N, _, Hin, Win = src.shape
+    Hout, Wout = (Hin + 2 - 4) // 2 + 1, (Win + 2 - 4) // 2 + 1
+    d = ConvDesc()
+    d.src[0], d.src_bstride[0], d.src_c[0], d.src_up2[0], d.n_src = src.ptr, (src.bstride if N > 1 else 0), cin, 0, 1
+    want_f32 = want_f32 or not want_spk
+    out = torch.empty(N, cout, Hout, Wout, device=src.device, dtype=torch.float32) if want_f32 else None
+    outp = _spk_alloc(N, cout, Hout, Wout, src.device) if want_spk else None
+    wp = conv_s2_prepack(weight)
+    d.wpack = wp.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.out = out.data_ptr() if out is not None else None
+    d.out_spk = outp.buf.data_ptr() if outp is not None else None
+    d.N, d.cin, d.cout, d.cout_store = N, cin, cout, cout
+    d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
+    d.ksize, d.stride, d.relu, d.precision = 4, 2, int(bool(relu)), 0
+    _check(lib().fldr_conv2d_s2_spk(ctypes.byref(d), _stream()), "fldr_conv2d_s2_spk")
+    if want_spk:
+        return (out, outp) if out is not None else outp
+    return out
+
+
+def s2_spk_ok(weight):
+    """Does fldr_conv2d_s2_spk take this layer (cin a multiple of 8, <= 64; all chunks' weights + two stages within 80 KB of LDS)?"""
+    cout, cin, k, _ = weight.shape
+    if k != 4 or cin % 8 or cin > 64 or cout > 32 or CONV_PRECISION == "fp32" or os.environ.get("FLDR_S2_SPK", "1") == "0":
+        return False
+    w_bytes = (2 if cout <= 16 else 4) * 2 * 1024                  # S2Cfg<MT, 1>::W_BYTES: steps x (hi, lo) KB
+    return (cin // 4) * w_bytes + 2 * 4 * 1440 * 4 <= 80 * 1024
 
 
 def conv2d_spk_levels(srcs, weight, bias, relu=False, residuals=None, want_f32=True, want_spk=False, precision=None):

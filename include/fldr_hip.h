@@ -318,6 +318,13 @@ int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
  * stride 2, no x2 sources, no residual, cout <= 64; wpack from fldr_conv_s2_prepack; `out` and / or `out_spk`. */
 int64_t fldr_conv_s2_prepack_size(int cout, int cin);
 int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+/* The same stride-2 4x4 convolution reading ONE split-packed source (an encoder reading the previous encoder's packed output:
+ * the producer then needs no fp32 copy): desc->src[0] = the packed tensor, src_c[0] = cin (a multiple of 8, <= 64),
+ * src_bstride[0] in BYTES; outputs as fldr_conv2d_s2_split.  The MFMA operands are the stored hi / lo halves themselves (what
+ * fldr_conv2d_s2_split derives from the unpacked value hi + lo, except in the rare case that lo was rounded up to a whole ulp
+ * of hi: same value, other split), so the results agree with that function to fp32 accumulation rounding.  Shapes whose
+ * weights do not fit the persistent kernel's LDS return FLDR_E_SHAPE (use fldr_spk_unpack + fldr_conv2d_s2_split). */
+int fldr_conv2d_s2_spk(const fldr_conv_desc* desc, fldr_stream_t stream);
 int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.

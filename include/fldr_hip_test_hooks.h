@@ -30,6 +30,7 @@ int fldr_debug_s2_persistent(int v);                               /* stride-2 e
 int fldr_debug_s2_xshift(int v);                                   /* tile-grid shift of the persistent stride-2 kernel (output columns; -1: default) */
 int fldr_debug_s2_vec4(int v);                                     /* 16-byte staging loads of the persistent stride-2 kernel: 1 (default) / 0 */
 int fldr_debug_dec3_xshift(int v);                                 /* tile-grid shift of dec3_synth (low-resolution columns; -1: default) */
+int fldr_debug_splat_group_fold(int v);                            /* fldr_softsplat_acc64, > 3 channels: 1 all channel groups of a tile in one workgroup where the map is large enough, 0 (default) one group per workgroup; other: query.  Same results */
 int fldr_debug_conv_occupancy(int* out4);                          /* occupancy query of the fp32-MFMA convolution kernels */
 
 #ifdef __cplusplus

@@ -289,6 +289,31 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape, hooks):
             assert torch.equal(hip.conv2d([ref[:, half:]], w3, None, precision="split"), hip.conv2d_spk([gp.narrow(half, half)], w3, None))
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 50, 70, 2), (8, 16, 34, 130, 1), (32, 16, 18, 66, 1), (16, 32, 144, 240, 1), (24, 16, 20, 36, 1)])
+def test_stride2_conv_on_packed_source(hip, dev, shape):
+    """fldr_conv2d_s2_spk (enc2 reading enc1's packed output): the bits of the fp32-source stride-2 kernel on the values the
+    packed tensor holds — fp32 and packed outputs, odd sizes, batch of 2, several workgroup rounds."""
+    cin, cout, H, W, N = shape
+    g = _gen(88)
+    x = F.relu(torch.randn(N, cin, H, W, generator=g)).to(dev) * 3
+    wt = (torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    xp = hip.spk_pack(x)
+    xv = xp.float()                                         # hi + lo: what the packed tensor holds
+    assert hip.s2_spk_ok(wt)
+    got32, gotp = hip.conv2d_s2_spk(xp, wt, b, relu=True, want_f32=True, want_spk=True)
+    ref32, refp = hip.conv2d([xv], wt, b, stride=2, relu=True, want_spk=True)
+    # the fp32-source kernel splits xv again: hi / lo of (hi + lo) are hi / lo themselves except where lo's own rounding moved a bit
+    _cmp(got32, ref32, atol=2e-6 * float(ref32.abs().max()) + 1e-7, what="s2 on packed source")
+    assert torch.equal(hip.spk_pack(got32).buf, gotp.buf)
+    only = hip.conv2d_s2_spk(xp, wt, b, relu=True, want_f32=False, want_spk=True)
+    assert torch.equal(only.buf, gotp.buf)
+    ref = F.relu(F.conv2d(xv.double().cpu(), wt.double().cpu(), b.double().cpu(), stride=2, padding=1))
+    a32 = hip.conv2d([xv], wt, b, stride=2, relu=True, precision="fp32").double().cpu()
+    e32, esp = (a32 - ref).abs().mean().item(), (got32.double().cpu() - ref).abs().mean().item()
+    assert esp <= 1.5 * e32 + 1e-8, (esp, e32)
+
+
 @pytest.mark.parametrize("case", [(96, 96, True, True), (96, 96, True, False), (48, 16, False, False), (64, 40, True, True)])
 def test_multi_level_conv_launch(hip, dev, case):
     """fldr_conv2d_spk_levels (rec_ctx_ds over the pyramid levels in one launch, fLDRnet.py:148-162): the bits of the per-level

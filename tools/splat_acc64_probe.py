@@ -4,6 +4,7 @@ piecewise-constant shift (the bench's synthetic pairs) and on a smoothly varying
 import os, sys, torch, torch.nn.functional as F
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
+hip.enter_test_hooks()          # variant hooks: the test build (libfldr_hip_test.so)
 dev = torch.device("cuda:0"); torch.manual_seed(0); L = hip.lib()
 
 
@@ -59,9 +60,16 @@ def features():
             tp = timeit(lambda i: hip.softsplat_pair_spk(f1c, ua, f0c, ub, "softmax"))
             ta = timeit(lambda i: hip.softsplat_acc64([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True, spk_batch=True,
                                                       bounds_ws=hip.splat_bounds_upsampled_pair(prev, None, "features", 2.0, h, w) if h * w > 2304 else None))
+            tf = None
+            if hasattr(hip.lib(), "fldr_debug_splat_group_fold"):
+                hip.lib().fldr_debug_splat_group_fold(1)
+                tf = timeit(lambda i: hip.softsplat_acc64([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True, spk_batch=True,
+                                                          bounds_ws=hip.splat_bounds_upsampled_pair(prev, None, "features", 2.0, h, w) if h * w > 2304 else None))
+                hip.lib().fldr_debug_splat_group_fold(0)
             a = hip.softsplat_acc64([f1, f0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=True, want_spk=False)
             s = hip.softsplat_fused(f1c, ua, None, "softmax", kernel="strip")
-            print("features %dx%d %s: strip pair %.1f us | acc64 pair %.1f us | max |acc64 - strip| %.2e" % (h, w, kind, tp, ta, (a[0] - s).abs().max().item()), flush=True)
+            print("features %dx%d %s: strip pair %.1f us | acc64 pair %.1f us%s | max |acc64 - strip| %.2e"
+                  % (h, w, kind, tp, ta, "" if tf is None else " (all channel groups in one workgroup: %.1f us)" % tf, (a[0] - s).abs().max().item()), flush=True)
 
 
 if __name__ == "__main__":
