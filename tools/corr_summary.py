@@ -8,7 +8,7 @@ def per_shape(d, key=None):
     f = (glob.glob(d + "/*/*kernel_trace.csv") + glob.glob(d + "/*/*counter_collection.csv"))[0]
     out = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        if "correlation_kernel" not in r["Kernel_Name"]:
+        if "correlation_" not in r["Kernel_Name"]:
             continue
         g = r.get("Grid_Size") or r.get("Grid_Size_X") or r.get("Workgroup_Count") or "?"
         if key is None:
@@ -29,4 +29,4 @@ for (g, v), (n, c, h, w) in zip(sorted(t.items(), key=lambda kv: float(kv[0]) if
     if g in fe: row["fetch_x2_MB"] = round(2 * 1024 * sum(fe[g].values()) / len(fe[g]) / 1e6, 1)
     if g in wr: row["write_MB"] = round(1024 * sum(wr[g].values()) / len(wr[g]) / 1e6, 1)
     rows.append(row)
-print(json.dumps({"kernel": "correlation_kernel (PWC-Net cost volume, radius 4, 81 channels)", "per_shape": rows}, indent=1))
+print(json.dumps({"kernel": "correlation_dma_kernel<8> (PWC-Net cost volume, radius 4, 81 channels; LDS-DMA loader waves)", "per_shape": rows}, indent=1))

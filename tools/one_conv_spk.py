@@ -1,5 +1,5 @@
-"""REPS launches of the dominant kernel (conv3x3_spk_kernel<3,3,false>, 96->96 3x3 @288x480, packed in / packed out) for the
-rocprofv3 PMC passes (profiles/r01_conv96_spk_*)."""
+"""REPS launches of the dominant kernel (conv3x3_ring_kernel<3,3,false,8,32>, 96->96 3x3 @288x480, packed in / packed out) for the
+rocprofv3 PMC passes (profiles/r0N_conv96_*)."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_hip as hip
