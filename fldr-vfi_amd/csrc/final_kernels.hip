@@ -43,16 +43,25 @@ struct FinalArgs {
     int64_t cstride[6];          // floats between the 3 channel planes of a candidate
 };
 
+struct D3Grid { int tiles_x, per_sample, total, per_xcd; };
+
 template <typename OUT>
 __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict__ d2, const float* __restrict__ weff,
                                                          const float* __restrict__ bias, FinalArgs cd,
                                                          const float* __restrict__ tv, double T, OUT* __restrict__ out,
-                                                         float* __restrict__ refine_dbg, int H, int W, int xs) {
+                                                         float* __restrict__ refine_dbg, int H, int W, int xs, D3Grid gr) {
     // xs: the tile grid starts xs low-resolution columns left of the image (fldr_dec3_synth_strided)
     const int h = H >> 1, w = W >> 1;
     __shared__ float tile[D3_CIN][D3_TH + 2][D3_TW + 2];
     const int tid = threadIdx.x, tx = tid % D3_TW, ty = tid / D3_TW;
-    const int i0 = blockIdx.y * D3_TH, j0 = blockIdx.x * D3_TW - xs, n = blockIdx.z;
+    // Tiles are dealt to the XCDs in contiguous row-major ranges (workgroup b runs on XCD b & 7): horizontally adjacent tiles
+    // share the 128-byte lines that hold their halo columns of dec2's output, and then find them in the same L2 instead
+    // of fetching them once per XCD.
+    const int lin = gr.per_xcd ? (int)(blockIdx.x & 7) * gr.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;   // (per_xcd 0: row-major, test hook)
+    if ((gr.per_xcd && (int)(blockIdx.x >> 3) >= gr.per_xcd) || lin >= gr.total) return;      // workgroup-uniform
+    const int n = lin / gr.per_sample, trem = lin - n * gr.per_sample;
+    const int tyi = trem / gr.tiles_x;
+    const int i0 = tyi * D3_TH, j0 = (trem - tyi * gr.tiles_x) * D3_TW - xs;
     const float* src = d2 + (int64_t)n * D3_CIN * h * w;
     constexpr int TILE_E = (D3_TH + 2) * (D3_TW + 2);
     // Staging: this thread's (up to two) slots of a channel's (TH+2) x (TW+2) tile are the same for all 16 channels, so the
@@ -212,6 +221,8 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     }
 }
 
+static int g_d3_xcd = 1;                         // 1: XCD-contiguous tile ranges (see the kernel); 0: row-major round-robin
+FLDR_HOOK int fldr_debug_dec3_xcd(int v) { if (v == 0 || v == 1) g_d3_xcd = v; return g_d3_xcd; }
 static int g_d3_xshift = -1;                     // -1: automatic (16 on wide frames); 0 .. 31: forced
 FLDR_HOOK int fldr_debug_dec3_xshift(int v) { if (v >= -1 && v < D3_TW) g_d3_xshift = v; return g_d3_xshift; }
 
@@ -240,9 +251,15 @@ extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const
     // into the lines left and right; PMC at 4K: 526 MB fetched for the 141 MB of dec2's output), while the full-resolution
     // candidate loads and the frame stores (64 t - 32 ...) stay line-aligned.  One extra half-filled tile column.
     const int xs = g_d3_xshift >= 0 ? g_d3_xshift : (W >= 1024 ? 16 : 0);
-    dim3 grid(fldr_cdiv(W / 2 + xs, D3_TW), fldr_cdiv(H / 2, D3_TH), N);
-    if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs);
-    else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs);
+    D3Grid gr;
+    gr.tiles_x = fldr_cdiv(W / 2 + xs, D3_TW);
+    gr.per_sample = gr.tiles_x * fldr_cdiv(H / 2, D3_TH);
+    if ((int64_t)gr.per_sample * N > (1ll << 30)) return FLDR_E_SHAPE;
+    gr.total = gr.per_sample * N;
+    gr.per_xcd = g_d3_xcd ? (gr.total + 7) / 8 : 0;
+    dim3 grid(g_d3_xcd ? 8 * gr.per_xcd : gr.total);
+    if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
+    else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
     FLDR_LAUNCH_RET();
 }
 

@@ -30,6 +30,9 @@
 #define SA_IMG_K 3
 #define SA_IMG_U 4
 #endif
+#ifndef SA_IMGQ_U
+#define SA_IMGQ_U 1                  // 4-pixel runs per thread in flight (QUAD walk)
+#endif
 #ifndef SA_FEAT_TW
 #define SA_FEAT_TW 32                // 16-channel-group configuration
 #define SA_FEAT_TH 8
@@ -57,12 +60,21 @@ struct SaArgs {
     int tiles_x, st_y, n_st, total, per_xcd;      // tiles per row, super-tile rows, super-tiles per (problem, sample, group), all work items, items per XCD
 };
 
-template <int CB, int U>
+template <int CB, int U, bool QUAD>
 struct SaBuf {
     int x[U], y[U];
     bool ok[U];
     float fx[U], fy[U], mv[U], val[U][CB];
 };
+// QUAD: an item is a run of four horizontally adjacent source pixels (x a multiple of 4), loaded with one 16-byte access per plane
+template <int CB, int U>
+struct SaBuf<CB, U, true> {
+    int x[U], y[U];
+    bool ok[U];
+    float4 fx[U], fy[U], mv[U], val[U][CB];
+};
+__device__ __forceinline__ void sa_pin4(float4& v) { fldr_pin(v.x); fldr_pin(v.y); fldr_pin(v.z); fldr_pin(v.w); }
+__device__ __forceinline__ float sa_at(const float4& v, int j) { return j == 0 ? v.x : (j == 1 ? v.y : (j == 2 ? v.z : v.w)); }
 
 // MODE: 0 summation; 1 average; 2 linear; 3 softmax.  CB value channels per workgroup (+ the normalisation accumulator when
 // MODE >= 1).  A workgroup owns a column of K vertically adjacent TW x TH tiles: ONE candidate search for the whole column
@@ -71,7 +83,15 @@ struct SaBuf {
 // iteration i + 1 — and of the next tile's first iteration — are in flight under iteration i / under the tile's write-out.
 // Work items are dealt to the XCDs in contiguous row-major ranges (blockIdx & 7 = XCD): neighbouring tiles read overlapping
 // source rows and the two halves of partly covered 128-byte lines, which then hit in the same L2.
-template <int MODE, int CB, int TW, int TH, int K, int U>
+//
+// QUAD (images whose rows are a multiple of 4 pixels, 16-byte aligned planes): a thread's item is a run of FOUR adjacent source
+// pixels.  (1) Every plane is read with 16-byte lane accesses — this chip streams 3.9-4.1 TB/s through 4-byte lanes and
+// 5.5-5.9 TB/s through 16-byte ones (tools/ubench/plane_bw_bench), and the 4-byte walk was pinned there.  (2) Under a coherent
+// flow pixel j's east corners ARE pixel j + 1's west corners: the thread adds the two fp32 products in fp64 (exactly) in
+// registers and issues one atomic — 10 instead of 16 per run and channel.  (3) Lanes are then 4 cells apart, so the
+// accumulator rows are stored de-interleaved by 4 (cell x at (x & 3) * TW / 4 + x / 4): the lanes of one atomic instruction
+// hit consecutive 8-byte words again.
+template <int MODE, int CB, int TW, int TH, int K, int U, bool QUAD>
 __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
 #pragma clang fp contract(off)
     constexpr int CA = MODE >= 1 ? CB + 1 : CB;
@@ -204,6 +224,13 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
             n_chunks = rect ? (int)((area + 255) / 256) : n_match;
         }
         Rw = max(X1 - X0 + 1, 1); Rh = max(Y1 - Y0 + 1, 0);
+        if constexpr (QUAD) {
+            // the walk's items are runs of 4 pixels: the rectangle widens to multiples of 4 (W % 4 == 0), the block walk
+            // takes four blocks (one per wave: 64 runs) per iteration
+            X0 &= ~3; X1 = min(X1 | 3, W - 1);
+            Rw = max((X1 - X0 + 1) >> 2, 1);
+            if (n_chunks > 0) n_chunks = rect ? (int)(((int64_t)Rw * Rh + 255) / 256) : (n_match + 3) >> 2;
+        }
         rx = tid % Rw; ry = tid / Rw;
         dqx = 256 % Rw; dqy = 256 / Rw;
 #if defined(SA_ABLATE) && SA_ABLATE == 1                              // diagnostic: search + zero + finish only
@@ -211,14 +238,19 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
 #endif
     };
 
-    auto load_chunk = [&](SaBuf<CB, U>& b, int u, int k) __attribute__((always_inline)) {
+    auto load_chunk = [&](SaBuf<CB, U, QUAD>& b, int u, int k) __attribute__((always_inline)) {
         int x, y;
         bool ok;
         if (rect) {
-            x = X0 + rx; y = Y0 + ry;
+            x = X0 + (QUAD ? 4 * rx : rx); y = Y0 + ry;
             ok = k < n_chunks && ry < Rh;
             rx += dqx; ry += dqy;
             if (rx >= Rw) { rx -= Rw; ++ry; }
+        } else if constexpr (QUAD) {
+            const int bi = 4 * k + wv;
+            const int e = blkq[bi < n_match ? bi : 0];
+            x = (e & 0xFFFF) * ST_BW + (lane & 15) * 4; y = (e >> 16) * ST_BH + (lane >> 4);
+            ok = bi < n_match && x < W && y < H;
         } else {
             const int e = blkq[k < n_chunks ? k : 0];
             x = (e & 0xFFFF) * ST_BW + lane; y = (e >> 16) * ST_BH + wv;
@@ -226,26 +258,123 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
         }
         b.x[u] = x; b.y[u] = y; b.ok[u] = ok;
         const int64_t pix = ok ? (int64_t)y * W + x : 0;                // clamped: every load below is unconditional
-        b.fx[u] = fl[pix]; b.fy[u] = fl[HW + pix];
-        b.mv[u] = 0.0f;
-        if ((MODE == 2 || MODE == 3) && mt != nullptr) b.mv[u] = mt[pix];
+        if constexpr (QUAD) {
+            b.fx[u] = *reinterpret_cast<const float4*>(fl + pix); b.fy[u] = *reinterpret_cast<const float4*>(fl + HW + pix);
+            b.mv[u] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if ((MODE == 2 || MODE == 3) && mt != nullptr) b.mv[u] = *reinterpret_cast<const float4*>(mt + pix);
 #pragma unroll
-        for (int c = 0; c < CB; ++c) {
-            const int cc = cbase + c < C ? cbase + c : C - 1;
-            b.val[u][c] = inn[(int64_t)cc * P.img_cstride + pix];
+            for (int c = 0; c < CB; ++c) {
+                const int cc = cbase + c < C ? cbase + c : C - 1;
+                b.val[u][c] = *reinterpret_cast<const float4*>(inn + (int64_t)cc * P.img_cstride + pix);
+            }
+        } else {
+            b.fx[u] = fl[pix]; b.fy[u] = fl[HW + pix];
+            b.mv[u] = 0.0f;
+            if ((MODE == 2 || MODE == 3) && mt != nullptr) b.mv[u] = mt[pix];
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int cc = cbase + c < C ? cbase + c : C - 1;
+                b.val[u][c] = inn[(int64_t)cc * P.img_cstride + pix];
+            }
         }
     };
-    auto load_iter = [&](SaBuf<CB, U>& b, int k0) __attribute__((always_inline)) {
+    auto load_iter = [&](SaBuf<CB, U, QUAD>& b, int k0) __attribute__((always_inline)) {
 #pragma unroll
         for (int u = 0; u < U; ++u) load_chunk(b, u, k0 + u);
     };
-    auto process = [&](SaBuf<CB, U>& b) __attribute__((always_inline)) {
+    auto process = [&](SaBuf<CB, U, QUAD>& b) __attribute__((always_inline)) {
+      if constexpr (QUAD) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            sa_pin4(b.fx[u]); sa_pin4(b.fy[u]); sa_pin4(b.mv[u]);
+#pragma unroll
+            for (int c = 0; c < CB; ++c) sa_pin4(b.val[u][c]);
+        }
+#if defined(SA_ABLATE) && SA_ABLATE == 3                              // diagnostic: the walk's loads only
+        return;
+#endif
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!b.ok[u]) continue;
+            int x0[4], y0[4], iw[4], ie[4];
+            float wnw[4], wne[4], wsw[4], wse[4], wg[4];
+            bool xa[4], xb[4], ya[4], yb[4];
+            bool any = false;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const StGeom g = st_geom(b.x[u] + j, b.y[u], sa_at(b.fx[u], j), sa_at(b.fy[u], j), W, H);     // x0 in [-2, W + 1], y0 in [-2, H + 1]
+                x0[j] = g.x0; y0[j] = g.y0; wnw[j] = g.wnw; wne[j] = g.wne; wsw[j] = g.wsw; wse[j] = g.wse;
+                const uint32_t ulx = (uint32_t)(g.x0 - tx0), uly = (uint32_t)(g.y0 - ty0), ux1 = ulx + 1u;      // tile-local north-west corner (wraps when outside)
+                // a corner counts when it lies in this tile (cells right of / below the image exist in a partial tile and are never written out)
+                xa[j] = ulx < (uint32_t)TW; xb[j] = ux1 < (uint32_t)TW; ya[j] = uly < (uint32_t)TH; yb[j] = uly + 1u < (uint32_t)TH;
+                iw[j] = (int)(uly * (uint32_t)TW + (ulx & 3u) * (uint32_t)(TW / 4) + (ulx >> 2));              // west / east column, row y0 (+ TW: row y0 + 1)
+                ie[j] = (int)(uly * (uint32_t)TW + (ux1 & 3u) * (uint32_t)(TW / 4) + (ux1 >> 2));
+                any = any || ((xa[j] || xb[j]) && (ya[j] || yb[j]));
+                wg[j] = 1.0f;
+                if (MODE == 2) wg[j] = sa_at(b.mv[u], j);
+                if (MODE == 3 && mt != nullptr) wg[j] = expf(sa_at(b.mv[u], j));
+            }
+            if (!any) continue;                                           // no footprint of the run touches the tile
+            float v[4][CA];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int c = 0; c < CA; ++c) {
+                    float t = wg[j];                                       // normalisation accumulator
+                    if (c < CB) {
+                        t = sa_at(b.val[u][c < CB ? c : 0], j);
+                        if (MODE == 3) t = (t + 1.0f) / 2.0f;              // softSplat.py:334
+                        if (MODE >= 2) t = t * wg[j];                      // :328 / :338
+                        if (cbase + c >= C) t = 0.0f;
+                    }
+                    v[j][c] = t;
+                }
+            // hand-off j -> j + 1: pixel j's east column is pixel j + 1's west column, same rows (then their validity agrees too)
+            bool gn[4], gs[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool coh = j < 3 && x0[j] + 1 == x0[j < 3 ? j + 1 : j] && y0[j] == y0[j < 3 ? j + 1 : j];
+                gn[j] = coh && xb[j] && ya[j]; gs[j] = coh && xb[j] && yb[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int jp = j > 0 ? j - 1 : 0;
+                if (xa[j] && ya[j]) {
+#pragma unroll
+                    for (int c = 0; c < CA; ++c) {                         // the reference's fp32 products (softSplat.py:40-51), summed in fp64
+                        double d = (double)(v[j][c] * wnw[j]);
+                        if (j > 0) d += (double)(gn[jp] ? v[jp][c] * wne[jp] : 0.0f);
+                        atomicAdd(acc + c * CELLS + iw[j], d);
+                    }
+                }
+                if (xa[j] && yb[j]) {
+#pragma unroll
+                    for (int c = 0; c < CA; ++c) {
+                        double d = (double)(v[j][c] * wsw[j]);
+                        if (j > 0) d += (double)(gs[jp] ? v[jp][c] * wse[jp] : 0.0f);
+                        atomicAdd(acc + c * CELLS + iw[j] + TW, d);
+                    }
+                }
+                if (xb[j] && ya[j] && !gn[j]) {
+#pragma unroll
+                    for (int c = 0; c < CA; ++c) atomicAdd(acc + c * CELLS + ie[j], (double)(v[j][c] * wne[j]));
+                }
+                if (xb[j] && yb[j] && !gs[j]) {
+#pragma unroll
+                    for (int c = 0; c < CA; ++c) atomicAdd(acc + c * CELLS + ie[j] + TW, (double)(v[j][c] * wse[j]));
+                }
+            }
+        }
+      } else {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             fldr_pin(b.fx[u]); fldr_pin(b.fy[u]); fldr_pin(b.mv[u]);
 #pragma unroll
             for (int c = 0; c < CB; ++c) fldr_pin(b.val[u][c]);
         }
+#if defined(SA_ABLATE) && SA_ABLATE == 3                              // diagnostic: the walk's loads only
+        return;
+#endif
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if (!b.ok[u]) continue;
@@ -282,9 +411,41 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
 #endif
             }
         }
+      }
     };
     // finish and write tile (tx0, fy0): (acc / norm - 0.5) * 2, norm 0 -> 1 (softSplat.py:343-349); the cells are left zeroed
     auto finish = [&](int fy0, int cbase) __attribute__((always_inline)) {
+      if constexpr (QUAD) {
+        static_assert(!QUAD || (CB % 8 != 0 && TW % 4 == 0), "the run walk serves the image configuration (fp32 output)");
+        for (int i = tid; i < CELLS / 4; i += 256) {
+            const int xq = i % (TW / 4), yy = i / (TW / 4);
+            const int x = tx0 + 4 * xq, y = fy0 + yy;
+            const int cell = yy * TW + xq;                               // cell (4 xq + j, yy) lives at cell + j * TW / 4
+            float norm[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (MODE >= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    norm[j] = (float)acc[CB * CELLS + cell + j * (TW / 4)]; acc[CB * CELLS + cell + j * (TW / 4)] = 0.0;
+                    if (norm[j] == 0.0f) norm[j] = 1.0f;
+                }
+            }
+            float o[CB][4];
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = (float)acc[c * CELLS + cell + j * (TW / 4)];
+                    acc[c * CELLS + cell + j * (TW / 4)] = 0.0;
+                    if (MODE >= 1) v = v / norm[j];
+                    o[c][j] = (v - 0.5f) * 2.0f;
+                }
+            if (x >= W || y >= H || !on) continue;                       // (W % 4 == 0: the whole run is inside or outside)
+            const int64_t pix = (int64_t)y * W + x;
+#pragma unroll
+            for (int c = 0; c < CB; ++c)
+                if (cbase + c < C) *reinterpret_cast<float4*>(on + (int64_t)(cbase + c) * HW + pix) = make_float4(o[c][0], o[c][1], o[c][2], o[c][3]);
+        }
+      } else {
         for (int i = tid; i < CELLS; i += 256) {
             const int x = tx0 + i % TW, y = fy0 + i / TW;
             float norm = 1.0f;
@@ -324,10 +485,11 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
                 }
             }
         }
+      }
     };
 
     // units of this workgroup: (tile k, group g) in k-major order; a unit's first loads go out before the previous unit is written
-    SaBuf<CB, U> b0, b1;
+    SaBuf<CB, U, QUAD> b0, b1;
     const int n_units = K * a.gpw;
     auto begin_unit = [&](int u) __attribute__((always_inline)) {
         const int k = u / a.gpw;
@@ -364,16 +526,18 @@ int fldr_range_read_acc64(int reset) { return fldr_tu_range_read(reset); }
 #ifndef SA_FOLD_MIN_TILES
 #define SA_FOLD_MIN_TILES 512
 #endif
+static int g_sa_quad = 1;                // images: runs of four pixels per thread where the geometry allows (see the kernel); 0: one pixel per item
+FLDR_HOOK int fldr_debug_splat_quad(int v) { if (v == 0 || v == 1) g_sa_quad = v; return g_sa_quad; }
 static int g_sa_group_fold = 0;          // measured at 288x480x48, both directions: 72.6 us folded vs 67.1 (1080 workgroups on 1024 slots: a second, nearly empty round)
 FLDR_HOOK int fldr_debug_splat_group_fold(int v) { if (v == 0 || v == 1) g_sa_group_fold = v; return g_sa_group_fold; }
 
-template <int MODE, int CB, int TW, int TH, int K, int U>
+template <int MODE, int CB, int TW, int TH, int K, int U, bool QUAD = false>
 static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
     constexpr int CA = MODE >= 1 ? CB + 1 : CB;
     constexpr int LDS = CA * TW * TH * 8 + SA_Q * 4 + 16 * 4 + 16 * 4 + 2 * 4 + SA_SBQ * 2;
     static_assert(LDS <= 160 * 1024, "tile does not fit the LDS");
     static std::atomic<uint64_t> attr_done{0};
-    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&splat_acc64_kernel<MODE, CB, TW, TH, K, U>), LDS, attr_done)) return e;
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&splat_acc64_kernel<MODE, CB, TW, TH, K, U, QUAD>), LDS, attr_done)) return e;
     a.tiles_x = fldr_cdiv(a.W, TW);
     a.st_y = fldr_cdiv(a.H, K * TH);
     a.n_st = a.tiles_x * a.st_y;
@@ -381,7 +545,7 @@ static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
     if (total > (1ll << 30)) return FLDR_E_SHAPE;
     a.total = (int)total;
     a.per_xcd = (a.total + 7) / 8;
-    hipLaunchKernelGGL((splat_acc64_kernel<MODE, CB, TW, TH, K, U>), dim3(8 * a.per_xcd), dim3(256), LDS, s, a);
+    hipLaunchKernelGGL((splat_acc64_kernel<MODE, CB, TW, TH, K, U, QUAD>), dim3(8 * a.per_xcd), dim3(256), LDS, s, a);
     return 0;
 }
 
@@ -390,7 +554,18 @@ static int sa_launch2(SaArgs& a, int nprob, hipStream_t s) {
 // channels (two packed groups), 32 x 8 tiles (35 KB: four workgroups per CU), one pixel per thread in flight.
 template <int MODE>
 static int sa_launch(SaArgs& a, int nprob, hipStream_t s) {
-    if (a.C <= 3) { a.groups = 1; a.gpw = 1; return sa_launch2<MODE, 3, SA_IMG_TW, SA_IMG_TH, SA_IMG_K, SA_IMG_U>(a, nprob, s); }
+    if (a.C <= 3) {
+        a.groups = 1; a.gpw = 1;
+        // runs of four pixels per thread (16-byte accesses, in-register hand-off between neighbouring pixels) where rows and planes allow
+        bool quad = g_sa_quad && a.W % 4 == 0;
+        for (int k = 0; k < nprob && quad; ++k) {
+            const SaProblem& p = a.p[k];
+            quad = ((reinterpret_cast<uintptr_t>(p.img) | reinterpret_cast<uintptr_t>(p.flow) | reinterpret_cast<uintptr_t>(p.metric) |
+                     reinterpret_cast<uintptr_t>(p.out_f32)) & 15) == 0 && ((p.img_bstride | p.img_cstride | p.flow_bstride) & 3) == 0 && p.out_spk == nullptr;
+        }
+        if (quad) return sa_launch2<MODE, 3, SA_IMG_TW, SA_IMG_TH, SA_IMG_K, SA_IMGQ_U, true>(a, nprob, s);
+        return sa_launch2<MODE, 3, SA_IMG_TW, SA_IMG_TH, SA_IMG_K, SA_IMG_U>(a, nprob, s);
+    }
     a.groups = fldr_cdiv(a.C, 16);
     // optionally (test-build hook; off: see g_sa_group_fold) all channel groups of a tile in ONE workgroup: one candidate search, the
     // flow of a source pixel fetched by one workgroup instead of `groups`

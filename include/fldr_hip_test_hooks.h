@@ -15,6 +15,8 @@ int fldr_debug_s2_persistent(int v);                                /* tuning ho
 int fldr_debug_s2_xshift(int v);                                  /* tuning hook: left shift (output columns) of the persistent stride-2 kernel's tile grid; -1 (default): 15 on wide images */
 int fldr_debug_s2_vec4(int v);                                   /* tuning hook: 1 (default) 16-byte staging loads in the persistent stride-2 encoder where the geometry allows, 0 never; other: query.  Bit-identical results */
 int fldr_debug_dec3_xshift(int v);                                /* tuning hook: left shift (low-resolution columns) of fldr_dec3_synth's tile grid; -1 (default): 16 on wide frames */
+int fldr_debug_splat_quad(int v);                                 /* image splat walk of fldr_softsplat_acc64: 1 (default) runs of four pixels per thread where W % 4 == 0 and the planes are 16-byte aligned, 0 one pixel per item; other: query */
+int fldr_debug_dec3_xcd(int v);                                   /* tile order of fldr_dec3_synth: 1 (default) contiguous tile ranges per XCD, 0 row-major round-robin; other: query.  Identical results */
 int fldr_debug_spk_small_units(int v);                              /* tuning hook: launches of <= v units run as 16-channel sub-groups (default 96; -1: never; 0: query) */
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */

@@ -502,6 +502,51 @@ def test_acc64_softsplat_matches_oracle(hip, oracle, dev, mode, shape):
     _cmp(softSplat.FunctionSoftsplat(x.to(dev), flow.to(dev), None if z is None else z.to(dev), mode), out, atol=0.0, what="FunctionSoftsplat == acc64")
 
 
+@pytest.mark.parametrize("mode", ["summation", "average", "linear", "softmax"])
+@pytest.mark.parametrize("case", [(2, 3, 96, 200, 5.0, "smooth"), (1, 3, 70, 132, 3.0, "random"), (1, 2, 150, 260, 600.0, "random"),
+                                  (1, 3, 40, 48, 2.0, "smooth"), (1, 3, 130, 256, 40.0, "outliers")])
+def test_acc64_image_walk_of_pixel_runs(hip, hooks, oracle, dev, mode, case):
+    """The image configuration's walk by runs of four adjacent source pixels (16-byte loads, neighbouring pixels' shared corners
+    summed in registers, de-interleaved accumulator rows) against the oracle and against the one-pixel-per-item walk: smooth flows
+    (every hand-off taken), random ones (almost none), 600 px (queue overflow: rectangle / whole-map walks), maps small enough for
+    the table-free walk, and a smooth field with 1 % of the vectors thrown to +-3e9 px (block-queue walk)."""
+    N, C, H, W, amp, kind = case
+    g = _gen(77)
+    x = torch.rand(N, C, H, W, generator=g) * 2 - 1
+    if kind == "random":
+        flow = (torch.rand(N, 2, H, W, generator=g) - 0.5) * amp
+    else:
+        lo = (torch.rand(N, 2, max(H // 8, 2), max(W // 8, 2), generator=g) - 0.5) * amp + torch.tensor([amp, -amp / 2]).view(1, 2, 1, 1)
+        flow = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+        if kind == "outliers":
+            m = torch.rand(N, 1, H, W, generator=g) < 0.01
+            flow = torch.where(m, torch.where(torch.rand(N, 2, H, W, generator=g) < 0.5, torch.tensor(3.0e9), torch.tensor(-3.0e9)), flow)
+    z = torch.randn(N, 1, H, W, generator=g) if mode in ("linear", "softmax") else None
+    if mode == "linear":
+        z = z.abs() + 0.1
+    zs = None if z is None else [z.to(dev)]
+    ref = oracle.function_softsplat(x, flow, z, mode)
+    outs = {}
+    try:
+        for q in (1, 0):
+            hooks.fldr_debug_splat_quad(q)
+            outs[q] = hip.softsplat_acc64([x.to(dev)], [flow.to(dev)], zs, mode)[0]
+            _cmp(outs[q], ref, atol=3e-5, rtol=1e-5, what="acc64 %s, runs of four: %d" % (mode, q))
+    finally:
+        hooks.fldr_debug_splat_quad(1)
+    # the two walks sum the same fp32 products in fp64: equal up to a rounding boundary of the fp32 output (one ulp, rarely)
+    d = (outs[0] - outs[1]).abs()
+    assert float(d.max()) <= (2.5e-7 if mode != "summation" else 1e-5) and float((d > 0).float().mean()) < 1e-3
+    # views with batch / channel strides (the frames of the model), two problems in one launch
+    if C == 3:
+        fr = torch.stack([x, x.flip(1)], 2).to(dev)                       # [N,3,2,H,W]
+        fl2 = [flow.to(dev), (-flow).to(dev)]
+        zz = None if z is None else [z.to(dev), z.to(dev)]
+        a0, a1 = hip.softsplat_acc64([fr[:, :, 0], fr[:, :, 1]], fl2, zz, mode)
+        assert float((a0 - outs[1]).abs().max()) <= (2.5e-7 if mode != "summation" else 1e-5)
+        _cmp(a1, oracle.function_softsplat(x.flip(1), -flow, z, mode), atol=3e-5, rtol=1e-5, what="acc64 strided pair, second problem")
+
+
 @pytest.mark.parametrize("mode", ["summation", "average", "softmax"])
 @pytest.mark.parametrize("shape", [(2, 48, 33, 70, 3.0, "smooth"), (1, 48, 36, 60, 9.0, "random"), (1, 13, 40, 130, 80.0, "random"),
                                    (1, 48, 72, 120, 30.0, "smooth"), (1, 48, 9, 15, 2.0, "smooth")])

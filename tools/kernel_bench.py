@@ -87,6 +87,13 @@ def dec3():
         L.fldr_debug_dec3_xshift(xs)
         print("x shift %2d: %.1f us" % (xs, timeit(lambda i: hip.dec3_synth(sets[i % 2][0], wt, bs, sets[i % 2][1], t, 1.5616), 16)), flush=True)
     L.fldr_debug_dec3_xshift(-1)
+    outs = {}
+    for xc in (0, 1, 0, 1):
+        L.fldr_debug_dec3_xcd(xc)
+        print("tile order %s: %.1f us" % ("XCD-contiguous" if xc else "row-major     ", timeit(lambda i: hip.dec3_synth(sets[i % 2][0], wt, bs, sets[i % 2][1], t, 1.5616), 16)), flush=True)
+        outs[xc] = hip.dec3_synth(sets[0][0], wt, bs, sets[0][1], t, 1.5616)
+    print("identical:", bool(torch.equal(outs[0], outs[1])))
+    L.fldr_debug_dec3_xcd(1)
 
 
 def pca():
