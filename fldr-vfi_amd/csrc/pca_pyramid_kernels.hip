@@ -41,6 +41,8 @@ struct PcapLevel {
     int32_t wg_start;                 // first workgroup of the level in the launch
     int64_t nblocks;                  // P * (H/8) * (W/8)
     int32_t item_start;               // matrix-core kernel: first 32-block item of the level
+    int32_t wg_start_b, wg_start_r;   // first item of the level in the emit pass (levels with `raw` have none there) / in the rescale launch (the others have none)
+    double* raw;                      // nblocks * K doubles or null: pass A parks the un-normalised projections here and a streaming launch rescales them
 };
 struct PcapArgs {
     PcapLevel lv[PCAP_MAX_LEVELS];
@@ -194,17 +196,24 @@ __device__ __forceinline__ void pcap_project(const float (&x)[64], const double*
 }
 
 // Work item = 256 consecutive blocks of one level (one block per thread); items are numbered level by level.
-struct PcapWhere { int level; bool live; int p; int64_t pix, BHW; const float* src; int W; };
+struct PcapWhere { int level; bool live; int p; int64_t pix, BHW, b, nb; const float* src; int W; double* raw; };   // b: block index in the level (0 for a dead lane) of nb
 
+// WHICH: the item numbering — 0 pass A (every level), 1 emit pass (levels without parked projections), 2 rescale launch (levels with).
+// A level without items in a numbering starts where the next one does and is never selected.
+template <int WHICH>
 __device__ __forceinline__ PcapWhere pcap_locate(const PcapArgs& a, int item) {
     PcapWhere w;
+    auto start_of = [&](int l) { return WHICH == 0 ? a.lv[l].wg_start : (WHICH == 1 ? a.lv[l].wg_start_b : a.lv[l].wg_start_r); };
     w.level = 0;
+    int start = start_of(0);
+    w.raw = a.lv[0].raw;
 #pragma unroll
     for (int l = 1; l < PCAP_MAX_LEVELS; ++l)
-        if (l < a.n_levels && item >= a.lv[l].wg_start) w.level = l;  // workgroup-uniform
+        if (l < a.n_levels && item >= start_of(l)) { w.level = l; start = start_of(l); w.raw = a.lv[l].raw; }   // workgroup-uniform
     const PcapLevel& L = a.lv[w.level];
-    const int64_t b = (int64_t)(item - L.wg_start) * 256 + threadIdx.x;
+    const int64_t b = (int64_t)(item - start) * 256 + threadIdx.x;
     w.live = b < L.nblocks;
+    w.b = w.live ? b : 0; w.nb = L.nblocks;
     const int BW = L.W >> 3;
     w.BHW = (int64_t)(L.H >> 3) * BW;
     const int64_t bb = w.live ? b : 0;                                  // dead lanes read block 0 of the level
@@ -216,55 +225,12 @@ __device__ __forceinline__ PcapWhere pcap_locate(const PcapArgs& a, int item) {
     return w;
 }
 
-// Both passes as ONE persistent, double-buffered loop: a workgroup walks the items blockIdx.x, + gridDim.x, ... and the 16
-// row loads of item i+1 are in flight while item i's ~1,200 fp64 operations run.  (One block per thread without the
-// prefetch ran as lock-stepped generations — every resident wave loading, then every wave computing — and reached
-// 107 us for the level-0 min/max pass against 58 us of arithmetic and 37 us of cold HBM read measured separately.)
-//   EMIT = false: pass A, min / max per level (flushed with one hardware atomic pair whenever the level changes);
-//   EMIT = true : pass B, recompute (same code => same bits), rescale, emit fp32 NCHW and / or the split-packed twin.
-template <int K, bool EMIT>
-__global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* __restrict__ table, int total_items) {
+// Rescale and emit one block's K projections (pca_comp.py:523-526, fLDRnet.py:146): fp32 NCHW and / or the split-packed twin.
+template <int K>
+__device__ __forceinline__ void pcap_emit(const PcapArgs& a, const PcapWhere& w, const double (&y)[K]) {
 #pragma clang fp contract(off)
-    __shared__ double slo[4], shi[4];
-    float xa[64], xb[64];
-    double lo = 1.0e300, hi = -1.0e300;
-    int cur_level = -1;
-
-    auto flush = [&]() {                                                // workgroup-uniform call sites only
-        if (cur_level < 0) return;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {                        // wave64 shuffle reduction
-            const double ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
-            lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
-        }
-        __syncthreads();                                                // slo / shi of the previous flush have been read
-        if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int i = 1; i < 4; ++i) { lo = slo[i] < lo ? slo[i] : lo; hi = shi[i] > hi ? shi[i] : hi; }
-            pcap_atomic_min(a.mm + PCAP_MM * 2 * cur_level, lo);
-            pcap_atomic_max(a.mm + PCAP_MM * (2 * cur_level + 1), hi);
-        }
-        lo = 1.0e300; hi = -1.0e300;
-    };
-
-    auto process = [&](const PcapWhere& w, const float (&x)[64]) {
-        double y[K];
-        // The table pointer is laundered once per block: its 1,100 scalar loads are loop-invariant, and hoisted out of the
-        // item loop they would need ~2,200 SGPRs (observed: thousands of spills).
-#if defined(PCAP_ABLATE) && PCAP_ABLATE == 2                           // diagnostic: no projection arithmetic
-        for (int k = 0; k < K; ++k) y[k] = (double)(x[k] + x[k + 16] + x[k + 32] + x[k + 48]);
-#else
-        pcap_project<K>(x, table, y);
-#endif
-        if constexpr (!EMIT) {
-            if (w.level != cur_level) { flush(); cur_level = w.level; }
-            if (w.live) {
-#pragma unroll
-                for (int k = 0; k < K; ++k) { lo = y[k] < lo ? y[k] : lo; hi = y[k] > hi ? y[k] : hi; }
-            }
-        } else {
-            if (!w.live) return;
+    {
+        {
             const PcapLevel& L = a.lv[w.level];
             const double mi = a.mm[PCAP_MM * 2 * w.level], range = a.mm[PCAP_MM * (2 * w.level + 1)] - mi;
             const double rr = 1.0 / range;                               // one true division per block; K Markstein quotients
@@ -317,6 +283,66 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
                 }
             }
         }
+    }
+}
+
+// Both passes as ONE persistent, double-buffered loop: a workgroup walks the items blockIdx.x, + gridDim.x, ... and the 16
+// row loads of item i+1 are in flight while item i's ~1,200 fp64 operations run.  (One block per thread without the
+// prefetch ran as lock-stepped generations — every resident wave loading, then every wave computing — and reached
+// 107 us for the level-0 min/max pass against 58 us of arithmetic and 37 us of cold HBM read measured separately.)
+//   EMIT = false: pass A, min / max per level (flushed with one hardware atomic pair whenever the level changes);
+//   EMIT = true : pass B, recompute (same code => same bits), rescale, emit fp32 NCHW and / or the split-packed twin.
+template <int K, bool EMIT>
+__global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* __restrict__ table, int total_items) {
+#pragma clang fp contract(off)
+    __shared__ double slo[4], shi[4];
+    float xa[64], xb[64];
+    double lo = 1.0e300, hi = -1.0e300;
+    int cur_level = -1;
+
+    auto flush = [&]() {                                                // workgroup-uniform call sites only
+        if (cur_level < 0) return;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {                        // wave64 shuffle reduction
+            const double ol = __shfl_xor(lo, off), oh = __shfl_xor(hi, off);
+            lo = ol < lo ? ol : lo; hi = oh > hi ? oh : hi;
+        }
+        __syncthreads();                                                // slo / shi of the previous flush have been read
+        if ((threadIdx.x & 63) == 0) { slo[threadIdx.x >> 6] = lo; shi[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < 4; ++i) { lo = slo[i] < lo ? slo[i] : lo; hi = shi[i] > hi ? shi[i] : hi; }
+            pcap_atomic_min(a.mm + PCAP_MM * 2 * cur_level, lo);
+            pcap_atomic_max(a.mm + PCAP_MM * (2 * cur_level + 1), hi);
+        }
+        lo = 1.0e300; hi = -1.0e300;
+    };
+
+    auto process = [&](const PcapWhere& w, const float (&x)[64]) {
+        double y[K];
+        // The table pointer is laundered once per block: its 1,100 scalar loads are loop-invariant, and hoisted out of the
+        // item loop they would need ~2,200 SGPRs (observed: thousands of spills).
+#if defined(PCAP_ABLATE) && PCAP_ABLATE == 2                           // diagnostic: no projection arithmetic
+        for (int k = 0; k < K; ++k) y[k] = (double)(x[k] + x[k + 16] + x[k + 32] + x[k + 48]);
+#else
+        pcap_project<K>(x, table, y);
+#endif
+        if constexpr (!EMIT) {
+            if (w.level != cur_level) { flush(); cur_level = w.level; }
+            if (w.live) {
+#pragma unroll
+                for (int k = 0; k < K; ++k) { lo = y[k] < lo ? y[k] : lo; hi = y[k] > hi ? y[k] : hi; }
+                // One read of the frames (w.raw, workgroup-uniform): y[] is parked and pcap_rescale_kernel streams it back instead of
+                // 256 bytes of pixels + 64 K FMAs per block.
+                if (w.raw != nullptr) {                                  // component-major: the lanes of a store write consecutive doubles
+#pragma unroll
+                    for (int k = 0; k < K; ++k) w.raw[(int64_t)k * w.nb + w.b] = y[k];
+                }
+            }
+        } else {
+            if (!w.live) return;
+            pcap_emit<K>(a, w, y);
+        }
     };
 
     const int stride = gridDim.x;
@@ -325,23 +351,37 @@ __global__ __launch_bounds__(256, 2) void pcap_kernel(PcapArgs a, const double* 
     // Pass B walks the items in the opposite direction: what pass A read LAST is still in the Infinity Cache (the 267 MB of a
     // 4K pyramid exceed its 256 MB, so a second scan in the same direction would miss everywhere).
     auto phys = [&](int i) { return (EMIT && PCAP_REVERSE) ? total_items - 1 - i : i; };
-    PcapWhere wa = pcap_locate(a, phys(item)), wb = wa;
+    PcapWhere wa = pcap_locate<EMIT ? 1 : 0>(a, phys(item)), wb = wa;
     pcap_load(wa.src, wa.W, xa);
     while (true) {
         int next = item + stride;                                        // workgroup-uniform control flow throughout
-        if (next < total_items) { wb = pcap_locate(a, phys(next)); pcap_load(wb.src, wb.W, xb); }
+        if (next < total_items) { wb = pcap_locate<EMIT ? 1 : 0>(a, phys(next)); pcap_load(wb.src, wb.W, xb); }
         __builtin_amdgcn_sched_barrier(0);                               // the prefetch is issued before the arithmetic below
         process(wa, xa);
         if (next >= total_items) break;
         item = next;
         next = item + stride;
-        if (next < total_items) { wa = pcap_locate(a, phys(next)); pcap_load(wa.src, wa.W, xa); }
+        if (next < total_items) { wa = pcap_locate<EMIT ? 1 : 0>(a, phys(next)); pcap_load(wa.src, wa.W, xa); }
         __builtin_amdgcn_sched_barrier(0);
         process(wb, xb);
         if (next >= total_items) break;
         item = next;
     }
     if constexpr (!EMIT) flush();
+}
+
+// The emit pass of the levels whose projections pass A parked (PcapLevel::raw, K planes of nblocks doubles): a streaming kernel — K
+// doubles in, fp32 / split-packed out, no arithmetic beyond the rescale.  One block per thread,
+// one 256-block item per workgroup, the items in REVERSE order (the tail of what pass A wrote is still in the Infinity Cache).
+template <int K>
+__global__ __launch_bounds__(256) void pcap_rescale_kernel(PcapArgs a, int total_items) {
+#pragma clang fp contract(off)
+    const PcapWhere w = pcap_locate<2>(a, total_items - 1 - (int)blockIdx.x);
+    if (!w.live) return;
+    double y[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) y[k] = w.raw[(int64_t)k * w.nb + w.b];
+    pcap_emit<K>(a, w, y);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -559,18 +599,23 @@ static int g_pcap_wgs = 512;                      // persistent workgroups (2 pe
 FLDR_HOOK int fldr_debug_pca_workgroups(int v) { if (v > 0) g_pcap_wgs = v; return g_pcap_wgs; }
 
 template <int K>
-static void pcap_launch(const PcapArgs& a, int total_items, hipStream_t s) {
+static void pcap_launch(const PcapArgs& a, int total_items, int items_emit, int items_rescale, hipStream_t s) {
     const int grid = total_items < g_pcap_wgs ? total_items : g_pcap_wgs;
     hipLaunchKernelGGL(pcap_init_kernel, dim3(1), dim3(64), 0, s, a.mm, a.n_levels);
     hipLaunchKernelGGL((pcap_kernel<K, false>), dim3(grid), dim3(256), 0, s, a, a.table, total_items);
-    hipLaunchKernelGGL((pcap_kernel<K, true>), dim3(grid), dim3(256), 0, s, a, a.table, total_items);
+    // the levels with parked projections first: the streaming rescale starts on what pass A wrote last
+    if (items_rescale > 0) hipLaunchKernelGGL((pcap_rescale_kernel<K>), dim3(items_rescale), dim3(256), 0, s, a, items_rescale);
+    if (items_emit > 0) {
+        const int grid_b = items_emit < g_pcap_wgs ? items_emit : g_pcap_wgs;
+        hipLaunchKernelGGL((pcap_kernel<K, true>), dim3(grid_b), dim3(256), 0, s, a, a.table, items_emit);
+    }
 }
 
 extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K,
                                         double* minmax_ws, fldr_stream_t stream) {
     FLDR_CHECK_ARG(levels && table && minmax_ws && n_levels >= 1 && n_levels <= PCAP_MAX_LEVELS);
     PcapArgs a;
-    int64_t wg = 0, items = 0;
+    int64_t wg = 0, items = 0, wg_b = 0, wg_r = 0;
     bool mfma_ok = true;
     for (int l = 0; l < n_levels; ++l) {
         const fldr_pca_level& in = levels[l];
@@ -584,11 +629,19 @@ extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_leve
         L.wg_start = (int)wg;
         wg += (L.nblocks + 255) / 256;
         if (wg >= (1ll << 30)) return FLDR_E_SHAPE;
+        // (the matrix-core variant recomputes everywhere)
+        L.raw = (K == 16 && g_pcap_variant == 1) ? nullptr : in.raw_ws;
+        if (((uintptr_t)in.raw_ws & 15) != 0) return FLDR_E_ARG;
+        L.wg_start_b = (int)wg_b; L.wg_start_r = (int)wg_r;
+        (L.raw ? wg_r : wg_b) += (L.nblocks + 255) / 256;
         L.item_start = (int)items;
         items += (L.nblocks + 31) / 32;
         if (L.nblocks + 32 >= (1ll << 31) || items >= (1ll << 30)) mfma_ok = false;
     }
-    for (int l = n_levels; l < PCAP_MAX_LEVELS; ++l) { a.lv[l] = a.lv[0]; a.lv[l].wg_start = 0x7fffffff; a.lv[l].item_start = 0x7fffffff; a.lv[l].nblocks = 0; }
+    for (int l = n_levels; l < PCAP_MAX_LEVELS; ++l) {
+        a.lv[l] = a.lv[0];
+        a.lv[l].wg_start = a.lv[l].wg_start_b = a.lv[l].wg_start_r = 0x7fffffff; a.lv[l].item_start = 0x7fffffff; a.lv[l].nblocks = 0;
+    }
     a.table = table; a.mm = minmax_ws; a.n_levels = n_levels;
     hipStream_t s = fldr_s(stream);
     if (K == 16 && g_pcap_variant == 1 && mfma_ok) {
@@ -600,9 +653,9 @@ extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_leve
         FLDR_LAUNCH_RET();
     }
     switch (K) {
-        case 16: pcap_launch<16>(a, (int)wg, s); break;
-        case 8:  pcap_launch<8>(a, (int)wg, s); break;
-        case 4:  pcap_launch<4>(a, (int)wg, s); break;
+        case 16: pcap_launch<16>(a, (int)wg, (int)wg_b, (int)wg_r, s); break;
+        case 8:  pcap_launch<8>(a, (int)wg, (int)wg_b, (int)wg_r, s); break;
+        case 4:  pcap_launch<4>(a, (int)wg, (int)wg_b, (int)wg_r, s); break;
         default: return FLDR_E_ARG;
     }
     FLDR_LAUNCH_RET();

@@ -526,7 +526,10 @@ int fldr_range_read_acc64(int reset) { return fldr_tu_range_read(reset); }
 #ifndef SA_FOLD_MIN_TILES
 #define SA_FOLD_MIN_TILES 512
 #endif
-static int g_sa_quad = 1;                // images: runs of four pixels per thread where the geometry allows (see the kernel); 0: one pixel per item
+#ifndef SA_QUAD_DEFAULT
+#define SA_QUAD_DEFAULT 1
+#endif
+static int g_sa_quad = SA_QUAD_DEFAULT;                // images: runs of four pixels per thread where the geometry allows (see the kernel); 0: one pixel per item
 FLDR_HOOK int fldr_debug_splat_quad(int v) { if (v == 0 || v == 1) g_sa_quad = v; return g_sa_quad; }
 static int g_sa_group_fold = 0;          // measured at 288x480x48, both directions: 72.6 us folded vs 67.1 (1080 workgroups on 1024 slots: a second, nearly empty round)
 FLDR_HOOK int fldr_debug_splat_group_fold(int v) { if (v == 0 || v == 1) g_sa_group_fold = v; return g_sa_group_fold; }

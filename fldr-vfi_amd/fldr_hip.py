@@ -54,7 +54,8 @@ class PrepDesc(ctypes.Structure):
 
 class PcaLevel(ctypes.Structure):
     _fields_ = [("planes", ctypes.c_void_p), ("out_f32", ctypes.c_void_p), ("out_spk", ctypes.c_void_p),
-                ("P", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("P", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("raw_ws", ctypes.c_void_p)]
 
 
 class SplatGatherDesc(ctypes.Structure):
@@ -644,7 +645,10 @@ def pca_table(ev, mean, meanvec):
     return tab
 
 
-def pca_project_pyramid(planes_list, ev, mean, meanvec, want_f32=True, want_spk=False):
+PCA_RAW_MIN_BYTES = int(os.environ.get("FLDR_PCA_RAW_MIN_BYTES", "0"))      # levels of at least this many projection bytes are parked between the two passes (4K pyramid: 196.9 us none, 186.7 from 4 MB, 168.4 all)
+
+
+def pca_project_pyramid(planes_list, ev, mean, meanvec, want_f32=True, want_spk=False, raw_min_bytes=None):
     """to_pca_diff(...).float() of every pyramid level in two launches (fLDRnet.py:133-146).  planes_list: [P,H_l,W_l]
     fp32 tensors.  -> (list of fp32 [P*K,h,w] or None, list of Spk [1,P*K,h,w] or None, minmax [n_levels,2])."""
     ev = ev.detach()
@@ -667,6 +671,11 @@ def pca_project_pyramid(planes_list, ev, mean, meanvec, want_f32=True, want_spk=
         arr[i].out_f32 = o32.data_ptr() if o32 is not None else None
         arr[i].out_spk = osp.buf.data_ptr() if osp is not None else None
         arr[i].P, arr[i].H, arr[i].W = P, H, W
+        nb = P * (H // 8) * (W // 8)
+        if nb * K * 8 >= (PCA_RAW_MIN_BYTES if raw_min_bytes is None else raw_min_bytes):        # one read of the frames: the projections parked as fp64 between the passes (default: every level)
+            raw = torch.empty(nb * K, device=pl.device, dtype=torch.float64)
+            keep.append(raw)
+            arr[i].raw_ws = raw.data_ptr()
     mm = torch.empty(n, 32, device=planes_list[0].device, dtype=torch.float64)      # each bound on a 128-byte line of its own
     _check(lib().fldr_pca_project_pyramid(arr, n, _dev(tab, "table", torch.float64), K, _dev(mm, "minmax", torch.float64), _stream()),
            "fldr_pca_project_pyramid")

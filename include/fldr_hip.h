@@ -205,6 +205,9 @@ typedef struct fldr_pca_level {
     float*       out_f32;      /* [P*K, H/8, W/8] or NULL */
     void*        out_spk;      /* packed [1, P*K, H/8, W/8] (fldr_spk_bytes) or NULL */
     int32_t      P, H, W, reserved;
+    double*      raw_ws;       /* P * (H/8) * (W/8) * K doubles of scratch (16-byte aligned) or NULL.  Given: the first pass parks the level's
+                                  un-normalised projections there and the second rescales them instead of reading the planes again and
+                                  recomputing (worth it on the big levels: 128 bytes per block instead of 256 + 64 K fp64 FMAs); same bits */
 } fldr_pca_level;
 int64_t fldr_pca_table_size(int K);
 int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K, fldr_stream_t stream);

@@ -215,6 +215,12 @@ def test_pca_pyramid_bit_identical_to_per_level(hip, dev, model, K, hooks):
         assert torch.equal(spk.buf, osp[i].buf), i
     only_spk = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=False, want_spk=True)[1]
     assert all(torch.equal(a.buf, b.buf) for a, b in zip(only_spk, osp))
+    # one read of the frames: the first pass parks the un-normalised projections of the big levels as fp64 and a streaming launch
+    # rescales them (every level / the levels above a size / none): the same bits
+    for raw_min in (0, P * (32 // 8) * (48 // 8) * K * 8 + 1, 1 << 40):
+        r32, rsp, rmm = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=True, want_spk=True, raw_min_bytes=raw_min)
+        assert torch.equal(rmm, mm)
+        assert all(torch.equal(a, b) for a, b in zip(r32, o32)) and all(torch.equal(a.buf, b.buf) for a, b in zip(rsp, osp)), raw_min
 
 
 def test_pca_pyramid_matrix_core_kernel(hip, oracle, dev, model, hooks):

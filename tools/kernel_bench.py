@@ -104,6 +104,8 @@ def pca():
     print("pyramid, rotating inputs: per-level %.1f us, pyramid kernels %.1f us" % (
         timeit(lambda i: [hip.pca_project_stream(p, ev, mean, mv, want_spk=True) for p in pyrs[i % 3]]),
         timeit(lambda i: hip.pca_project_pyramid(pyrs[i % 3], ev, mean, mv, want_f32=True, want_spk=True))))
+    for rm, what in ((1 << 40, "recompute in pass B          "), (4 << 20, "projections parked >= 4 MB   "), (0, "projections parked, all levels")):
+        print("pyramid, %s: %.1f us" % (what, timeit(lambda i: hip.pca_project_pyramid(pyrs[i % 3], ev, mean, mv, want_f32=True, want_spk=True, raw_min_bytes=rm))), flush=True)
     print("level 0 only            : per-level %.1f us, pyramid kernels %.1f us" % (
         timeit(lambda i: hip.pca_project_stream(pyrs[i % 3][0], ev, mean, mv, want_spk=True)),
         timeit(lambda i: hip.pca_project_pyramid(pyrs[i % 3][:1], ev, mean, mv, want_f32=True, want_spk=True))))
