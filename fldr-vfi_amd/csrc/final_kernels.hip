@@ -87,8 +87,12 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
 #pragma unroll
     for (int c = 0; c < D3_CIN; ++c) {
         const char* base = reinterpret_cast<const char*>(src + c * hw);          // uniform
+#if defined(DEC3_ABLATE) && (DEC3_ABLATE & 1)                         // diagnostic: no reads of dec2's output
+        st[c][0] = 0.25f; st[c][1] = 0.5f; (void)base;
+#else
         st[c][0] = *reinterpret_cast<const float*>(base + goff[0]);
         st[c][1] = *reinterpret_cast<const float*>(base + goff[1]);
+#endif
     }
 #pragma unroll
     for (int c = 0; c < D3_CIN; ++c) {
@@ -114,7 +118,9 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
             for (int ch = 0; ch < 3; ++ch)
                 {
                     const float2* cp = reinterpret_cast<const float2*>(reinterpret_cast<const char*>(cd.cand[k] + (int64_t)n * cd.bstride[k] + (int64_t)ch * cd.cstride[k]) + pob);
-#if defined(DEC3_NT) && (DEC3_NT & 1)
+#if defined(DEC3_ABLATE) && (DEC3_ABLATE & 2)                         // diagnostic: no candidate reads
+                    cv[a][k][ch] = make_float2(0.1f * k, 0.2f * ch); (void)cp;
+#elif defined(DEC3_NT) && (DEC3_NT & 1)
                     typedef float d3_f2 __attribute__((ext_vector_type(2)));
                     const d3_f2 t2 = __builtin_nontemporal_load(reinterpret_cast<const d3_f2*>(cp));          // read once: streaming hint
                     cv[a][k][ch] = make_float2(t2[0], t2[1]);
@@ -185,7 +191,11 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
             for (int k = 0; k < 6; ++k) { s[k] = (double)acc[ph][k] * inv_T; mx = s[k] > mx ? s[k] : mx; }
             double sum = 0.0;
 #pragma unroll
+#if defined(DEC3_ABLATE) && (DEC3_ABLATE & 4)                         // diagnostic: no exponentials
+                        for (int k = 0; k < 6; ++k) { s[k] = s[k] - mx + 2.0; sum += s[k]; }
+#else
                         for (int k = 0; k < 6; ++k) { s[k] = exp(s[k] - mx); sum += s[k]; }
+#endif
             const double inv_sum = 1.0 / sum;
             double wo[6];
 #pragma unroll

@@ -126,9 +126,11 @@ def interpolate(model, args, frames, t_value, pyramid=None):
     return pred[:, :, :OH, :OW]
 
 
-def interpolate_multi(model, args, frames, t_values, pyramid=None):
+def interpolate_multi(model, args, frames, t_values, pyramid=None, streams=None):
     """All outputs of one pair (e.g. t = 1/8 ... 7/8 for the 8x X-Test / Inter4K protocol, main.py:833-867) with the
-    pair-invariant stage (PCA features, six flow levels, splat metrics) computed once.  Returns a list of frames."""
+    pair-invariant stage (PCA features, six flow levels, splat metrics) computed once.  Returns a list of frames.
+    streams: optional list of torch.cuda.Stream — the first output (which fills the cache) runs on the current stream, the
+    others, independent of each other from there on, are dealt round-robin to `streams` and joined before returning."""
     B, C, T, OH, OW = frames.shape
     prev = model.pair_cache
     model.pair_cache = True
@@ -137,10 +139,27 @@ def interpolate_multi(model, args, frames, t_values, pyramid=None):
             if pyramid is None:
                 pyramid = build_pyramid(pad_frames(frames, args), args)
             outs = []
-            for tv in t_values:
+
+            def one(tv):
                 t = torch.full((B, 1), float(tv), device=frames.device, dtype=torch.float32)
                 pred, _ = model([None] * (args.S_tst + 1), t, normInput=pyramid, is_training=False, validation=False)
-                outs.append(pred[:, :, :OH, :OW])
+                return pred[:, :, :OH, :OW]
+            if not streams or len(t_values) < 2:
+                outs = [one(tv) for tv in t_values]
+            else:
+                cur = torch.cuda.current_stream()
+                outs.append(one(t_values[0]))
+                ready = torch.cuda.Event()
+                ready.record(cur)
+                for i, tv in enumerate(t_values[1:]):
+                    st = streams[i % len(streams)]
+                    st.wait_event(ready)
+                    with torch.cuda.stream(st):
+                        outs.append(one(tv))
+                for st in streams:                                       # the caller's stream owns every output from here on
+                    cur.wait_stream(st)
+                for o in outs[1:]:
+                    o.record_stream(cur)
     finally:
         model.pair_cache = prev
         model._pair_state = None

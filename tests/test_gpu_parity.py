@@ -1070,6 +1070,13 @@ def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
             with torch.no_grad():
                 ref = oracle.forward(weights, pyr, t)[:, :, :256, :384]
             _cmp(c, ref, atol=1e-4, what="cached vs oracle t=%g" % tv)
+    # the later outputs of a pair are independent once the cache is filled: dealt to side streams, the same frames (same cache: same bits)
+    side = [torch.cuda.Stream(device=dev) for _ in range(3)]
+    par = Hn.interpolate_multi(m, a, frames, ts, streams=side)
+    torch.cuda.synchronize()
+    for tv, c, q in zip(ts, cached, par):
+        err = _cmp(q, c, atol=2e-5, max_outlier_frac=5e-3, what="side streams vs one stream t=%g" % tv)
+        assert err < 5e-3, err
     # deterministic mode (gather splat for the feature maps): cached and uncached outputs are the same bits
     prev = hip.SPLAT_FEATURES
     try:
@@ -1077,6 +1084,9 @@ def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
         det = Hn.interpolate_multi(m, a, frames, [0.5, 0.875])
         for tv, c in zip([0.5, 0.875], det):
             assert torch.equal(c, Hn.interpolate(m, a, frames, torch.tensor([[tv]], device=dev))), tv
+        det_s = Hn.interpolate_multi(m, a, frames, [0.5, 0.875, 0.25], streams=side)
+        torch.cuda.synchronize()
+        assert torch.equal(det_s[0], det[0]) and torch.equal(det_s[1], det[1])
     finally:
         hip.SPLAT_FEATURES = prev
     # a different pair must not hit the cache
