@@ -45,14 +45,35 @@ struct FinalArgs {
 
 struct D3Grid { int tiles_x, per_sample, total, per_xcd; };
 
-template <typename OUT>
-__global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict__ d2, const float* __restrict__ weff,
+// MF (round 3): the phase convolutions on the fp16 MATRIX cores with the 3 x fp16 split of the 3x3 convolutions (x = hi + lo,
+// hi*hi + hi*lo + lo*hi, fp32 accumulation), reading dec2's SPLIT-PACKED output.  6 of 16 matrix rows are useful and every
+// product is issued three times — and it is still the better deal: 96 v_mfma_f32_16x16x32_f16 per wave and tile (1,536 cycles of
+// a pipe that was idle) replace 768 packed fp32 FMAs + 144 LDS reads on the vector ALUs (~3,600 cycles of the pipe the fp64
+// tail needs); ablation of the vector kernel at 4K: 163 of its 237 us are arithmetic.  Per phase (a, b): D[co][pixel] +=
+// A[co][k] * B[k][pixel], k = (tap (dy2, dx2), channel of an 8-channel group): an A operand is a 1-KB block of the prepacked
+// table (fldr_dec3_prepack_spk: [phase][group][hi, lo][lane][8 halves], rows 6 .. 15 zero), a B operand one 16-byte LDS read of
+// the packed tile (lane group = tap: the pixel at row + a + dy2, column + b + dx2).  The tile and the table arrive by LDS-DMA;
+// the logits go back through the LDS to the thread-per-pixel layout of the fp64 tail, which is unchanged.
+#define D3M_PLANE 5632                 // (TH + 2) x (TW + 2) pixels of 16 bytes, padded to 1-KB DMA pieces with an overlapping last one
+#define D3M_TABLE (4 * 2 * 2 * 1024)   // A operands
+#define D3M_HDR 16                     // floats before the table: {1 / scale, scale, max |w|, 0 ...}; floats 4 .. 7 are the DMA's zero block
+typedef _Float16 d3_h8 __attribute__((ext_vector_type(8)));
+typedef float d3_f4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) const void* d3_gptr_t;
+typedef __attribute__((address_space(3))) void* d3_lptr_t;
+
+template <typename OUT, bool MF>
+__global__ __launch_bounds__(256) void dec3_synth_kernel(const void* __restrict__ d2v, const float* __restrict__ weff,
                                                          const float* __restrict__ bias, FinalArgs cd,
                                                          const float* __restrict__ tv, double T, OUT* __restrict__ out,
                                                          float* __restrict__ refine_dbg, int H, int W, int xs, D3Grid gr) {
     // xs: the tile grid starts xs low-resolution columns left of the image (fldr_dec3_synth_strided)
     const int h = H >> 1, w = W >> 1;
-    __shared__ float tile[D3_CIN][D3_TH + 2][D3_TW + 2];
+    constexpr int LOGITS_BYTES = D3_COUT * D3_TH * D3_TW * 4;                // one phase: [co][pixel]
+    constexpr int SMEM = MF ? 4 * D3M_PLANE + LOGITS_BYTES + D3M_TABLE : D3_CIN * (D3_TH + 2) * (D3_TW + 2) * 4;
+    __shared__ __attribute__((aligned(1024))) unsigned char d3_smem[SMEM];
+    float (*tile)[D3_TH + 2][D3_TW + 2] = reinterpret_cast<float (*)[D3_TH + 2][D3_TW + 2]>(d3_smem);
+    const float* d2 = static_cast<const float*>(d2v);
     const int tid = threadIdx.x, tx = tid % D3_TW, ty = tid / D3_TW;
     // Tiles are dealt to the XCDs in contiguous row-major ranges (workgroup b runs on XCD b & 7): horizontally adjacent tiles
     // share the 128-byte lines that hold their halo columns of dec2's output, and then find them in the same L2 instead
@@ -62,8 +83,31 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     const int n = lin / gr.per_sample, trem = lin - n * gr.per_sample;
     const int tyi = trem / gr.tiles_x;
     const int i0 = tyi * D3_TH, j0 = (trem - tyi * gr.tiles_x) * D3_TW - xs;
-    const float* src = d2 + (int64_t)n * D3_CIN * h * w;
     constexpr int TILE_E = (D3_TH + 2) * (D3_TW + 2);
+    if constexpr (MF) {
+        // ---- the packed tile (4 planes: group 0 hi / lo, group 1 hi / lo) and the A table by LDS-DMA; pixels outside the image
+        //      come from the zero block.  A DMA instruction fills 64 consecutive 16-byte slots. ----
+        const int lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const unsigned char* tab = reinterpret_cast<const unsigned char*>(weff);
+        const unsigned char* zero = tab + 16;
+        const int64_t plane_b = (int64_t)h * w * 16;
+        const unsigned char* pk = static_cast<const unsigned char*>(d2v) + (int64_t)n * 4 * plane_b + (int64_t)wv * plane_b;   // wave wv stages plane wv
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int piece = i * 64 < D3M_PLANE / 16 - 64 ? i * 64 : D3M_PLANE / 16 - 64;
+            const int e = piece + lane;
+            const int gy = i0 - 1 + e / (D3_TW + 2), gx = j0 - 1 + e % (D3_TW + 2);
+            const bool ok = e < TILE_E && gy >= 0 && gy < h && gx >= 0 && gx < w;
+            const unsigned char* g = ok ? pk + ((int64_t)gy * w + gx) * 16 : zero;
+            __builtin_amdgcn_global_load_lds((d3_gptr_t)g, (d3_lptr_t)(d3_smem + wv * D3M_PLANE + piece * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < D3M_TABLE / 1024 / 4; ++i)
+            __builtin_amdgcn_global_load_lds((d3_gptr_t)(tab + D3M_HDR * 4 + ((i * 4 + wv) * 64 + lane) * 16),
+                                             (d3_lptr_t)(d3_smem + SMEM - D3M_TABLE + (i * 4 + wv) * 1024), 16, 0, 0);
+    } else {
+    const float* src = d2 + (int64_t)n * D3_CIN * h * w;
     // Staging: this thread's (up to two) slots of a channel's (TH+2) x (TW+2) tile are the same for all 16 channels, so the
     // index arithmetic is done once and every load is a scalar channel base + a precomputed 32-bit lane offset (the kernel
     // is bound by its vector-ALU instruction count: the flat element -> (channel, row, column) decode per load cost
@@ -102,6 +146,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
         if (lidx[1] >= 0) tc[lidx[1]] = inb[1] ? st[c][1] : 0.0f;
     }
     __syncthreads();
+    }
 
     // Candidate pixels of this thread's 2x2 output quad: row a = 0 is requested BEFORE the convolution below and row 1
     // before row 0's fp64 tail, so that HBM keeps streaming under the ALU phases (clamped addresses for the threads of
@@ -132,6 +177,63 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
     load_cands(0);
 
     float acc[4][D3_COUT];
+    if constexpr (MF) {
+        const int lane = tid & 63, lq = lane & 15, lg = lane >> 4;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const float inv_scale = weff[0];
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                // vmcnt(0): my DMA pieces (and row 0 of the candidates) have landed
+        __syncthreads();
+        const unsigned char* tabl = d3_smem + SMEM - D3M_TABLE + lane * 16;
+        // One phase at a time: 24 matrix instructions into four accumulators (pixel blocks: row 2 wv + (q >> 1), columns 16 (q & 1) ...),
+        // then the phase's logits cross from the matrix layout (lane = pixel column, registers = 4 channels) to the tail's (thread =
+        // pixel, registers = channels) through 6 KB of LDS.  A wave's matrix columns are exactly its own threads' pixels (rows 2 wv,
+        // 2 wv + 1 = threads 64 wv ... 64 wv + 63), so the exchange needs no workgroup barrier.
+        float* lg_s = reinterpret_cast<float*>(d3_smem + 4 * D3M_PLANE);   // [co][pixel = row * 32 + column]
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int a = ph >> 1, b = ph & 1;
+            d3_h8 wa[2][2];                                                // [group][hi, lo]
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) wa[g][k] = *reinterpret_cast<const d3_h8*>(tabl + ((ph * 2 + g) * 2 + k) * 1024);
+            d3_f4 d[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // lane group lg = tap (dy2, dx2) = (lg >> 1, lg & 1): the pixel at tile row r + a + dy2, tile column c + b + dx2
+                const int slot = (2 * wv + (q >> 1) + a + (lg >> 1)) * (D3_TW + 2) + 16 * (q & 1) + lq + b + (lg & 1);
+                d3_f4 c4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const d3_h8 xh = *reinterpret_cast<const d3_h8*>(d3_smem + (2 * g) * D3M_PLANE + slot * 16);
+                    const d3_h8 xl = *reinterpret_cast<const d3_h8*>(d3_smem + (2 * g + 1) * D3M_PLANE + slot * 16);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][0], xh, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][0], xl, c4, 0, 0, 0);
+                    c4 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[g][1], xh, c4, 0, 0, 0);
+                }
+                d[q] = c4;
+            }
+            if (lg < 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = 4 * lg + r;                         // matrix row
+                        if (co < D3_COUT) lg_s[co * (D3_TH * D3_TW) + (2 * wv + (q >> 1)) * D3_TW + 16 * (q & 1) + lq] = d[q][r];
+                    }
+            }
+            // (lanes exchange data without a workgroup barrier: the wave-scope fences keep the compiler — which orders memory
+            // operations per thread — from moving a thread's reads across other lanes' writes; LDS executes a wave's operations in order)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int co = 0; co < D3_COUT; ++co) acc[ph][co] = lg_s[co * (D3_TH * D3_TW) + tid] * inv_scale + bias[co];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else {
 #pragma unroll
     for (int ph = 0; ph < 4; ++ph)
 #pragma unroll
@@ -158,6 +260,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const float* __restrict
                 acc[ph][co] = s;
             }
         }
+    }
     }
 
 #pragma unroll
@@ -242,10 +345,10 @@ extern "C" int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t
     FLDR_LAUNCH_RET();
 }
 
-extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bias, const float* const cand[6],
-                                       const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t,
-                                       double T_param, double* out_f64, float* out_f32, float* refine_out_or_null, int N,
-                                       int H, int W, fldr_stream_t stream) {
+static int d3_launch(bool mf, const void* d2, const float* weff, const float* bias, const float* const cand[6],
+                     const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t,
+                     double T_param, double* out_f64, float* out_f32, float* refine_out_or_null, int N,
+                     int H, int W, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d2 && weff && bias && cand && cand_bstride && cand_cstride && t && N > 0 && H > 0 && W > 0);
     FLDR_CHECK_ARG((out_f64 != nullptr) != (out_f32 != nullptr));
     if ((H | W) & 1) return FLDR_E_SHAPE;
@@ -260,7 +363,9 @@ extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const
     // start 15 floats into a 128-byte line and touch 2 lines per row instead of 3 ([32 t - 1, 32 t + 32]: one float each
     // into the lines left and right; PMC at 4K: 526 MB fetched for the 141 MB of dec2's output), while the full-resolution
     // candidate loads and the frame stores (64 t - 32 ...) stay line-aligned.  One extra half-filled tile column.
-    const int xs = g_d3_xshift >= 0 ? g_d3_xshift : (W >= 1024 ? 16 : 0);
+    // (the packed source's pixels are 16-byte records: no shift)
+    const int xs = mf ? 0 : (g_d3_xshift >= 0 ? g_d3_xshift : (W >= 1024 ? 16 : 0));
+    if (mf && ((reinterpret_cast<uintptr_t>(d2) | reinterpret_cast<uintptr_t>(weff)) & 15)) return FLDR_E_ARG;
     D3Grid gr;
     gr.tiles_x = fldr_cdiv(W / 2 + xs, D3_TW);
     gr.per_sample = gr.tiles_x * fldr_cdiv(H / 2, D3_TH);
@@ -268,8 +373,84 @@ extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const
     gr.total = gr.per_sample * N;
     gr.per_xcd = g_d3_xcd ? (gr.total + 7) / 8 : 0;
     dim3 grid(g_d3_xcd ? 8 * gr.per_xcd : gr.total);
-    if (out_f64) hipLaunchKernelGGL(dec3_synth_kernel<double>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
-    else         hipLaunchKernelGGL(dec3_synth_kernel<float>, grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
+    if (mf) {
+        if (out_f64) hipLaunchKernelGGL((dec3_synth_kernel<double, true>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
+        else         hipLaunchKernelGGL((dec3_synth_kernel<float, true>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
+    } else {
+        if (out_f64) hipLaunchKernelGGL((dec3_synth_kernel<double, false>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
+        else         hipLaunchKernelGGL((dec3_synth_kernel<float, false>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
+    }
+    FLDR_LAUNCH_RET();
+}
+
+extern "C" int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+                                       const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t,
+                                       double T_param, double* out_f64, float* out_f32, float* refine_out_or_null, int N,
+                                       int H, int W, fldr_stream_t stream) {
+    return d3_launch(false, d2, weff, bias, cand, cand_bstride, cand_cstride, t, T_param, out_f64, out_f32, refine_out_or_null, N, H, W, stream);
+}
+
+// The same operator on dec2's SPLIT-PACKED output (fldr_spk_bytes(16, H/2, W/2) bytes per sample), phase convolutions on the
+// fp16 matrix cores (3 x fp16 split: fp32-equivalent logits, not the bits of the fp32-FMA kernel above); wm: fldr_dec3_prepack_spk.
+extern "C" int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const float* bias, const float* const cand[6],
+                                   const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t,
+                                   double T_param, double* out_f64, float* out_f32, float* refine_out_or_null, int N,
+                                   int H, int W, fldr_stream_t stream) {
+    return d3_launch(true, d2_spk, wm, bias, cand, cand_bstride, cand_cstride, t, T_param, out_f64, out_f32, refine_out_or_null, N, H, W, stream);
+}
+
+// wm: D3M_HDR floats {1 / scale, scale, max |w|, 0, zero block ...} + the A operands [phase][group][hi, lo][lane][8 halves]
+// (lane = (matrix row = output channel, lane group = tap); element j = input channel 8 group + j): the per-phase 2x2 weights
+// of dec3_prepack_kernel, scaled by a power of two into the fp16 range and split into hi + lo.
+__global__ void dec3_prepack_spk_kernel(const float* __restrict__ w, float* __restrict__ wm) {
+    __shared__ float we[D3_CIN * 4 * D3_COUT * 4];
+    __shared__ float red[256];
+    const int tid = threadIdx.x;
+    float m = 0.0f;
+    for (int i = tid; i < D3_CIN * 4 * D3_COUT * 4; i += 256) {
+        const int tap = i & 3, co = (i >> 2) % D3_COUT, ph = (i / (4 * D3_COUT)) & 3, c = i / (16 * D3_COUT);
+        const int a = ph >> 1, b = ph & 1, dy2 = tap >> 1, dx2 = tap & 1;
+        const int r0 = a == 0 ? (dy2 == 0 ? 0 : 1) : (dy2 == 0 ? 0 : 2), r1 = a == 0 ? (dy2 == 0 ? 0 : 2) : (dy2 == 0 ? 1 : 2);
+        const int c0 = b == 0 ? (dx2 == 0 ? 0 : 1) : (dx2 == 0 ? 0 : 2), c1 = b == 0 ? (dx2 == 0 ? 0 : 2) : (dx2 == 0 ? 1 : 2);
+        const float* wk = w + ((int64_t)co * D3_CIN + c) * 9;
+        float sum = 0.0f;
+        for (int r = r0; r <= r1; ++r)
+            for (int q = c0; q <= c1; ++q) sum += wk[r * 3 + q];
+        we[i] = sum;
+        m = fmaxf(m, fabsf(sum));
+    }
+    red[tid] = m;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (tid < st) red[tid] = fmaxf(red[tid], red[tid + st]);
+        __syncthreads();
+    }
+    const float mx = red[0];
+    float scale = 1.0f;                                                  // largest power of two with mx * scale <= 8192 (as spk_absmax_kernel)
+    if (mx > 0.0f) scale = exp2f(floorf(log2f(8192.0f / mx)));
+    if (tid < D3M_HDR) wm[tid] = tid == 0 ? 1.0f / scale : (tid == 1 ? scale : (tid == 2 ? mx : 0.0f));
+    d3_h8* frag = reinterpret_cast<d3_h8*>(wm + D3M_HDR);
+    for (int i = tid; i < 16 * 64; i += 256) {
+        const int lane = i & 63, blk = i >> 6;
+        const int kind = blk & 1, g = (blk >> 1) & 1, ph = blk >> 2;
+        const int co = lane & 15, tap = lane >> 4;
+        d3_h8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = g * 8 + j;
+            const float x = co < D3_COUT ? we[((c * 4 + ph) * D3_COUT + co) * 4 + tap] * scale : 0.0f;
+            const _Float16 hh = (_Float16)x;
+            v[j] = kind == 0 ? hh : (_Float16)(x - (float)hh);
+        }
+        frag[i] = v;
+    }
+}
+
+extern "C" int64_t fldr_dec3_prepack_spk_size(void) { return D3M_HDR + D3M_TABLE / 4; }
+
+extern "C" int fldr_dec3_prepack_spk(const float* weight, float* wm, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(weight && wm && (reinterpret_cast<uintptr_t>(wm) & 15) == 0);
+    hipLaunchKernelGGL(dec3_prepack_spk_kernel, dim3(1), dim3(256), 0, fldr_s(stream), weight, wm);
     FLDR_LAUNCH_RET();
 }
 

@@ -345,7 +345,8 @@ class DCTVFInet(nn.Module):
         unet = self.refine_unet
         if tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and H % 2 == 0 and W % 2 == 0:
             # dec3 + softmax/T + blend in one kernel; refine_out (6 full-resolution planes) is never stored
-            out = fldr_hip.dec3_synth(unet.forward_until_dec2(srcs), unet.dec3.weight, unet.dec3.bias, cands, t4, T)
+            out = fldr_hip.dec3_synth(unet.forward_until_dec2(srcs, packed_out=fldr_hip.DEC3_MFMA and fldr_hip.use_spk()),
+                                      unet.dec3.weight, unet.dec3.bias, cands, t4, T)
         else:
             refine_out = unet(srcs)
             out = fldr_hip.synth_tail(refine_out[:, 0:6], cands, t4, T)                                # :511-524
@@ -386,7 +387,7 @@ class PCARefineUNet(nn.Module):
         self.dec2 = _conv3(2 * nf + nf, nf)
         self.dec3 = _conv3(nf, self.output_maps)
 
-    def forward_until_dec2(self, concat):
+    def forward_until_dec2(self, concat, packed_out=False):
         """Everything up to and including dec2 + ReLU (fLDRnet.py:621-640), at half resolution."""
         srcs = list(concat) if isinstance(concat, (list, tuple)) else [concat]
         cv = fldr_hip.conv2d
@@ -404,7 +405,9 @@ class PCARefineUNet(nn.Module):
             out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)
             out = cs([out], self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
             out = cs([out, enc2p], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
-            return cs([out, enc1p], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False])
+            # dec2's output stays split-packed when the fused dec3 + blend kernel consumes it (matrix-core phase convolutions)
+            return cs([out, enc1p], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False],
+                      want_f32=not packed_out, want_spk=packed_out)
         enc1 = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True)
         enc2 = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True)
         out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True)

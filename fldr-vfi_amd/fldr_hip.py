@@ -169,6 +169,11 @@ _SIGNATURES = {
     "fldr_dec3_synth_strided": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                                ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p,
                                                _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fldr_dec3_prepack_spk_size": (ctypes.c_int64, []),
+    "fldr_dec3_prepack_spk": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
+    "fldr_dec3_synth_spk": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
+                                           ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p,
+                                           _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_ssim_y_ws_doubles": (ctypes.c_int64, [ctypes.c_int] * 3),
@@ -645,6 +650,7 @@ def pca_table(ev, mean, meanvec):
     return tab
 
 
+DEC3_MFMA = os.environ.get("FLDR_DEC3_MFMA", "1") != "0"      # the fused dec3 + blend kernel reads dec2's packed output (matrix-core phase convolutions)
 PCA_RAW_MIN_BYTES = int(os.environ.get("FLDR_PCA_RAW_MIN_BYTES", "0"))      # levels of at least this many projection bytes are parked between the two passes (4K pyramid: 196.9 us none, 186.7 from 4 MB, 168.4 all)
 
 
@@ -1167,18 +1173,30 @@ def synth_tail(refine, cands, t, T_param, out_dtype=torch.float64):
 
 
 def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, want_refine=False):
-    """Fused dec3 (on the nearest-x2 upsampled dec2 output) + softmax/T + blend (fLDRnet.py:642-643, 511-524)."""
+    """Fused dec3 (on the nearest-x2 upsampled dec2 output) + softmax/T + blend (fLDRnet.py:642-643, 511-524).  d2: dec2's
+    output as an fp32 tensor (phase convolutions in fp32 on the vector ALUs) or split-packed (Spk: on the fp16 matrix cores with
+    the 3 x fp16 split, the model's path)."""
     N, cin, h, w = d2.shape
     assert tuple(weight.shape) == (6, 16, 3, 3) and cin == 16 and len(cands) == 6
     H, W = 2 * h, 2 * w
-    hit = getattr(weight, "_fldr_dec3", None)
+    packed = isinstance(d2, Spk)
+    key = "_fldr_dec3m" if packed else "_fldr_dec3"
+    hit = getattr(weight, key, None)
     if hit is None or hit[0] != (weight._version, weight.data_ptr()):
-        weff = torch.empty(1536, device=weight.device, dtype=torch.float32)
-        _check(lib().fldr_dec3_prepack(_dev(weight.detach().contiguous(), "weight"), _dev(weff, "weff"), _stream()), "fldr_dec3_prepack")
+        if packed:
+            weff = torch.empty(int(lib().fldr_dec3_prepack_spk_size()), device=weight.device, dtype=torch.float32)
+            _check(lib().fldr_dec3_prepack_spk(_dev(weight.detach().contiguous(), "weight"), _dev(weff, "wm"), _stream()), "fldr_dec3_prepack_spk")
+        else:
+            weff = torch.empty(1536, device=weight.device, dtype=torch.float32)
+            _check(lib().fldr_dec3_prepack(_dev(weight.detach().contiguous(), "weight"), _dev(weff, "weff"), _stream()), "fldr_dec3_prepack")
         _prepack_done()
-        weight._fldr_dec3 = hit = ((weight._version, weight.data_ptr()), weff)
+        setattr(weight, key, ((weight._version, weight.data_ptr()), weff))
+        hit = getattr(weight, key)
     weff = hit[1]
-    d2 = d2.contiguous()
+    if packed:
+        assert d2.bstride == 4 * h * w * 16, "dec3_synth: the packed source must be a whole 16-channel tensor"
+    else:
+        d2 = d2.contiguous()
     ptrs = (ctypes.c_void_p * 6)()
     strides = (ctypes.c_int64 * 6)()
     cstrides = (ctypes.c_int64 * 6)()
@@ -1193,9 +1211,14 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
     refine = torch.empty(N, 6, H, W, device=d2.device, dtype=torch.float32) if want_refine else None
     o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
     o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
-    _check(lib().fldr_dec3_synth_strided(_dev(d2, "d2"), _dev(weff, "weff"), _dev(bias.detach(), "bias"), ptrs, strides, cstrides,
+    if packed:
+        _check(lib().fldr_dec3_synth_spk(ctypes.c_void_p(d2.ptr), _dev(weff, "wm"), _dev(bias.detach(), "bias"), ptrs, strides, cstrides,
                                          _dev(t, "t"), float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None,
-                                         N, H, W, _stream()), "fldr_dec3_synth_strided")
+                                         N, H, W, _stream()), "fldr_dec3_synth_spk")
+    else:
+        _check(lib().fldr_dec3_synth_strided(_dev(d2, "d2"), _dev(weff, "weff"), _dev(bias.detach(), "bias"), ptrs, strides, cstrides,
+                                             _dev(t, "t"), float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None,
+                                             N, H, W, _stream()), "fldr_dec3_synth_strided")
     return (out, refine) if want_refine else out
 
 

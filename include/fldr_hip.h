@@ -398,6 +398,15 @@ int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bia
                             const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
                             double* out_f64, float* out_f32, float* refine_out_or_null, int N, int H, int W,
                             fldr_stream_t stream);
+/* The same fused operator on dec2's SPLIT-PACKED output (fldr_spk_bytes(16, H/2, W/2) bytes per sample): the phase convolutions run
+ * on the fp16 matrix cores with the 3 x fp16 split of the 3x3 convolutions (fp32-equivalent logits; not the bits of the fp32-FMA
+ * kernel of fldr_dec3_synth), the fp64 tail is the same code.  wm: fldr_dec3_prepack_spk (fldr_dec3_prepack_spk_size() floats,
+ * 16-byte aligned).  The model's default since round 3 (fLDRnet.py:642-643 + :511-524). */
+int64_t fldr_dec3_prepack_spk_size(void);
+int fldr_dec3_prepack_spk(const float* weight, float* wm, fldr_stream_t stream);
+int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const float* bias, const float* const cand[6],
+                        const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
+                        double* out_f64, float* out_f32, float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Callers either side of the path, on the device (the reference does these on the CPU).

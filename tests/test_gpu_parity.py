@@ -1047,6 +1047,34 @@ def test_fused_dec3_synth_matches_unfused(hip, dev, hooks):
         hip.lib().fldr_debug_dec3_xshift(-1)
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 38), (1, 8, 32), (1, 37, 70), (1, 64, 96)])
+def test_fused_dec3_synth_on_the_matrix_cores(hip, dev, shape):
+    """fldr_dec3_synth_spk: the phase convolutions of the fused dec3 + blend kernel on the fp16 matrix cores (3 x fp16 split) from
+    dec2's split-packed output, against torch (logits and blended frame) and against the fp32-FMA kernel: partial tiles, tiles
+    at every border, two samples."""
+    g = _gen(44)
+    N, h, w = shape
+    d2 = torch.rand(N, 16, h, w, generator=g) * 1.7                         # post-ReLU activations
+    wt = torch.randn(6, 16, 3, 3, generator=g) / 6
+    bs = torch.randn(6, generator=g) * 0.3
+    cands = [(torch.rand(N, 3, 2 * h, 2 * w, generator=g) * 2 - 1).to(dev) for _ in range(6)]
+    t = torch.tensor([[0.25], [0.5]])[:N]
+    ref_logits = F.conv2d(F.interpolate(d2.double(), scale_factor=2, mode="nearest"), wt.double(), bs.double(), padding=1)
+    d2p = hip.spk_pack(d2.to(dev))
+    out, logits = hip.dec3_synth(d2p, wt.to(dev), bs.to(dev), cands, t.to(dev), 1.5616, want_refine=True)
+    _cmp(logits, ref_logits.float(), atol=4e-6, rtol=2e-6, what="matrix-core dec3 logits")
+    occ = F.softmax(ref_logits / 1.5616, dim=1)
+    t4 = t.view(N, 1, 1, 1).double()
+    wk = [(1 - t4), t4] * 3
+    num = sum(wk[k] * occ[:, k:k + 1] * cands[k].cpu().double() for k in range(6))
+    den = sum(wk[k] * occ[:, k:k + 1] for k in range(6))
+    _cmp(out, num / den, atol=3e-6, what="matrix-core dec3 + blend vs torch")
+    vec = hip.dec3_synth(d2.to(dev), wt.to(dev), bs.to(dev), cands, t.to(dev), 1.5616)
+    _cmp(out, vec, atol=3e-6, what="matrix-core vs fp32-FMA kernel")
+    o32 = hip.dec3_synth(d2p, wt.to(dev), bs.to(dev), cands, t.to(dev), 1.5616, out_dtype=torch.float32)
+    assert o32.dtype == torch.float32 and torch.equal(o32, out.float())
+
+
 def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
     """8x protocol: 7 outputs per pair with PCA/flows/z computed once == 7 independent forwards == oracle."""
     import fldr_harness as Hn

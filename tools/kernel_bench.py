@@ -87,6 +87,9 @@ def dec3():
         L.fldr_debug_dec3_xshift(xs)
         print("x shift %2d: %.1f us" % (xs, timeit(lambda i: hip.dec3_synth(sets[i % 2][0], wt, bs, sets[i % 2][1], t, 1.5616), 16)), flush=True)
     L.fldr_debug_dec3_xshift(-1)
+    psets = [hip.spk_pack(sets[i][0]) for i in range(2)]
+    print("split-packed source, matrix cores: %.1f us" % timeit(lambda i: hip.dec3_synth(psets[i % 2], wt, bs, sets[i % 2][1], t, 1.5616), 16), flush=True)
+    print("fp32 source, vector ALUs         : %.1f us" % timeit(lambda i: hip.dec3_synth(sets[i % 2][0], wt, bs, sets[i % 2][1], t, 1.5616), 16), flush=True)
     outs = {}
     for xc in (0, 1, 0, 1):
         L.fldr_debug_dec3_xcd(xc)
