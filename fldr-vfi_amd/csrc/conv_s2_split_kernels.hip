@@ -1057,7 +1057,8 @@ static int s2_launch_pers_spk(S2Args& a, int N, hipStream_t s, int lds_bytes) {
     const int64_t total = (int64_t)N * a.n_tiles;
     if (total >= (1ll << 30)) return FLDR_E_SHAPE;
     a.tiles_per_xcd = (int)((total + 7) / 8);
-    a.wgs_per_xcd = a.tiles_per_xcd < 64 ? a.tiles_per_xcd : 64;
+    const int cap = lds_bytes > 80 * 1024 ? 32 : 64;                         // workgroups per XCD that fit: one or two per CU
+    a.wgs_per_xcd = a.tiles_per_xcd < cap ? a.tiles_per_xcd : cap;
     hipLaunchKernelGGL((conv4x4s2_pers_spk_kernel<MT, NMT, PT>), dim3(8 * a.wgs_per_xcd), dim3(256), lds_bytes, s, a);
     FLDR_LAUNCH_RET();
 }
@@ -1079,6 +1080,6 @@ extern "C" int fldr_conv2d_s2_spk(const fldr_conv_desc* d, fldr_stream_t stream)
     const int n_chunks = d->cin / S2_CC;
     hipStream_t s = fldr_s(stream);
     if (mt == 16) { const int lds = n_chunks * S2Cfg<16, 1>::W_BYTES + 2 * S2Cfg<16, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<16, 1, 4>(a, d->N, s, lds); }
-    else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds); }
+    else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 156 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds); }   // (> 80 KB: one workgroup per CU)
     return FLDR_E_SHAPE;
 }

@@ -387,6 +387,21 @@ class PCARefineUNet(nn.Module):
         self.dec2 = _conv3(2 * nf + nf, nf)
         self.dec3 = _conv3(nf, self.output_maps)
 
+    def _enc3_halves(self):
+        """enc3's weights / bias as two halves of 32 output channels (cached copies: the prepacked tables hang on them), or None
+        where the packed-source encoder does not take them."""
+        w, b = self.enc3.weight, self.enc3.bias
+        if tuple(w.shape[:1]) != (64,) or not fldr_hip.use_spk():
+            return None
+        key = (w._version, w.data_ptr(), b._version, b.data_ptr())
+        hit = getattr(self, "_enc3_split", None)
+        if hit is None or hit[0] != key:
+            parts = [(w.detach()[k:k + 32].contiguous(), b.detach()[k:k + 32].contiguous()) for k in (0, 32)]
+            if not all(fldr_hip.s2_spk_ok(p[0]) for p in parts):
+                parts = None
+            self._enc3_split = hit = (key, parts)
+        return hit[1]
+
     def forward_until_dec2(self, concat, packed_out=False):
         """Everything up to and including dec2 + ReLU (fLDRnet.py:621-640), at half resolution."""
         srcs = list(concat) if isinstance(concat, (list, tuple)) else [concat]
@@ -395,15 +410,26 @@ class PCARefineUNet(nn.Module):
             # the encoders (exact fp32-MFMA stride-2 kernels) emit the split-packed twins the decoder reads; decoder
             # activations only exist split-packed
             cs = fldr_hip.conv2d_spk
+            halves = self._enc3_halves() if fldr_hip.ENC3_SPLIT else None
             if fldr_hip.s2_spk_ok(self.enc2.weight):
                 # enc2 reads enc1's PACKED output: enc1 writes no fp32 copy of its 16 half-resolution planes (141 MB at 4K)
                 enc1p = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True, want_f32=False, want_spk=True)
-                enc2, enc2p = fldr_hip.conv2d_s2_spk(enc1p, self.enc2.weight, self.enc2.bias, relu=True, want_f32=True, want_spk=True)
+                if halves is not None:
+                    enc2, enc2p = None, fldr_hip.conv2d_s2_spk(enc1p, self.enc2.weight, self.enc2.bias, relu=True, want_f32=False, want_spk=True)
+                else:
+                    enc2, enc2p = fldr_hip.conv2d_s2_spk(enc1p, self.enc2.weight, self.enc2.bias, relu=True, want_f32=True, want_spk=True)
             else:
+                halves = None
                 enc1, enc1p = cv(srcs, self.enc1.weight, self.enc1.bias, stride=2, relu=True, want_spk=True)
                 enc2, enc2p = cv([enc1], self.enc2.weight, self.enc2.bias, stride=2, relu=True, want_spk=True)
-            out = cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)
-            out = cs([out], self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
+            if halves is not None:
+                # enc3 (32 -> 64) as two persistent launches of 32 output channels on enc2's PACKED output (64 KB of weights each in
+                # LDS; the whole layer's 128 KB only fit the per-tile kernel, which exposes a load round trip per 4-channel chunk):
+                # enc2 writes no fp32 copy either; dec0 reads the two halves as two sources
+                out = [fldr_hip.conv2d_s2_spk(enc2p, w, b, relu=True, want_f32=False, want_spk=True) for (w, b) in halves]
+            else:
+                out = [cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)]
+            out = cs(out, self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
             out = cs([out, enc2p], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
             # dec2's output stays split-packed when the fused dec3 + blend kernel consumes it (matrix-core phase convolutions)
             return cs([out, enc1p], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False],

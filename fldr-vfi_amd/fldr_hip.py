@@ -650,6 +650,7 @@ def pca_table(ev, mean, meanvec):
     return tab
 
 
+ENC3_SPLIT = os.environ.get("FLDR_ENC3_SPLIT", "1") != "0"    # enc3 as two 32-channel persistent launches on enc2's packed output
 DEC3_MFMA = os.environ.get("FLDR_DEC3_MFMA", "1") != "0"      # the fused dec3 + blend kernel reads dec2's packed output (matrix-core phase convolutions)
 PCA_RAW_MIN_BYTES = int(os.environ.get("FLDR_PCA_RAW_MIN_BYTES", "0"))      # levels of at least this many projection bytes are parked between the two passes (4K pyramid: 196.9 us none, 186.7 from 4 MB, 168.4 all)
 
@@ -1112,7 +1113,7 @@ def s2_spk_ok(weight):
     if k != 4 or cin % 8 or cin > 64 or cout > 32 or CONV_PRECISION == "fp32" or os.environ.get("FLDR_S2_SPK", "1") == "0":
         return False
     w_bytes = (2 if cout <= 16 else 4) * 2 * 1024                  # S2Cfg<MT, 1>::W_BYTES: steps x (hi, lo) KB
-    return (cin // 4) * w_bytes + 2 * 4 * 1440 * 4 <= 80 * 1024
+    return (cin // 4) * w_bytes + 2 * 4 * 1440 * 4 <= (80 if cout <= 16 else 156) * 1024      # (17..32 outputs: one workgroup per CU above 80 KB)
 
 
 def conv2d_spk_levels(srcs, weight, bias, relu=False, residuals=None, want_f32=True, want_spk=False, precision=None):

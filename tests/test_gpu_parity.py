@@ -295,7 +295,8 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape, hooks):
             assert torch.equal(hip.conv2d([ref[:, half:]], w3, None, precision="split"), hip.conv2d_spk([gp.narrow(half, half)], w3, None))
 
 
-@pytest.mark.parametrize("shape", [(16, 32, 50, 70, 2), (8, 16, 34, 130, 1), (32, 16, 18, 66, 1), (16, 32, 144, 240, 1), (24, 16, 20, 36, 1)])
+@pytest.mark.parametrize("shape", [(16, 32, 50, 70, 2), (8, 16, 34, 130, 1), (32, 16, 18, 66, 1), (16, 32, 144, 240, 1), (24, 16, 20, 36, 1),
+                                   (32, 32, 68, 120, 1), (32, 32, 272, 96, 2), (40, 24, 30, 44, 1)])
 def test_stride2_conv_on_packed_source(hip, dev, shape):
     """fldr_conv2d_s2_spk (enc2 reading enc1's packed output): the bits of the fp32-source stride-2 kernel on the values the
     packed tensor holds — fp32 and packed outputs, odd sizes, batch of 2, several workgroup rounds."""
