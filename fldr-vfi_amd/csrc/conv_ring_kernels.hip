@@ -21,7 +21,6 @@
 //     therefore run up to two iterations apart instead of meeting at a barrier 6 times per unit.
 //   * Every spin is bounded (RING_SPIN_LIMIT polls, then the wave gives up, counts the event in fldr_ring_timeouts and
 //     runs on): the grid always drains.
-#include <type_traits>
 #include "spk_common.h"
 
 #define RING_SLOTS 3
@@ -32,23 +31,6 @@
 #endif
 #ifndef RING_FIN_PRIO
 #define RING_FIN_PRIO 0                         // wave priority of a consumer during its epilogue (0 = unchanged)
-#endif
-#ifndef RING_DEFER
-#define RING_DEFER 0                            // 1: a unit's epilogue runs between the MFMAs of the NEXT unit's first iteration (see the consumer
-                                                // loop).  Measured: 96->96 @272x480 59.9 vs 62.8 us alone, but 414 vs 418 pairs/s in the
-                                                // three-stream bench (the interleaved stores cost what the hidden VALU work saves): off.
-#endif
-#ifndef RING_LEAN
-#define RING_LEAN 0                             // 1: single-buffered hi weights / lo pixels in the iteration that carries a parked epilogue
-#endif
-#ifndef RING_FAIR
-#define RING_FAIR 0                             // 1: the two consumer waves of a SIMD trade issue priority by progress (see the consumer loop)
-#endif
-#ifndef RING_FAIR_SKEW
-#define RING_FAIR_SKEW 1
-#endif
-#ifndef RING_EARLY_FREE
-#define RING_EARLY_FREE 0                       // 1: FREE is signalled right after the last operand read is ISSUED (step 3)
 #endif
 
 #ifdef RING_STAMPS
@@ -332,22 +314,15 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     };
     const int gout = (a.cout_store + 7) >> 3;
     const int cbase = grp0 * MTOT;
-    // bias of this lane's 4 channels per 16-channel block: in registers, or (kernels with the deferred epilogue, which need
-    // the 4 * NMT registers) fetched from the LDS table block by block
-    constexpr bool CAN_DEFER = RING_DEFER && !HAS_RES && NC == 8;
-    float bias_r[CAN_DEFER ? 1 : NMT][4];
-    if constexpr (!CAN_DEFER) {
+    // bias of this lane's 4 channels per 16-channel block, in registers
+    float bias_r[NMT][4];
 #pragma unroll
-        for (int m = 0; m < NMT; ++m) {
-            const f4 bv = *reinterpret_cast<const f4*>(smem + Cfg::BIAS_OFF + (m * 16 + lg * 4) * 4);
+    for (int m = 0; m < NMT; ++m) {
+        const f4 bv = *reinterpret_cast<const f4*>(smem + Cfg::BIAS_OFF + (m * 16 + lg * 4) * 4);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) bias_r[m][r] = bv[r];
-        }
+        for (int r = 0; r < 4; ++r) bias_r[m][r] = bv[r];
     }
-    auto bias_of = [&](int m) __attribute__((always_inline)) -> f4 {
-        if constexpr (CAN_DEFER) return *reinterpret_cast<const f4*>(smem + Cfg::BIAS_OFF + (m * 16 + lg * 4) * 4);
-        else return f4{bias_r[m][0], bias_r[m][1], bias_r[m][2], bias_r[m][3]};
-    };
+    auto bias_of = [&](int m) __attribute__((always_inline)) -> f4 { return f4{bias_r[m][0], bias_r[m][1], bias_r[m][2], bias_r[m][3]}; };
     auto unit_pixels = [&](int u, uint32_t (&po)[NQ], int& n) {
         int ty, tx;
         unit_decode(u, n, ty, tx);
@@ -480,61 +455,19 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
     };
 
-    // Deferred epilogue (RING_DEFER; launches without residual whose only output is the packed tensor, units on the fast
-    // path): a unit's accumulators move to `tmp` when its last chunk is done and are scaled / split / stored BETWEEN the MFMAs
-    // of the next unit's first iteration, two blocks' worth of VALU work and stores per MFMA step.  Stand-alone, the epilogue
-    // stops its wave's matrix instructions for ~3,300 cycles per unit (the SIMD partner then issues alone, one MFMA per 20
-    // cycles with its own polls and bookkeeping exposed): 15 % of the 96->96 launch (ablation: 64.2 -> 54.7 us without it;
-    // 58.5 with the deferred VALU work but no stores, 59.9-61.5 with everything: the stores are most of the cost).
-    constexpr int NBLK_E = NMT * NQ;                                     // (pixel block, 16-channel block) pairs of a wave
-    f4 tmp[CAN_DEFER ? NMT : 1][CAN_DEFER ? NQ : 1];
-    uint32_t pend_voff = 0;
-    char* pend_spkn = nullptr;
-    const bool defer_launch = CAN_DEFER && a.out_spk != nullptr && a.out_f32 == nullptr && grp_full;     // kernel-uniform
-    // block b = q * NMT + m of the pending unit, branch-free (fast path of finish_store, packed output only)
-    // (addresses: one lane-dependent 32-bit offset `pend_voff`, fixed when the unit is parked; everything that depends on the
-    // block is wave-uniform and stays in scalar registers — nothing per block for the compiler to hoist into VGPRs)
-    auto epi_block = [&](int b) __attribute__((always_inline)) {
-        if constexpr (CAN_DEFER) {
-            const int q = b / NMT, m = b - q * NMT;
-            const uint32_t s_pix = (uint32_t)((q / CB) * uW + (q % CB) * 16);
-            const uint32_t s_off = ((uint32_t)(((cbase >> 3) + 2 * m) * 2) * HW32 + s_pix) * 16u;     // wave-uniform
-            char* pb = pend_spkn + s_off;
-            h4 ohi, olo;
-            const f4 bsv = bias_of(m);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = fmaxf(tmp[m][q][r] * inv_scale + bsv[r], relu_floor);
-                _Float16 h, l;
-                spk_split(v, h, l, range_bad);
-                ohi[r] = h; olo[r] = l;
-            }
-#if defined(RING_ABLATE) && RING_ABLATE == 6                          // diagnostic: deferred epilogue without its stores
-            asm volatile("" :: "v"(ohi), "v"(olo), "s"(pb));
-#else
-            *reinterpret_cast<h4*>(pb + pend_voff) = ohi;
-            *reinterpret_cast<h4*>(pb + HW32 * 16u + pend_voff) = olo;
-#endif
-        }
-    };
-
     int st_cur = 0;
     uint32_t full_target = RING_NLOAD;                                    // RING_NLOAD * (use index of the slot + 1)
 #ifdef RING_STAMPS
     unsigned long long cs_wait = 0, cs_steps = 0, cs_fin = 0;
     RSTAMP(c_begin)
 #endif
-    // the MFMA steps of one iteration on slot st_cur; EPI: with the pending unit's epilogue blocks spread over the steps
-    auto steps = [&](auto epi_tag) __attribute__((always_inline)) {
-        constexpr bool EPI = decltype(epi_tag)::value;
+    // the MFMA steps of one iteration on slot st_cur
+    auto steps = [&]() __attribute__((always_inline)) {
         const unsigned char* sb = smem + st_cur * Cfg::STAGE;
         const unsigned char* win = sb + lane * 16;
         // Operand registers.  The lo weights are single-buffered (they feed only the last third of a step's MFMAs and are
-        // fetched at its start).  In the iteration that carries a parked epilogue (EPI) the hi weights and the lo pixels
-        // are single-buffered too — refilled for the next step right after their last use, behind the second third of
-        // the step's MFMAs — which frees the 20 registers the parked accumulators need.
-        constexpr bool LEAN = RING_LEAN && EPI && TERMS > 1;
-        h8 bh[2][NQ], bl[LEAN ? 1 : 2][NQ], ah[LEAN ? 1 : 2][NMT], al[NMT];
+        // fetched at its start).
+        h8 bh[2][NQ], bl[2][NQ], ah[2][NMT], al[NMT];
         auto tap_off = [&](int s) {
             // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values)
             const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
@@ -564,7 +497,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
         };
         // issue order = consumption order of the term-major MFMA sequence (hi x hi, hi x lo, lo x hi)
-        auto ld = [&](int buf, int s) { ld_bh(buf, s); ld_ah(LEAN ? 0 : buf, s); ld_bl(LEAN ? 0 : buf, s); };
+        auto ld = [&](int buf, int s) { ld_bh(buf, s); ld_ah(buf, s); ld_bl(buf, s); };
         constexpr int N_MFMA = NQ * TERMS * NMT, N_DS = TERMS > 1 ? 2 * NQ + 2 * NMT : NQ + NMT;
 #ifdef RING_NTAIL
         constexpr int N_TAIL = N_MFMA >= 12 ? RING_NTAIL : (N_MFMA >= 6 ? 2 : 0);
@@ -577,26 +510,20 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #pragma unroll
         for (int s = 0; s < SPK_STEPS; ++s) {
 #if defined(RING_ABLATE) && RING_ABLATE == 1                          // diagnostic: operands read once per iteration
-            if (s + 1 < SPK_STEPS && !LEAN) { for (int q = 0; q < NQ; ++q) { bh[(s + 1) & 1][q] = bh[s & 1][q]; bl[(s + 1) & 1][q] = bl[s & 1][q]; }
+            if (s + 1 < SPK_STEPS) { for (int q = 0; q < NQ; ++q) { bh[(s + 1) & 1][q] = bh[s & 1][q]; bl[(s + 1) & 1][q] = bl[s & 1][q]; }
                                               for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; } }
 #else
             if (s > 0) ld_al(s);                                         // (after the previous step's last lo-weight MFMA in program order)
-            if (s + 1 < SPK_STEPS) { if constexpr (LEAN) ld_bh((s + 1) & 1, s + 1); else ld((s + 1) & 1, s + 1); }   // lands while this step's MFMAs run
-#endif
-#if RING_EARLY_FREE
-            if (s + 2 == SPK_STEPS) { if (lane == 0) asm volatile("ds_add_u32 %0, %1" :: "v"(ctr + 16 + 4 * st_cur), "v"(1u) : "memory"); }
+            if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);                // lands while this step's MFMAs run
 #endif
 #pragma unroll
             for (int term = 0; term < TERMS; ++term) {
-                if constexpr (LEAN) {                                     // hi weights / lo pixels of the next step, behind their last readers
-                    if (term == 2 && s + 1 < SPK_STEPS) { ld_ah(0, s + 1); ld_bl(0, s + 1); }
-                }
 #pragma unroll
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const h8 av = term == 2 ? al[m] : ah[LEAN ? 0 : (s & 1)][m];
-                        const h8 bv = term == 1 ? bl[LEAN ? 0 : (s & 1)][q] : bh[s & 1][q];
+                        const h8 av = term == 2 ? al[m] : ah[s & 1][m];
+                        const h8 bv = term == 1 ? bl[s & 1][q] : bh[s & 1][q];
 #if defined(RING_ABLATE) && RING_ABLATE == 2                          // diagnostic: no MFMAs
                         asm volatile("" :: "v"(av), "v"(bv));
 #else
@@ -604,27 +531,8 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
                     }
             }
-            if constexpr (EPI) {
-                // blocks [b0, b1) of the pending unit ride on this step: ~24 VALU instructions and 2 stores each
-                constexpr int per = (NBLK_E + SPK_STEPS - 1) / SPK_STEPS;
-                const int b0 = s * per < NBLK_E ? s * per : NBLK_E, b1 = (s + 1) * per < NBLK_E ? (s + 1) * per : NBLK_E;
-#pragma unroll
-                for (int b = b0; b < b1; ++b) epi_block(b);
-                // {1 MFMA, 1 LDS read while there are reads, 3 VALU} per matrix instruction; the stores go wherever they fit
-                // (LEAN: the reads come in two groups — lo weights + next hi pixels from the step's start, next hi weights + lo
-                // pixels from its last third)
-                constexpr int third = N_MFMA / (TERMS > 1 ? 3 : 1);
-#pragma unroll
-                for (int i = 0; i < N_MFMA; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    const bool rd = LEAN ? (i < NMT + NQ || (i >= 2 * third && i < 2 * third + NMT + NQ)) : i < N_DS;
-                    if ((s + 1 < SPK_STEPS || (LEAN && s > 0 && i < NMT)) && rd) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    if (b1 > b0) __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-                }
-            } else {
-                // spread the next step's LDS reads evenly between this step's MFMAs
-                spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);
-            }
+            // spread the next step's LDS reads evenly between this step's MFMAs
+            spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);
         }
     };
     // one iteration's hand-shake around `steps`: wait for the slot, run, release it, step to the next slot
@@ -636,25 +544,6 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #ifdef RING_STAMPS
         { RSTAMP(t) c0 = t; }
 #endif
-#if RING_FAIR
-        if constexpr (NC == 8) {
-            // The SIMD's arbiter serves its OLDER wave first when both consumer waves have an MFMA ready; with RING_FAIR each
-            // consumer publishes its iteration count and takes the LOWER issue priority while it is further ahead of its
-            // SIMD partner than RING_FAIR_SKEW iterations, the higher one while behind.  Measured: the waves then interleave
-            // (wait-FULL 1,500 -> 550 cycles per iteration) but the launch time does not change (64 us either way): off.
-            uint32_t pg, fl;
-            if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ctr + 32 + 4 * cw), "v"((uint32_t)g) : "memory");
-            asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(pg), "=&v"(fl) : "v"(ctr + 32 + 4 * (cw ^ 4)), "v"(ctr + 4 * st_cur) : "memory");
-            pg = (uint32_t)__builtin_amdgcn_readfirstlane((int)pg);
-            fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)fl);
-            const int d = g - (int)pg - (cw < 4 ? RING_FAIR_SKEW : -RING_FAIR_SKEW);      // > 0: further ahead than wanted
-            if (d > 0) __builtin_amdgcn_s_setprio(0);
-            else if (d < 0) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(1);
-            if (fl < full_target) ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
-        } else
-#endif
 #if defined(RING_ABLATE) && RING_ABLATE == 5                          // diagnostic: consumers never look at FULL after the first fills (timing only: stale operands)
         if (g < RING_SLOTS)
 #endif
@@ -664,9 +553,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
     };
     auto iter_end = [&]() __attribute__((always_inline)) {
-#if !RING_EARLY_FREE
         ring_signal(ctr + 16 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
-#endif
 #ifdef RING_STAMPS
         { RSTAMP(t) c2 = t; }
 #endif
@@ -683,16 +570,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         if (++st_cur == RING_SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
         ++g;
     };
-    // The parked epilogue runs in the iteration that FOLLOWS the park in straight-line code (the first chunk of the next
-    // unit), not behind a flag tested at the loop head: `tmp` is then live from the park to the end of that one iteration
-    // only (with a flag, it counts as live through every plain iteration and is spilled to scratch, whose reloads share
-    // vmcnt with the epilogue's stores).
-    const bool can_park = defer_launch && n_chunks > 1;                   // kernel-uniform
     while (g < total) {
         const bool last = cur_c == n_chunks - 1;                          // workgroup-uniform
         if constexpr (HAS_RES) { if (last) residual_prefetch(); }
         iter_begin();
-        steps(std::false_type{});
+        steps();
         iter_end();
         if (last) {
             if constexpr (HAS_RES) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the residual prefetched at the top
@@ -702,40 +584,9 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             cur_c = 0; cur_u += a.wgs_per_xcd;
             iter_close();
 #else
-            bool parked = false;
-            if constexpr (CAN_DEFER) {
-                if (can_park) {
-                    int n, ty, tx;
-                    unit_decode(cur_u, n, ty, tx);
-                    const int oy0 = ty * SPK_TH + ROWS * cw, ox0 = tx * TW;
-                    if (oy0 + ROWS <= uH && ox0 + TW <= uW) {         // wave-uniform: the fast path of finish_store
-                        pend_voff = ((uint32_t)(oy0 * uW + ox0 + lj) + (uint32_t)(lg >> 1) * 2u * HW32) * 16u + (uint32_t)(lg & 1) * 8u;
-                        pend_spkn = reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride + u_spk_off;
-#pragma unroll
-                        for (int m = 0; m < NMT; ++m)
-#pragma unroll
-                            for (int q = 0; q < NQ; ++q) { tmp[m][q] = acc[m][q]; acc[m][q] = f4{0.0f, 0.0f, 0.0f, 0.0f}; }
-                        parked = true;
-                        cur_c = 0; cur_u += a.wgs_per_xcd;
-                        iter_close();
-                        if (g < total) {                                  // first chunk of the next unit, carrying the epilogue (n_chunks > 1: not its last)
-                            iter_begin();
-                            steps(std::true_type{});
-                            iter_end();
-                            cur_c = 1;
-                            iter_close();
-                        } else {                                          // the workgroup's last unit
-#pragma unroll
-                            for (int b = 0; b < NBLK_E; ++b) epi_block(b);
-                        }
-                    }
-                }
-            }
-            if (!parked) {
-                finish_store();
-                cur_c = 0; cur_u += a.wgs_per_xcd;
-                iter_close();
-            }
+            finish_store();
+            cur_c = 0; cur_u += a.wgs_per_xcd;
+            iter_close();
 #endif
             if (RING_FIN_PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
