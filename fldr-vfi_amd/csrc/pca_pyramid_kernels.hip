@@ -384,6 +384,7 @@ __global__ __launch_bounds__(256) void pcap_rescale_kernel(PcapArgs a, int total
     pcap_emit<K>(a, w, y);
 }
 
+#ifdef FLDR_TEST_HOOKS                 // (the matrix-core formulation is a measured alternative, not a product path: test build only)
 // ------------------------------------------------------------------------------------------------
 // K = 16 on the fp64 matrix cores (opt-in: fldr_debug_pca_variant(1); the scalar-fed kernel above stays the default because it
 // is bit-identical to the per-level kernels and this one is no faster — 196 vs 202 us per 4K pyramid, both passes within
@@ -576,6 +577,9 @@ __global__ __launch_bounds__(256, 2) void pcam_kernel(PcapArgs a, const double* 
 
 static int g_pcap_variant = 0;                    // 1: fp64 matrix cores (K = 16), 0 (default): scalar-fed vector kernel
 FLDR_HOOK int fldr_debug_pca_variant(int v) { if (v == 0 || v == 1) g_pcap_variant = v; return g_pcap_variant; }
+#else
+static const int g_pcap_variant = 0;
+#endif  // FLDR_TEST_HOOKS
 
 extern "C" int64_t fldr_pca_table_size(int K) {
     if (K != 4 && K != 8 && K != 16) return FLDR_E_ARG;
@@ -644,6 +648,7 @@ extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_leve
     }
     a.table = table; a.mm = minmax_ws; a.n_levels = n_levels;
     hipStream_t s = fldr_s(stream);
+#ifdef FLDR_TEST_HOOKS
     if (K == 16 && g_pcap_variant == 1 && mfma_ok) {
         const int waves = (int)items, wgs = (waves + 3) / 4;
         const int grid = wgs < g_pcap_wgs ? wgs : g_pcap_wgs;
@@ -652,6 +657,9 @@ extern "C" int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_leve
         hipLaunchKernelGGL((pcam_kernel<true>), dim3(grid), dim3(256), 0, s, a, a.table, (int)items);
         FLDR_LAUNCH_RET();
     }
+#else
+    (void)mfma_ok; (void)items;
+#endif
     switch (K) {
         case 16: pcap_launch<16>(a, (int)wg, (int)wg_b, (int)wg_r, s); break;
         case 8:  pcap_launch<8>(a, (int)wg, (int)wg_b, (int)wg_r, s); break;

@@ -25,7 +25,6 @@ struct PrepArgs {
     float sy, sx, mul, inv_wm1, inv_hm1, r_wm1, r_hm1, za0, za1;     // inv_*: the grid normalisation divisors max(S-1,1); r_*: their reciprocals
     int withmask;
     int phase;                     // bit 0: z0 / z1 + flow_t0 / flow_t1; bit 1: flowback_0 / _1 + im0_tot / im1_tot (3 = everything)
-    int vec_ok;                    // W % 4 == 0 and every output plane 16-byte aligned: 16-byte stores
     int kx, ky;                    // sx == 2^-kx / sy == 2^-ky exactly (integer source-index arithmetic), else -1
     float rkx, rky;                // 2^-(kx+1), 2^-(ky+1)
 };
@@ -163,14 +162,12 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
     lo2[(int64_t)(N + n) * hw + i] = make_float2(p[2 * hw], p[3 * hw]);
 }
 
-// Optional output path (PREP_LDS_STORES): the 16 values of a pixel go to an LDS tile [plane][4 rows][64 pixels]; after one
-// barrier the workgroup writes every plane's tile as 16-byte pieces instead of 4-byte lanes straight from the pixel's thread.
-// The persistent encoders gained 10 % from 16-byte lanes; this kernel does not (it is bound by its ~1,000 vector
-// instructions per pixel, not by its stores), and the 16 KB of LDS cost throughput beside the other streams' kernels.
+// (An output path through an LDS tile — every plane written as 16-byte pieces after one barrier instead of 4-byte lanes straight from
+// the pixel's thread — was built and measured in round 2: the kernel alone 316 vs 321 us, but 433 vs 439 pairs/s with three pairs in
+// flight; the kernel is bound by its ~1,000 vector instructions per pixel, not by its stores.  Removed.)
 #define PREP_NPL 16                // z0, z1, flow_t0 (x, y), flow_t1, flowback_0, flowback_1, im0_tot (3), im1_tot (3)
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) float tile[PREP_NPL][4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int px = blockIdx.x * 64 + tx;
     const int py = blockIdx.y * 4 + ty;
@@ -184,13 +181,9 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
         a.flow_t0 + o2, a.flow_t0 + o2 + HW, a.flow_t1 + o2, a.flow_t1 + o2 + HW,
         a.flowback_0 + o2, a.flowback_0 + o2 + HW, a.flowback_1 + o2, a.flowback_1 + o2 + HW,
         a.im0_tot + o3, a.im0_tot + o3 + HW, a.im0_tot + o3 + 2 * HW, a.im1_tot + o3, a.im1_tot + o3 + HW, a.im1_tot + o3 + 2 * HW};
-#ifndef PREP_LDS_STORES
-#define PREP_LDS_STORES 0          // measured: the kernel alone 316 vs 321 us, but 433 vs 439 pairs/s with three pairs in flight: off
-#endif
     const uint32_t pix_off = (__umul24((uint32_t)(live ? py : 0), (uint32_t)a.W) + (uint32_t)(live ? px : 0)) * 4u;
     auto put = [&](int plane, float v) __attribute__((always_inline)) {
-        if (PREP_LDS_STORES && a.vec_ok) tile[plane][ty][tx] = v;
-        else prep_stf(dst[plane], pix_off, v);                          // 4-byte lanes, straight from the pixel's thread
+        prep_stf(dst[plane], pix_off, v);                               // 4-byte lanes, straight from the pixel's thread
     };
     if (live) {
         const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;      // byte offset of this pixel inside a plane
@@ -261,34 +254,6 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
             }
         }
     }
-    if (!PREP_LDS_STORES) return;
-    __syncthreads();
-
-    // ---- the planes of this launch, written as rows of the 64 x 4 tile ----
-    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
-    if (PREP_LDS_STORES && a.vec_ok) {                                // uniform: 16-byte pieces (W % 4 == 0, plane bases 16-byte aligned: host-checked)
-        // wave w writes planes w, w + 4, w + 8, w + 12; lane -> (row, quad) of the 4 x 64 tile: one 16-byte store per lane and plane
-        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-        const int r = lane >> 4, c4 = (lane & 15) * 4;
-        const bool ok = y0 + r < a.H && x0 + c4 < a.W;
-#pragma unroll
-        for (int pass = 0; pass < PREP_NPL / 4; ++pass) {
-            const int pl = pass * 4 + wave;                               // wave-uniform
-            const bool on = pl < 2 ? (ph1 && a.z0 != nullptr) : (pl < 6 ? ph1 : ph2);
-            float* d = dst[0];
-#pragma unroll
-            for (int k = 0; k < PREP_NPL; ++k) d = pl == k ? dst[k] : d;  // (scalar select chain: no dynamically indexed pointer array in scratch)
-            if (!on || !ok) continue;
-            typedef float prep_f4 __attribute__((ext_vector_type(4)));
-            const prep_f4 v = *reinterpret_cast<const prep_f4*>(&tile[pl][r][c4]);
-            prep_f4* o = reinterpret_cast<prep_f4*>(d + (int64_t)(y0 + r) * a.W + x0 + c4);
-#if PREP_NT
-            __builtin_nontemporal_store(v, o);
-#else
-            *o = v;
-#endif
-        }
-    }
 }
 
 extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
@@ -313,12 +278,6 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     }
     a.rkx = a.kx >= 0 ? 1.0f / (float)(1 << (a.kx + 1)) : 0.0f;
     a.rky = a.ky >= 0 ? 1.0f / (float)(1 << (a.ky + 1)) : 0.0f;
-    {
-        const void* outs[8] = {d->z0, d->z1, d->flow_t0, d->flow_t1, d->flowback_0, d->flowback_1, d->im0_tot, d->im1_tot};
-        bool v = (d->W & 3) == 0;
-        for (const void* o : outs) v = v && (reinterpret_cast<uintptr_t>(o) & 15) == 0;
-        a.vec_ok = v ? 1 : 0;
-    }
     const int64_t hw = (int64_t)d->h * d->w;
     if (!(d->phase & 4))                                          // bit 2: d->ws already holds the interleaved flow (second phase of a split call)
         hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
