@@ -121,9 +121,11 @@ __device__ __attribute__((aligned(16))) float corr_zero_block[4];
 #ifndef CORR_NLOAD
 #define CORR_NLOAD 3                   // loader waves (one wave issuing all 28 DMAs of a chunk took 2 us per chunk: the compute waves need 1)
 #endif
+struct CorrGrid { int tiles_x, per_sample, total, per_xcd; };      // per_xcd 0: plain row-major grid (test hook)
+
 template <int CC>
 __global__ __launch_bounds__(64 * (9 + CORR_NLOAD)) void correlation_dma_kernel(const float* __restrict__ a, const float* __restrict__ b,
-                                                              float* __restrict__ out, int C, int H, int W) {
+                                                              float* __restrict__ out, int C, int H, int W, CorrGrid gr) {
     constexpr int NA = CC * CORR_TH * (CORR_TW / 4), NB = CC * CORR_BH * (CORR_BW / 4);     // 16-byte pieces of a chunk
     constexpr int STAGE = (NA + NB) * 16;
     constexpr int NJ = (NA + NB) / 64;                                    // DMA wave-instructions per chunk
@@ -133,7 +135,12 @@ __global__ __launch_bounds__(64 * (9 + CORR_NLOAD)) void correlation_dma_kernel(
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // 0..8: compute wave of dy = wave - 4; 9..: loaders
     const int lane = tid & 63;
-    const int x0 = blockIdx.x * CORR_TW, y0 = blockIdx.y * CORR_TH, n = blockIdx.z;
+    // Tiles are dealt to the XCDs in contiguous row-major ranges (workgroup b runs on XCD b & 7): a tile's 16 x 40 window of the
+    // second map overlaps its neighbours' (2.5 x the tile's own pixels), and neighbours then share it in one L2.
+    const int lin = gr.per_xcd ? (int)(blockIdx.x & 7) * gr.per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if ((gr.per_xcd && (int)(blockIdx.x >> 3) >= gr.per_xcd) || lin >= gr.total) return;      // workgroup-uniform, before any barrier
+    const int n = lin / gr.per_sample, trem = lin - n * gr.per_sample, tyi = trem / gr.tiles_x;
+    const int x0 = (trem - tyi * gr.tiles_x) * CORR_TW, y0 = tyi * CORR_TH;
     const int64_t HW = (int64_t)H * W;
 
     if (wave >= 9) {
@@ -230,6 +237,8 @@ __global__ __launch_bounds__(64 * (9 + CORR_NLOAD)) void correlation_dma_kernel(
 
 static int g_corr_variant = 1;                       // 1: LDS-DMA double buffer where the shape allows; 0: the synchronous kernel
 static int g_corr_cc = 8;
+static int g_corr_xcd = 1;                           // 1: contiguous tile ranges per XCD; 0: plain row-major grid
+FLDR_HOOK int fldr_debug_corr_xcd(int v) { if (v == 0 || v == 1) g_corr_xcd = v; return g_corr_xcd; }
 FLDR_HOOK int fldr_debug_corr_variant(int v) { if (v == 0 || v == 1) g_corr_variant = v; return g_corr_variant; }
 FLDR_HOOK int fldr_debug_corr_chunk(int v) { if (v == 8 || v == 16) g_corr_cc = v; return g_corr_cc; }
 
@@ -238,8 +247,13 @@ static int corr_dma_launch(const float* a, const float* b, float* out, int N, in
     constexpr int LDS = 2 * (CC * CORR_TH * (CORR_TW / 4) + CC * CORR_BH * (CORR_BW / 4)) * 16;
     static std::atomic<uint64_t> attr_done{0};
     if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&correlation_dma_kernel<CC>), LDS, attr_done)) return e;
-    dim3 grid(fldr_cdiv(W, CORR_TW), fldr_cdiv(H, CORR_TH), N);
-    hipLaunchKernelGGL(correlation_dma_kernel<CC>, grid, dim3(64 * (9 + CORR_NLOAD)), LDS, s, a, b, out, C, H, W);
+    CorrGrid gr;
+    gr.tiles_x = fldr_cdiv(W, CORR_TW);
+    gr.per_sample = gr.tiles_x * fldr_cdiv(H, CORR_TH);
+    if ((int64_t)gr.per_sample * N > (1ll << 30)) return FLDR_E_SHAPE;
+    gr.total = gr.per_sample * N;
+    gr.per_xcd = g_corr_xcd ? (gr.total + 7) / 8 : 0;
+    hipLaunchKernelGGL(correlation_dma_kernel<CC>, dim3(g_corr_xcd ? 8 * gr.per_xcd : gr.total), dim3(64 * (9 + CORR_NLOAD)), LDS, s, a, b, out, C, H, W, gr);
     return 0;
 }
 

@@ -116,6 +116,7 @@ _SIGNATURES = {
     "fldr_debug_corr_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_splat_group_fold": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_corr_chunk": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_corr_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_softsplat_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_correlation_bwd": (ctypes.c_int, [_c_float_p] * 5 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_pca_project": (ctypes.c_int, [_c_float_p] * 7 + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

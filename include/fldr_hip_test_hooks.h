@@ -22,6 +22,7 @@ int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hoo
 int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */
 int fldr_debug_ring_consumers(int v);                              /* tuning hook of the ring pipeline: 8 (default; two consumer waves per SIMD) or 4 consumer waves; other: query */
 int fldr_debug_corr_variant(int v);                                /* cost volume staging: 1 (default) LDS-DMA double buffer where W % 4 == 0, 0 synchronous; other: query.  Bit-identical results */
+int fldr_debug_corr_xcd(int v);                                    /* tile order of the LDS-DMA cost-volume kernel: 1 (default) contiguous tile ranges per XCD, 0 row-major; other: query.  Identical results */
 int fldr_debug_corr_chunk(int v);                                  /* channels per staged chunk of the LDS-DMA cost-volume kernel: 8 (default) or 16; other: query */
 int fldr_debug_ring_tile_width(int v);                             /* tuning hook of the ring pipeline: 0 (default) automatic per launch, 16 / 32 forced; other: query.  Bit-identical results */
 int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */

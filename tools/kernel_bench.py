@@ -146,7 +146,14 @@ def corr():
             L.fldr_debug_corr_variant(variant); L.fldr_debug_corr_chunk(cc)
             t.append(timeit(lambda i: hip.correlation_fwd(a[i % 3], b[i % 3]), 30))
         mb = n * h * w * (2 * c + 81) * 4 / 1e6
-        print("%3d ch @%4dx%4d (%6.1f MB): sync %.1f us, dma8 %.1f us (%.2f of 8 TB/s), dma16 %.1f us" % (c, h, w, mb, t[0], t[1], mb / t[1] / 8.0, t[2]), flush=True)
+        L.fldr_debug_corr_variant(1); L.fldr_debug_corr_chunk(8)
+        L.fldr_debug_corr_xcd(0)
+        trm = timeit(lambda i: hip.correlation_fwd(a[i % 3], b[i % 3]), 30)
+        o0 = hip.correlation_fwd(a[0], b[0])
+        L.fldr_debug_corr_xcd(1)
+        same = bool(torch.equal(o0, hip.correlation_fwd(a[0], b[0])))
+        print("%3d ch @%4dx%4d (%6.1f MB): sync %.1f us, dma8 %.1f us (%.2f of 8 TB/s), dma16 %.1f us; dma8 row-major tile order %.1f us (same bits: %s)" % (
+            c, h, w, mb, t[0], t[1], mb / t[1] / 8.0, t[2], trm, same), flush=True)
     L.fldr_debug_corr_variant(1); L.fldr_debug_corr_chunk(8)
 
 
