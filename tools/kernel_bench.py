@@ -157,6 +157,16 @@ def corr():
     L.fldr_debug_corr_variant(1); L.fldr_debug_corr_chunk(8)
 
 
+def prep():
+    """fldr_level0_prep at the 4K shape (x8 upsampling of a 288x480 flow pair, three rotated frame pairs)."""
+    H, W, up = 2304, 3840, 8
+    lo = torch.randn(1, 4, H // up, W // up, device=dev) * 1.5
+    frames = [torch.rand(1, 3, 2, H, W, device=dev) * 2 - 1 for _ in range(3)]
+    t4 = torch.tensor([0.5], device=dev).view(1, 1, 1, 1)
+    us = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True), 16)
+    print("level0_prep 2304x3840: %.1f us" % us, flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["conv", "s2", "dec3", "pca", "band", "gather"]
     for name in which:
