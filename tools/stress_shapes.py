@@ -116,3 +116,52 @@ for it in range(12):
     err = (out - unf).abs().max().item()
     if not err < 3e-6: bad += 1; print("dec3 MISMATCH", N, h, w, err)
 print("fused dec3+tail vs conv + synth_tail: 12 shapes,", bad, "mismatches", flush=True)
+
+# ---- round 3: fused dec3 + blend on the matrix cores (packed source) vs the fp32-FMA kernel ----
+bad = 0
+for it in range(14):
+    N = random.choice([1, 2, 3]); h = random.choice([1, 2, 7, 8, 9, 20, 41]); w = random.choice([1, 2, 15, 31, 32, 33, 70])
+    d2 = torch.rand(N, 16, h, w, device=dev) * random.choice([0.3, 1.0, 4.0]); wt = torch.randn(6, 16, 3, 3, device=dev) / 6; bs = torch.randn(6, device=dev) * 0.3
+    x = torch.rand(N, 3, 2, 2 * h, 2 * w, device=dev) * 2 - 1
+    cands = [torch.rand(N, 3, 2 * h, 2 * w, device=dev) * 2 - 1 for _ in range(4)] + [x[:, :, 0], x[:, :, 1]]
+    t = torch.rand(N, 1, device=dev)
+    vec = hip.dec3_synth(d2, wt, bs, cands, t, 1.5616)
+    mat = hip.dec3_synth(hip.spk_pack(d2), wt, bs, cands, t, 1.5616)
+    err = (mat - vec).abs().max().item()
+    if not err < 5e-6: bad += 1; print("dec3 matrix-core MISMATCH", N, h, w, err)
+print("dec3+blend on the matrix cores vs the fp32-FMA kernel: 14 shapes,", bad, "mismatches", flush=True)
+
+# ---- round 3: image splat, walk by runs of four pixels vs one pixel per item (same fp32 products, fp64 sums) ----
+bad = 0
+for it in range(24):
+    N = random.choice([1, 2]); C = random.choice([1, 2, 3]); H = random.choice([1, 3, 11, 24, 25, 49, 70]); W = 4 * random.choice([1, 2, 13, 16, 17, 33, 75])
+    mode = random.choice(["summation", "average", "linear", "softmax"])
+    x = torch.rand(N, C, H, W, device=dev) * 2 - 1
+    flow = (torch.rand(N, 2, H, W, device=dev) - 0.5) * random.choice([0.0, 1.0, 8.0, 100.0])
+    if random.random() < 0.6:
+        flow = torch.nn.functional.interpolate(torch.randn(N, 2, 2, 3, device=dev) * random.choice([1.0, 5.0, 40.0]), size=(H, W), mode="bilinear").contiguous()
+    z = [torch.rand(N, 1, H, W, device=dev) + 0.1] if mode in ("linear", "softmax") else None
+    outs = []
+    for q in (1, 0):
+        hip.lib().fldr_debug_splat_quad(q)
+        outs.append(hip.softsplat_acc64([x], [flow], z, mode)[0])
+    d = (outs[0] - outs[1]).abs()
+    tol = 1e-5 * max(1.0, float(outs[1].abs().max())) if mode == "summation" else 2.5e-7
+    if not (float(d.max()) <= tol): bad += 1; print("acc64 run-walk MISMATCH", N, C, H, W, mode, float(d.max()))
+hip.lib().fldr_debug_splat_quad(1)
+print("image splat by runs of four vs one pixel per item: 24 shapes,", bad, "mismatches", flush=True)
+
+# ---- round 3: PCA pyramid with parked projections (every level / none) ----
+bad = 0
+for it in range(8):
+    K = random.choice([4, 8, 16]); P = random.choice([5, 6, 12])
+    ev = torch.randn(K, 64, device=dev, dtype=torch.float64); mean = torch.randn(64, device=dev, dtype=torch.float64) * 0.1
+    mv = torch.rand(K, device=dev, dtype=torch.float64) + 0.5
+    levels = [(8 * random.choice([1, 2, 9, 18, 36]), 8 * random.choice([1, 3, 15, 30, 64])) for _ in range(random.choice([1, 2, 4, 6]))]
+    planes = [torch.rand(P, h, w, device=dev) * 2 - 1 for (h, w) in levels]
+    a32, asp, amm = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=True, want_spk=True, raw_min_bytes=1 << 40)
+    b32, bsp, bmm = hip.pca_project_pyramid(planes, ev, mean, mv, want_f32=True, want_spk=True, raw_min_bytes=0)
+    ok = torch.equal(amm, bmm) and all(torch.equal(x, y) for x, y in zip(a32, b32)) and all(torch.equal(x.buf, y.buf) for x, y in zip(asp, bsp))
+    bad += not ok
+    if not ok: print("pca parked MISMATCH", K, P, levels)
+print("PCA pyramid, projections parked vs recomputed: 8 pyramids,", bad, "mismatches", flush=True)
