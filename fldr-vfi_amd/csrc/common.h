@@ -73,6 +73,7 @@ int fldr_range_read_split(int reset);
 int fldr_range_read_warp(int reset);
 int fldr_range_read_gather(int reset);
 int fldr_range_read_acc64(int reset);
+int fldr_ring_timeouts_read(int reset);             // conv_ring_kernels.hip: expired ring waits (fldr_range_status bit 1)
 
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
 // the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.

@@ -56,6 +56,14 @@ FLDR_HOOK int fldr_debug_ring_timeouts(void) {
 }
 
 int fldr_range_read_ring(int reset) { return fldr_tu_range_read(reset); }
+// Product-visible status of the bounded ring waits (fldr_range_status bit 1): number of waits that expired — a wave then ran on
+// with operands that had not landed, i.e. a convolution may have produced wrong output — since load / the last reset.
+int fldr_ring_timeouts_read(int reset) {
+    int v = -1;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_ring_timeouts), sizeof(int)) != hipSuccess) return -1;
+    if (v > 0 && reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(fldr_ring_timeouts), &z, sizeof(int)); }
+    return v;
+}
 
 // TW: tile width in pixels (32, or 16 for launches whose 8 x 32 tiles fill the last round of persistent workgroups badly:
 // see ring_pick_tile_width).  The LDS input plane is (8 + 2) x (TW + 2) pixels of 16 bytes, padded to a multiple of 256 bytes.

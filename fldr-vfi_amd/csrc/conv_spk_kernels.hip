@@ -455,19 +455,33 @@ __global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t
 
 int fldr_range_read_spk(int reset) { return fldr_tu_range_read(reset); }
 
-// Sticky range status of the fp16 hi/lo splits (common.h: fldr_split_hl): 1 if any value beyond +-65504 (or a NaN) was
-// split — and saturated — since the last reset on the current device, else 0; negative on a HIP error.  Synchronises.
+// Sticky status of the split-precision convolutions on the current device since the last reset; negative on a HIP error.
+//   bit 0 (FLDR_STATUS_RANGE): a value beyond +-65504 (or a NaN) was split — and saturated (common.h: fldr_split_hl);
+//   bit 1 (FLDR_STATUS_RING_TIMEOUT): a bounded wait of the loader / consumer ring expired (conv_ring_kernels.hip): the wave
+//          ran on with operands that had not landed — the output of that convolution is not to be trusted.
+// Synchronises.
 extern "C" int fldr_range_status(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     int v = 0;
     int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather, fldr_range_read_acc64};
-    for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x; }
+    for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x ? FLDR_STATUS_RANGE : 0; }
+    const int to = fldr_ring_timeouts_read(reset);
+    if (to < 0) return to;
+    if (to > 0) v |= FLDR_STATUS_RING_TIMEOUT;
     return v;
 }
 
 // sizeof of the descriptor structs as this library was compiled (binding self-check: tests/test_host_cpu.py)
 extern "C" int fldr_sizeof_desc(int which) {
-    return which == 0 ? (int)sizeof(fldr_conv_desc) : which == 1 ? (int)sizeof(fldr_spk_conv_desc) : which == 2 ? (int)sizeof(fldr_prep_desc) : FLDR_E_ARG;
+    switch (which) {
+        case 0: return (int)sizeof(fldr_conv_desc);
+        case 1: return (int)sizeof(fldr_spk_conv_desc);
+        case 2: return (int)sizeof(fldr_prep_desc);
+        case 3: return (int)sizeof(fldr_pca_level);
+        case 4: return (int)sizeof(fldr_splat_acc_desc);
+        case 5: return (int)sizeof(fldr_splat_gather_desc);
+        default: return FLDR_E_ARG;
+    }
 }
 
 extern "C" int64_t fldr_spk_bytes(int C, int H, int W) {

@@ -27,7 +27,22 @@ struct PrepArgs {
     int phase;                     // bit 0: z0 / z1 + flow_t0 / flow_t1; bit 1: flowback_0 / _1 + im0_tot / im1_tot (3 = everything)
     int kx, ky;                    // sx == 2^-kx / sy == 2^-ky exactly (integer source-index arithmetic), else -1
     float rkx, rky;                // 2^-(kx+1), 2^-(ky+1)
+    // 1-D grid, XCD-aware (round 4): workgroups b and b + 8 share an XCD (and its L2), so XCD x = b & 7 walks the CONTIGUOUS
+    // range of tiles [x * tiles_per_xcd, (x + 1) * tiles_per_xcd) in row-major order — a band of rows.  Every frame plane is read
+    // twice directly and eight times through gathers a few pixels away: dealt round-robin, each of the 8 L2s fetched nearly the
+    // whole frame again (647 MB fetched for 212 MB of planes, profiles/r03_forward_pmc.txt).
+    int tiles_x, n_tiles, tiles_per_xcd;
+    uint32_t m_tiles_x;            // floor(2^32 / tiles_x) + 1
 };
+// tile index of this workgroup, or -1
+__device__ __forceinline__ int prep_tile(const PrepArgs& a, int& bx, int& by) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    const int tile = a.tiles_per_xcd ? xcd * a.tiles_per_xcd + k : (int)blockIdx.x;     // (0: row-major deal, the A/B setting)
+    if ((a.tiles_per_xcd && k >= a.tiles_per_xcd) || tile >= a.n_tiles) return -1;
+    by = a.tiles_x == 1 ? tile : (int)__umulhi((uint32_t)tile, a.m_tiles_x);
+    bx = tile - by * a.tiles_x;
+    return tile;
+}
 
 // Uniform base pointer + 32-bit byte offset: one global_load / global_store with an SGPR base and a VGPR offset, no 64-bit
 // address arithmetic per access (the kernel is bound by its VALU instruction count).  Planes are < 4 GB (host-checked).
@@ -169,9 +184,11 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int px = blockIdx.x * 64 + tx;
-    const int py = blockIdx.y * 4 + ty;
-    const int n = blockIdx.z;
+    int bx, by;
+    if (prep_tile(a, bx, by) < 0) return;
+    const int px = bx * 64 + tx;
+    const int py = by * 4 + ty;
+    const int n = blockIdx.y;
     const bool live = px < a.W && py < a.H;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
     const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;        // uniform
@@ -256,6 +273,159 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     }
 }
 
+// ---- runs of four pixels (round 4) -------------------------------------------------------------------------------------
+// The thread-per-pixel kernel above moves its 6 + 16 planes through 4-byte lanes, and this chip streams planes at 3.9-4.1 TB/s
+// that way against 5.2-6.0 TB/s through 16-byte lanes (tools/ubench/plane_bw_bench): its 1.21 GB in 311 us sat exactly on that
+// cap.  Here a thread owns FOUR horizontally adjacent pixels (x = 4 m .. 4 m + 3): the frames at the run are six 16-byte loads,
+// every output plane one 16-byte streaming store, and everything that is constant over the run is evaluated once — the row's
+// vertical source indices, and, for upsampling factors >= 8, the horizontal ones too: with sx = 2^-k, k >= 3, the source index
+// (2 x + 1 - 2^k) >> (k + 1) is the same for the four pixels of an aligned run (2 x + 1 = 8 m + r, r in {1,3,5,7}: the shift drops
+// r), so the 2x2 low-resolution neighbourhood — 8 loads and their addresses — is shared and only the fraction differs.  The
+// per-pixel arithmetic (taps, gathers, sums) is the SAME device functions in the same order: bit-identical outputs.
+// Requirements (else the kernel above runs): W % 4 == 0, kx >= 3, every plane base / stride a multiple of 16 bytes.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int R> struct PrepVec;
+template <> struct PrepVec<4> { typedef f4v T; };
+template <> struct PrepVec<2> { typedef f2v T; };
+template <int R>
+__device__ __forceinline__ typename PrepVec<R>::T prep_ldv(const float* __restrict__ base, uint32_t boff) {
+    return *reinterpret_cast<const typename PrepVec<R>::T*>(reinterpret_cast<const char*>(base) + boff);
+}
+template <int R>
+__device__ __forceinline__ void prep_stv(float* __restrict__ base, uint32_t boff, const float (&v)[R]) {
+    typename PrepVec<R>::T x;
+#pragma unroll
+    for (int j = 0; j < R; ++j) x[j] = v[j];
+#if PREP_NT
+    __builtin_nontemporal_store(x, reinterpret_cast<typename PrepVec<R>::T*>(reinterpret_cast<char*>(base) + boff));
+#else
+    *reinterpret_cast<typename PrepVec<R>::T*>(reinterpret_cast<char*>(base) + boff) = x;
+#endif
+}
+
+#ifndef PREP_QUAD_WAVES
+#define PREP_QUAD_WAVES 2                        // minimum waves per SIMD the register allocation is held to
+#endif
+// R: pixels per thread (4: 16-byte lanes; 2: 8-byte lanes, half the registers, lanes of a gather two pixels apart instead of four)
+template <int R>
+__global__ __launch_bounds__(256, R == 4 ? PREP_QUAD_WAVES : 4) void level0_prep_run_kernel(PrepArgs a) {
+#pragma clang fp contract(off)
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    int bx, by;
+    if (prep_tile(a, bx, by) < 0) return;
+    const int px0 = (bx * 64 + tx) * R;
+    const int py = by * 4 + ty;
+    const int n = blockIdx.y;
+    if (px0 >= a.W || py >= a.H) return;
+    const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
+    const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;        // uniform
+    const int64_t o1 = (int64_t)n * HW, o2 = (int64_t)n * 2 * HW, o3 = (int64_t)n * 3 * HW;
+    const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px0) * 4u;      // byte offset of the run inside a plane
+    const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;
+    const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;
+    const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
+    const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
+    const float tv = a.t[n], omt = 1.0f - tv;
+    const bool want_z = ph1 && a.z0;
+
+    // the frames at the run (direct reads, issued first; only the splat metrics use them)
+    typename PrepVec<R>::T c0[3], c1[3];
+    if (want_z) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { c0[c] = prep_ldv<R>(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldv<R>(i1 + (int64_t)c * a.i1_cstride, pixb); }
+    }
+
+    // upsampled flows at the run: one neighbourhood (see above), R fractions
+    const PrepLin ly = prep_lin(py, a.sy, a.h, a.ky, a.rky);
+    PrepLin lx[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) lx[j] = prep_lin(px0 + j, a.sx, a.w, a.kx, a.rkx);
+    const PrepQuad q = prep_quad(lo10, lo01, a.w, lx[0], ly);
+    float f10x[R], f10y[R], f01x[R], f01y[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        f10x[j] = prep_up(q, 0, lx[j], ly, a.mul, 0, 1.0f); f10y[j] = prep_up(q, 1, lx[j], ly, a.mul, 0, 1.0f);
+        f01x[j] = prep_up(q, 2, lx[j], ly, a.mul, 0, 1.0f); f01y[j] = prep_up(q, 3, lx[j], ly, a.mul, 0, 1.0f);
+    }
+    const float fpy = (float)py;
+
+    if (want_z) {
+        float z0v[R], z1v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float fpx = (float)(px0 + j);
+            const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, f01x[j], f01y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, f10x[j], f10y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
+            float acc0 = 0.0f, acc1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float w0 = fldr_tap_sample_p(t0, i1 + (int64_t)c * a.i1_cstride) * m0;
+                const float w1 = fldr_tap_sample_p(t1, i0 + (int64_t)c * a.i0_cstride) * m1;
+                acc0 += a.za0 * fabsf(c0[c][j] - w0);
+                acc1 += a.za1 * fabsf(c1[c][j] - w1);
+            }
+            z0v[j] = fldr_div_by(acc0, 3.0f, 1.0f / 3.0f);
+            z1v[j] = fldr_div_by(acc1, 3.0f, 1.0f / 3.0f);
+        }
+        prep_stv<R>(a.z0 + o1, pixb, z0v);
+        prep_stv<R>(a.z1 + o1, pixb, z1v);
+    }
+    if (ph1) {
+        float v[4][R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            v[0][j] = prep_up(q, 2, lx[j], ly, a.mul, 1, tv);  v[1][j] = prep_up(q, 3, lx[j], ly, a.mul, 1, tv);
+            v[2][j] = prep_up(q, 0, lx[j], ly, a.mul, 1, omt); v[3][j] = prep_up(q, 1, lx[j], ly, a.mul, 1, omt);
+        }
+        prep_stv<R>(a.flow_t0 + o2, pixb, v[0]); prep_stv<R>(a.flow_t0 + o2 + HW, pixb, v[1]);
+        prep_stv<R>(a.flow_t1 + o2, pixb, v[2]); prep_stv<R>(a.flow_t1 + o2 + HW, pixb, v[3]);
+    }
+    if (ph2) {
+        float fb[4][R];                                                    // flowback_0 (x, y), flowback_1 (x, y) of the run's pixels
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float fpx = (float)(px0 + j);
+            const FldrTap tb0 = fldr_grid_tap(fpx, fpy, omt * f01x[j], omt * f01y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+            const FldrTap tb1 = fldr_grid_tap(fpx, fpy, tv * f10x[j], tv * f10y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+            const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
+            const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
+            float fb0x, fb0y, fb1x, fb1y;
+            prep_sample_up2(tb0, tb0p, lo10, a, tv, fb0x, fb0y);
+            prep_sample_up2(tb1, tb1p, lo01, a, omt, fb1x, fb1y);
+            fb[0][j] = fb0x * mb0; fb[1][j] = fb0y * mb0; fb[2][j] = fb1x * mb1; fb[3][j] = fb1y * mb1;
+        }
+        prep_stv<R>(a.flowback_0 + o2, pixb, fb[0]); prep_stv<R>(a.flowback_0 + o2 + HW, pixb, fb[1]);
+        prep_stv<R>(a.flowback_1 + o2, pixb, fb[2]); prep_stv<R>(a.flowback_1 + o2 + HW, pixb, fb[3]);
+        float im[6][R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const float fpx = (float)(px0 + j);
+            const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, fb[0][j], fb[1][j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, fb[2][j], fb[3][j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const float mi0 = a.withmask ? fldr_tap_mask_p(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1) : 1.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                im[c][j] = fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0;
+                im[3 + c][j] = fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            prep_stv<R>(a.im0_tot + o3 + (int64_t)c * HW, pixb, im[c]);
+            prep_stv<R>(a.im1_tot + o3 + (int64_t)c * HW, pixb, im[3 + c]);
+        }
+    }
+}
+
+static int g_prep_quad = 0;                      // pixels per thread where the geometry allows: 0 / 1 one (the kernel above), 2, 4
+static int g_prep_xcd = 0;                       // 0: tiles dealt to the workgroups in row-major order (cross-check / A-B)
+FLDR_HOOK int fldr_debug_prep_xcd(int v) { if (v == 0 || v == 1) g_prep_xcd = v; return g_prep_xcd; }
+FLDR_HOOK int fldr_debug_prep_quad(int v) { if (v == 0 || v == 1 || v == 2 || v == 4) g_prep_quad = v; return g_prep_quad; }
+
+static inline bool prep_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
 extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->ws && d->flow_lo && d->I0 && d->I1 && d->t && d->flow_t0 && d->flow_t1 && d->flowback_0 && d->flowback_1);
     FLDR_CHECK_ARG(d->im0_tot && d->im1_tot && (!d->z0 == !d->z1) && d->N > 0 && d->h > 0 && d->w > 0 && d->H > 0 && d->W > 0);
@@ -282,7 +452,21 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     if (!(d->phase & 4))                                          // bit 2: d->ws already holds the interleaved flow (second phase of a split call)
         hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
                            reinterpret_cast<float2*>(d->ws), hw);
-    dim3 grid(fldr_cdiv(d->W, 64), fldr_cdiv(d->H, 4), d->N);
-    hipLaunchKernelGGL(level0_prep_kernel, grid, dim3(256), 0, fldr_s(stream), a);
+    const int64_t HW = (int64_t)d->H * d->W;
+    const int R = g_prep_quad == 2 ? 2 : 4;
+    const bool quad = g_prep_quad > 1 && a.kx >= 3 && !(d->W & 3) && !(HW & 3) && !(a.i0_cstride & 3) && !(a.i1_cstride & 3) && !(a.i0_bstride & 3) &&
+                      !(a.i1_bstride & 3) && prep_al16(a.I0) && prep_al16(a.I1) && (!a.z0 || (prep_al16(a.z0) && prep_al16(a.z1))) && prep_al16(a.flow_t0) &&
+                      prep_al16(a.flow_t1) && prep_al16(a.flowback_0) && prep_al16(a.flowback_1) && prep_al16(a.im0_tot) && prep_al16(a.im1_tot);
+    a.tiles_x = fldr_cdiv(d->W, quad ? 64 * R : 64);
+    a.n_tiles = a.tiles_x * fldr_cdiv(d->H, 4);
+    if ((int64_t)a.n_tiles * a.tiles_x >= (1ll << 32)) return FLDR_E_SHAPE;                      // exactness of the umulhi division
+    a.m_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x) + 1u;
+    // whole tile rows per XCD (a band of rows); g_prep_xcd == 0: tiles dealt round-robin as before (tiles_per_xcd = n_tiles on "XCD" 0 .. 7
+    // is expressed by one tile per step: see prep_tile)
+    a.tiles_per_xcd = g_prep_xcd ? fldr_cdiv(fldr_cdiv(a.n_tiles, a.tiles_x), 8) * a.tiles_x : 0;
+    dim3 grid(8 * (g_prep_xcd ? a.tiles_per_xcd : fldr_cdiv(a.n_tiles, 8)), d->N);
+    if (quad && R == 4) hipLaunchKernelGGL(level0_prep_run_kernel<4>, grid, dim3(256), 0, fldr_s(stream), a);
+    else if (quad) hipLaunchKernelGGL(level0_prep_run_kernel<2>, grid, dim3(256), 0, fldr_s(stream), a);
+    else hipLaunchKernelGGL(level0_prep_kernel, grid, dim3(256), 0, fldr_s(stream), a);
     FLDR_LAUNCH_RET();
 }

@@ -579,6 +579,9 @@ static int sa_launch(SaArgs& a, int nprob, hipStream_t s) {
 
 extern "C" int fldr_softsplat_acc64(const fldr_splat_acc_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->nprob >= 1 && d->nprob <= 2 && d->N > 0 && d->C > 0 && d->H > 0 && d->W > 0 && d->mode >= 0 && d->mode <= 3);
+    // flags: bit 0 tables of ws[j] already filled; bit 1 ws[0] holds the pair tables of fldr_splat_bounds_upsampled_pair (always laid
+    // out for TWO problems: nprob must be 2, and bit 0 would name a different layout); bit 2 whole-map walk, no tables
+    FLDR_CHECK_ARG(!(d->flags & ~7) && (!(d->flags & 2) || (d->nprob == 2 && !(d->flags & 1))));
     if (d->W > 65535 * ST_BW || d->H > 32767 * ST_BH || (int64_t)d->H * d->W * 4 >= (1ll << 32)) return FLDR_E_SHAPE;
     if ((int64_t)fldr_cdiv(d->W, ST_SBX * ST_BW) * fldr_cdiv(d->H, ST_SBY * ST_BH) > 65535) return FLDR_E_SHAPE;
     SaArgs a;

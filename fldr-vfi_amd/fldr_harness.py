@@ -151,15 +151,23 @@ def interpolate_multi(model, args, frames, t_values, pyramid=None, streams=None)
                 outs.append(one(t_values[0]))
                 ready = torch.cuda.Event()
                 ready.record(cur)
-                for i, tv in enumerate(t_values[1:]):
-                    st = streams[i % len(streams)]
-                    st.wait_event(ready)
-                    with torch.cuda.stream(st):
-                        outs.append(one(tv))
-                for st in streams:                                       # the caller's stream owns every output from here on
-                    cur.wait_stream(st)
-                for o in outs[1:]:
-                    o.record_stream(cur)
+                used = []
+                try:
+                    for i, tv in enumerate(t_values[1:]):
+                        st = streams[i % len(streams)]
+                        st.wait_event(ready)
+                        if st not in used:
+                            used.append(st)
+                        with torch.cuda.stream(st):
+                            outs.append(one(tv))
+                finally:
+                    # Join the side streams on EVERY path, before the pair cache is dropped below: the cached flow / z0 / z1 and the
+                    # pyramid belong to the current stream's allocator pool and kernels already queued on the side streams still read
+                    # them if one(tv) raised half-way; the caller's stream owns every output produced so far from here on.
+                    for st in used:
+                        cur.wait_stream(st)
+                    for o in outs[1:]:
+                        o.record_stream(cur)
     finally:
         model.pair_cache = prev
         model._pair_state = None

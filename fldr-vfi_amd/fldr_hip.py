@@ -148,6 +148,8 @@ _SIGNATURES = {
     "fldr_debug_dec3_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_dec3_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_splat_quad": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_prep_quad": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_prep_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
@@ -188,6 +190,7 @@ _SIGNATURES = {
 EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_"))
 HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_"))
 TEST_LIB_PATH = os.path.join(_HERE, "libfldr_hip_test.so")
+ABI_VERSION = 102                # include/fldr_hip.h: FLDR_VERSION
 _lib = None
 _hooks_lib = None
 
@@ -207,6 +210,14 @@ def _load(path, want_hooks):
             raise
         fn.restype = res
         fn.argtypes = args
+    # binding self-check: this file's struct mirrors against the structs the library was compiled with (fldr_sizeof_desc), and the
+    # ABI version it was written for — a stale .so next to a newer binding (or the reverse) fails here instead of corrupting memory
+    if not os.environ.get("FLDR_LIB"):
+        if l.fldr_version() != ABI_VERSION:
+            raise ImportError("%s reports ABI version %d, this binding is written for %d: rebuild it" % (path, l.fldr_version(), ABI_VERSION))
+        for which, cls in enumerate((ConvDesc, SpkConvDesc, PrepDesc, PcaLevel, SplatAccDesc, SplatGatherDesc)):
+            if l.fldr_sizeof_desc(which) != ctypes.sizeof(cls):
+                raise ImportError("%s: sizeof(%s) is %d in the library, %d in this binding" % (path, cls.__name__, l.fldr_sizeof_desc(which), ctypes.sizeof(cls)))
     return l
 
 
@@ -819,16 +830,29 @@ CONV_PRECISION = os.environ.get("FLDR_CONV_PRECISION", "split")
 def range_status(reset=True):
     """True if an activation left the range of the fp16 hi/lo split (|x| >= 65504, or NaN) since the last reset: such
     values SATURATE (finite, never inf / NaN from finite inputs) and are flagged here.  Synchronises the device."""
+    return bool(device_status(reset) & STATUS_RANGE)
+
+
+STATUS_RANGE, STATUS_RING_TIMEOUT = 1, 2
+
+
+def device_status(reset=True):
+    """fldr_range_status: bit 0 (STATUS_RANGE) an activation was saturated by the fp16 split, bit 1 (STATUS_RING_TIMEOUT) a bounded
+    wait of the convolution ring expired (that convolution's output is not to be trusted).  Synchronises the device."""
     v = lib().fldr_range_status(int(bool(reset)))
     if v < 0:
         raise FldrError("fldr_range_status failed (%d)" % v)
-    return bool(v)
+    return v
 
 
 def check_range():
     """Raise if the split-precision convolutions saturated an activation (see range_status); the remedy is
     FLDR_CONV_PRECISION=fp32 (exact fp32 MFMA everywhere)."""
-    if range_status(reset=True):
+    v = device_status(reset=True)
+    if v & STATUS_RING_TIMEOUT:
+        raise FldrError("a bounded wait of the 3x3 convolution ring expired: a wave ran on with operands that had not landed, "
+                        "the outputs since the last check are not to be trusted")
+    if v & STATUS_RANGE:
         raise FldrError("an activation exceeded the fp16 split range (|x| >= 65504 or NaN) and was saturated; "
                         "rerun with FLDR_CONV_PRECISION=fp32")
 

@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define FLDR_VERSION 101          /* major*10000 + minor*100 + patch */
+#define FLDR_VERSION 102          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_range_status bits,
+                                     fldr_sizeof_desc(3..5) — a caller built against an older header must be rebuilt */
 
 #define FLDR_E_ARG   (-1)         /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define FLDR_E_SHAPE (-2)         /* shape constraint violated (e.g. H,W not multiples of 8 for the PCA) */
@@ -364,11 +365,16 @@ int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
  * N = 1, one packed source; residual / out_f32 / out_spk for all entries or none.  Results are the bits of n_levels separate
  * fldr_conv2d_spk calls. */
 int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_levels, fldr_stream_t stream);
-int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc — binding self-check */
+int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc, 3: fldr_pca_level,
+                                                                      4: fldr_splat_acc_desc, 5: fldr_splat_gather_desc — binding self-check: a binding compares its own struct sizes */
 /* Range status of the fp16 hi/lo splits behind the split-precision convolutions (fp32-equivalent for |x| <= 65504; up to
  * 131008 the excess is kept to fp16 precision; beyond that, and for NaN inputs, values SATURATE to a finite number —
- * never inf / NaN out of finite inputs): 1 if that happened on
- * the current device since the last reset, 0 if not, negative on a HIP error.  Synchronises the device. */
+ * never inf / NaN out of finite inputs): bit 0 (FLDR_STATUS_RANGE) is set if that happened on the current device since the
+ * last reset.  Bit 1 (FLDR_STATUS_RING_TIMEOUT): one of the bounded waits inside the loader / consumer ring of the 3x3
+ * convolutions expired (never observed; it would mean a wave ran on with operands that had not landed, so the affected
+ * convolution's output must not be trusted).  0 = clean, negative on a HIP error.  Synchronises the device. */
+#define FLDR_STATUS_RANGE        1
+#define FLDR_STATUS_RING_TIMEOUT 2
 int fldr_range_status(int reset);
 
 /* ------------------------------------------------------------------------------------------

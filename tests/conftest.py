@@ -47,3 +47,13 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _product_ring_never_timed_out():
+    """After the session: the PRODUCT library's convolution ring never ran on past an expired wait (fldr_range_status bit 1) —
+    every model-level test above ran on that library, so a silent wrong-output convolution would show here."""
+    yield
+    if torch.cuda.is_available() and "fldr_hip" in sys.modules:
+        import fldr_hip
+        assert not (fldr_hip.device_status(reset=False) & fldr_hip.STATUS_RING_TIMEOUT), "a ring wait expired in libfldr_hip.so"

@@ -112,6 +112,45 @@ def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
     assert torch.equal(r["im0_tot"], hip.bwarp(I0, fb0, True)) and torch.equal(r["im1_tot"], hip.bwarp(I1, fb1, True))
 
 
+@pytest.mark.parametrize("shape", [(1, 20, 70, 8, 0.5, 6.0), (2, 9, 33, 8, 0.125, 60.0), (1, 6, 40, 16, 0.75, 3.0), (1, 37, 45, 8, 0.3, 400.0)])
+def test_level0_prep_runs_of_four_bit_identical(hip, hooks, dev, shape):
+    """Round 4: the level-0 prep kernel with a run of four pixels per thread (16-byte loads / streaming stores, the low-resolution
+    neighbourhood shared by the run) and XCD-banded tiles against the thread-per-pixel kernel in row-major order: every plane
+    bit-identical — contiguous frames, frames read in place as channel-strided views, the two-phase call, wild flows, partial
+    tiles (W = 560: 2.19 tiles of 256 pixels) — and the fallback on planes that are not 16-byte aligned."""
+    N, h, w, up, tv, amp = shape
+    H, W = h * up, w * up
+    g = _gen(77)
+    flow_lo = ((torch.rand(N, 4, h, w, generator=g) - 0.5) * amp).to(dev)
+    x = (torch.rand(N, 3, 2, H, W, generator=g) * 2 - 1).to(dev)
+    t4 = torch.full((N, 1, 1, 1), tv).to(dev)
+    keys = ("z0", "z1", "flow_t0", "flow_t1", "flowback_0", "flowback_1", "im0_tot", "im1_tot")
+    I0, I1 = x[:, :, 0], x[:, :, 1]                                       # strided views: read in place
+    hooks.fldr_debug_prep_quad(0); hooks.fldr_debug_prep_xcd(0)
+    ref = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+    try:
+        for quad, xcd in ((0, 1), (2, 0), (4, 0), (4, 1)):
+            hooks.fldr_debug_prep_quad(quad); hooks.fldr_debug_prep_xcd(xcd)
+            r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+            for k in keys:
+                assert torch.equal(r[k], ref[k]), (quad, xcd, k)
+            rc = hip.level0_prep(flow_lo, I0.contiguous(), I1.contiguous(), t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+            st = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True, phase=1)
+            st = hip.level0_prep(None, None, None, None, H, W, 0, 0, state=st)
+            for k in keys:
+                assert torch.equal(rc[k], ref[k]) and torch.equal(st[k], ref[k]), (quad, xcd, k)
+        # frames at a 4-byte offset: the run kernel's 16-byte loads do not apply, the call must fall back and still agree
+        hooks.fldr_debug_prep_quad(4)
+        buf = torch.empty(x.numel() + 1, device=dev)
+        buf[1:] = x.reshape(-1)
+        xo = buf[1:].view_as(x)
+        r = hip.level0_prep(flow_lo, xo[:, :, 0], xo[:, :, 1], t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+        for k in keys:
+            assert torch.equal(r[k], ref[k]), ("misaligned", k)
+    finally:
+        hooks.fldr_debug_prep_quad(0); hooks.fldr_debug_prep_xcd(0)
+
+
 @pytest.mark.parametrize("shape", [(1, 27, 60, 8, 0.5, 6.0), (2, 13, 21, 8, 0.25, 40.0), (1, 9, 15, 4, 1.0, 2.0), (1, 34, 40, 8, 0.0, 10.0)])
 def test_splat_bounds_from_low_resolution_flow(hip, oracle, dev, shape):
     """fldr_splat_bounds_upsampled (the bounds table of the level-0 image splats from the LOW-resolution flow): every block /

@@ -160,11 +160,20 @@ def corr():
 def prep():
     """fldr_level0_prep at the 4K shape (x8 upsampling of a 288x480 flow pair, three rotated frame pairs)."""
     H, W, up = 2304, 3840, 8
-    lo = torch.randn(1, 4, H // up, W // up, device=dev) * 1.5
+    noise = float(os.environ.get("PREP_NOISE", "0.02"))                   # low-resolution pixels: 0.02 = the bench's rigid shift, 1.5 = incoherent gathers
+    lo = torch.tensor([-0.75, -0.5, 0.75, 0.5], device=dev).view(1, 4, 1, 1) + torch.randn(1, 4, H // up, W // up, device=dev) * noise
     frames = [torch.rand(1, 3, 2, H, W, device=dev) * 2 - 1 for _ in range(3)]
     t4 = torch.tensor([0.5], device=dev).view(1, 1, 1, 1)
-    us = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True), 16)
-    print("level0_prep 2304x3840: %.1f us" % us, flush=True)
+    ref = None
+    for rep in range(2):
+        for quad, xcd in ((0, 0), (2, 0), (2, 1), (4, 0)):
+            L.fldr_debug_prep_quad(quad); L.fldr_debug_prep_xcd(xcd)
+            us = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True), 16)
+            r = hip.level0_prep(lo, frames[0][:, :, 0], frames[0][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True)
+            same = ref is None or all(torch.equal(r[k], ref[k]) for k in ("z0", "z1", "flow_t0", "flow_t1", "flowback_0", "flowback_1", "im0_tot", "im1_tot"))
+            ref = ref or r
+            print("level0_prep 2304x3840, %s, %s: %.1f us (same bits: %s)" % ("runs of %d px" % quad if quad else "thread per px", "XCD bands" if xcd else "row-major deal", us, same), flush=True)
+    L.fldr_debug_prep_quad(0); L.fldr_debug_prep_xcd(0)
 
 
 if __name__ == "__main__":
