@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--incl-ingest-steps", type=int, default=60, help="steps of the informational uint8-in -> uint8-out run with the ingest kernels inside the loop (0 = skip)")
     ap.add_argument("--multi-t-pairs", type=int, default=4, help="pairs of the informational 4096x2160 7-outputs-per-pair run, BASELINE config 3 (0 = skip)")
     ap.add_argument("--fp16-mode-steps", type=int, default=60, help="steps of the informational fp16-input convolution run (BASELINE config 5; 0 = skip)")
+    ap.add_argument("--xtest-dir", default=None, help="X-Test style folder (<dir>/<type>/<scene>/*.png, 33 frames per scene): after the timed region every rank "
+                                                      "evaluates its share of the pairs (8x: 7 outputs per pair) and parity.x_test_psnr / x_test carry the mean PSNR / SSIM-Y")
+    ap.add_argument("--xtest-multiple", type=int, default=8)
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -209,17 +212,25 @@ def main():
     import torch
     import torch.distributed as dist
     from fldr_harness import shard_pairs, max_over_ranks, gather_floats
-    if world > 1:
+    # FLDR_BENCH_FORCE_PG=1: create the process group (and run every barrier / reduction / gather of the multi-GPU path) at world
+    # size 1 too — the RCCL rehearsal a 1-GPU box allows (tests/test_gpu_parity.py::test_bench_rccl_process_group_world_size_one)
+    use_pg = world > 1 or os.environ.get("FLDR_BENCH_FORCE_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
     gpu = not a.dry
     if gpu:
         torch.cuda.set_device(local_rank)
         device = torch.device("cuda", local_rank)
     else:
         device = torch.device("cpu")
-    if world > 1:
-        if a.backend == "nccl" and gpu:
-            dist.init_process_group("nccl", device_id=device)
+    pg_backend = None
+    if use_pg:
+        pg_backend = "nccl" if (a.backend == "nccl" and gpu) else "gloo"
+        if pg_backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)              # RCCL on ROCm
         else:
             dist.init_process_group("gloo")
 
@@ -228,7 +239,7 @@ def main():
             torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
 
     npairs = max(a.pairs, a.streams, 1)
@@ -413,6 +424,9 @@ def main():
             finally:
                 fldr_hip.CONV_PRECISION = prev
     per_rank = gather_floats(a.steps / dt_local, device)
+    x_test = None
+    if gpu and a.xtest_dir:                            # BASELINE metric, second half: PSNR on X-Test when the data is there (every rank: collective)
+        x_test = Hn.evaluate_dir(a.xtest_dir, multiple=a.xtest_multiple, model=model, args=args, device=device, rank=rank, world=world)
 
     if rank == 0:
         hp = ((a.height + 255) // 256 * 256, (a.width + 255) // 256 * 256)
@@ -429,6 +443,9 @@ def main():
                        "pairs_in_flight": a.streams, "distinct_pairs_per_gpu": npairs,
                        "per_rank_pairs_per_s": [round(x, 2) for x in per_rank]},
         }
+        if use_pg:
+            res["config"]["process_group"] = {"backend": pg_backend + (" (RCCL)" if pg_backend == "nccl" else ""), "world_size": dist.get_world_size(),
+                                              "forced_at_world_size_1": world == 1}
         if a.dry:
             res["dry"] = True
             res["data"] = "none (dry run: 1 ms sleep per step)"
@@ -462,8 +479,11 @@ def main():
                 with torch.no_grad():
                     g0 = Hn.interpolate(model, args, frames[0], t, pyramid=pyrs[0]).cpu()
                 res["cpu_baseline"], res["parity"] = cpu_baseline(frames[0].cpu(), t.cpu(), g0)
+            if x_test is not None:
+                res["x_test"] = dict(x_test, dir=a.xtest_dir, multiple=a.xtest_multiple)
+                res.setdefault("parity", {})["x_test_psnr"] = x_test["psnr"]
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256) void splat_tile_kernel(const float* __restrict
     }
 }
 
-#endif  // FLDR_TEST_HOOKS
+// (the test-build guard continues through the band kernel below)
 
 // ------------------------------------------------------------------------------------------------
 // Band splat: destination-owned, NO atomics at all.
@@ -832,6 +832,10 @@ static void splat_band_launch(const float* img, int64_t ibs, int64_t ics, const 
     }
 }
 
+#endif  // FLDR_TEST_HOOKS (tile + band kernels)
+
+// floats of one flow-bounds table (block + super-block intervals): the workspace of fldr_splat_bounds_upsampled[_pair] /
+// fldr_softsplat_acc64 (and of the test build's fldr_softsplat_tile)
 extern "C" int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return FLDR_E_ARG;
     const int64_t nsb = (int64_t)fldr_cdiv(W, ST_SBX * ST_BW) * fldr_cdiv(H, ST_SBY * ST_BH);
@@ -851,7 +855,6 @@ static void splat_tile_launch(const float* img, int64_t ibs, int64_t ics, const 
         hipLaunchKernelGGL((splat_tile_kernel<MODE, 12, 64, 16>), grid, dim3(256), 0, s, img, ibs, ics, flow, metric, blk, sbt, out, C, H, W, groups, nsb_x, nsb);
     }
 }
-#endif  // FLDR_TEST_HOOKS
 
 // FunctionSoftsplat (softSplat.py:320-352) end to end, destination-owned.  ws: fldr_softsplat_tile_ws_floats floats.
 static int g_splat_tile_variant = 1;     // 0: LDS-atomic tiles, 1: claim-and-add bands
@@ -889,7 +892,6 @@ static int splat_tile_run(const float* img, int64_t img_bstride, int64_t img_cst
         }
         FLDR_LAUNCH_RET();
     }
-#ifdef FLDR_TEST_HOOKS
     switch (mode) {
         case 0: splat_tile_launch<0>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
         case 1: splat_tile_launch<1>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
@@ -897,9 +899,6 @@ static int splat_tile_run(const float* img, int64_t img_bstride, int64_t img_cst
         default: splat_tile_launch<3>(img, img_bstride, img_cstride, flow, metric, blk, sbt, out, N, C, H, W, nsb_x, nsb, s); break;
     }
     FLDR_LAUNCH_RET();
-#else
-    return FLDR_E_ARG;                                               // (unreachable: the variant switch is a test-build hook)
-#endif
 }
 
 extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
@@ -907,6 +906,15 @@ extern "C" int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride
                                            fldr_stream_t stream) {
     return splat_tile_run(img, img_bstride, img_cstride, flow, metric, out, ws, N, C, H, W, mode, 0, stream);
 }
+
+// fldr_softsplat_tile_strided with the bounds table already in `ws` (any table whose block / super-block intervals CONTAIN the
+// flow values of their pixels gives the exact result: the table only selects candidate sources).
+extern "C" int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                              const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                              fldr_stream_t stream) {
+    return splat_tile_run(img, img_bstride, img_cstride, flow, metric, out, ws, N, C, H, W, mode, 1, stream);
+}
+#endif  // FLDR_TEST_HOOKS (the destination-owned splats of rounds 1-2: fldr_softsplat_tile*)
 
 // The bounds table of `ws` for flow = F.interpolate(scale * flow_lo, (H, W), bilinear) * mul, from flow_lo alone (conservative:
 // see splat_bounds_up_kernel).  flow_lo: sample n at flow_lo + n*lo_bstride, [2,h,w] contiguous; scale_mode 0: 1, 1: t[n],
@@ -939,12 +947,4 @@ extern "C" int fldr_splat_bounds_upsampled_pair(const float* flow_l, int64_t lo_
     float* sbt = ws + (int64_t)2 * N * nsb * ST_SB_BLOCKS * 4;
     splat_bounds_up_launch(flow_l, lo_bstride ? lo_bstride : 4 * (int64_t)h * w, t, 0, mul, blk, sbt, h, w, H, W, nsb_x, nsb, pair, N, 2 * N, fldr_s(stream));
     FLDR_LAUNCH_RET();
-}
-
-// fldr_softsplat_tile_strided with the bounds table already in `ws` (any table whose block / super-block intervals CONTAIN the
-// flow values of their pixels gives the exact result: the table only selects candidate sources).
-extern "C" int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
-                                              const float* metric, float* out, float* ws, int N, int C, int H, int W, int mode,
-                                              fldr_stream_t stream) {
-    return splat_tile_run(img, img_bstride, img_cstride, flow, metric, out, ws, N, C, H, W, mode, 1, stream);
 }

@@ -277,6 +277,110 @@ def synthetic_pair_varying(H, W, seed=0, device="cpu", zoom=1.012, rot_deg=0.25,
 
 
 
+# ---- dataset-shaped evaluation (X-Test / Inter4K style folders of PNG frames) ----------------------------------------------
+def list_xtest_triplets(root, multiple=8, t_step_size=32):
+    """The sample list of utils.make_2D_dataset_X_Test (utils.py:414-432) — <root>/<type>/<scene>/*.png, consecutive frames
+    t_step_size apart are (I0, I1), the multiple - 1 frames between them the targets at t = k / multiple — GROUPED BY PAIR,
+    so that the pair-invariant stage runs once per pair: [(I0_path, I1_path, 'type/scene', [(It_path, t), ...]), ...]."""
+    import glob
+    ts = np.linspace(1 / multiple, 1 - 1 / multiple, multiple - 1)
+    pairs = []
+    for type_folder in sorted(glob.glob(os.path.join(root, '*', ''))):
+        for scene_folder in sorted(glob.glob(os.path.join(type_folder, '*', ''))):
+            frames = sorted(glob.glob(scene_folder + '*.png'))
+            for idx in range(0, len(frames), t_step_size):
+                if idx == len(frames) - 1 or idx + t_step_size >= len(frames):
+                    break
+                targets = [(frames[idx + int((t_step_size // multiple) * (m + 1))], float(ts[m])) for m in range(multiple - 1)]
+                pairs.append((frames[idx], frames[idx + t_step_size], os.path.relpath(scene_folder, root), targets))
+    return pairs
+
+
+def load_bgr_u8(path):
+    """cv2.imread(path) without cv2: uint8 [H,W,3] in BGR order (the checkpoint was trained on cv2's channel order)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert("RGB"))[:, :, ::-1])
+
+
+def reduce_sums(values, device="cpu"):
+    """SUM-reduce a short list of floats over the ranks (fp64; [sum PSNR, sum SSIM, count]: 24 bytes, the only collective of an
+    evaluation run — main.py:960-962 keeps these in AverageClass on its single process)."""
+    import torch.distributed as dist
+    t = torch.tensor([float(v) for v in values], device=device, dtype=torch.float64)
+    if _collectives_on():
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
+
+
+def evaluate_dir(root, multiple=8, t_step_size=32, model=None, args=None, device=None, want_ssim=True, rank=0, world=1,
+                 predict=None, max_pairs=None, log=None):
+    """main.test() on a directory (main.py:815-911, utils.py:208-251,644-669): walk X-Test-style folders, interpolate the
+    multiple - 1 intermediate frames of every pair with the pair-invariant cache, score each against its ground-truth PNG with
+    PSNR (data_range 255, all channels) and SSIM-Y on the DEVICE (fldr_frame_metrics / fldr_ssim_y_u8: only uint8 frames cross
+    PCIe), pairs dealt round-robin to the ranks, three sums reduced at the end.
+    predict(frames_u8 [1,2,3,H,W] uint8 on `device`, ts, targets_u8 list of [1,3,H,W]) -> [(psnr, ssim or None), ...] replaces the
+    model (the CPU test of the walk / sharding / reduction uses it).
+    -> dict(psnr, ssim, frames, pairs, per_t={t: psnr}, scenes={scene: psnr}) — the same on every rank."""
+    pairs = list_xtest_triplets(root, multiple, t_step_size)
+    if not pairs:
+        raise RuntimeError("Found 0 files in subfolders of: " + root + "\n")            # utils.py:454-458
+    if max_pairs:
+        pairs = pairs[:max_pairs]
+    if predict is None:
+        import fldr_hip
+        if model is None:
+            model, device, args = prepare_model(device, args=args)
+        device = device or next(model.parameters()).device
+
+        def predict(frames_u8, ts, targets_u8):
+            B, T, C, H, W = frames_u8.shape
+            prev = model.pair_cache
+            model.pair_cache = True
+            res = []
+            try:
+                with torch.no_grad():
+                    pyr = fldr_hip.ingest_pyramid(frames_u8, args.S_tst + 1)
+                    for tv, tgt in zip(ts, targets_u8):
+                        t = torch.full((B, 1), float(tv), device=frames_u8.device, dtype=torch.float32)
+                        pred, _ = model([None] * (args.S_tst + 1), t, normInput=pyr, is_training=False, validation=False)
+                        sse, img = fldr_hip.frame_metrics(pred, min(H, pred.shape[2]), min(W, pred.shape[3]), tgt, want_u8=True)
+                        ss = fldr_hip.ssim_y_u8(img, tgt) if want_ssim else None
+                        res.append((sse, ss))
+                # one synchronisation per pair, after all its outputs are queued
+                out = []
+                for sse, ss in res:
+                    mse = float(sse[0].item()) / (3.0 * H * W)
+                    out.append((float("inf") if mse == 0 else 10 * math.log10(255.0 ** 2 / mse), float(ss[0].item()) if ss is not None else None))
+                fldr_hip.check_range()
+                return out
+            finally:
+                model.pair_cache = prev
+                model._pair_state = None
+    dev = device if device is not None else "cpu"
+    sums = {"psnr": 0.0, "ssim": 0.0, "n": 0.0}
+    per_t, scenes = {}, {}
+    for i in shard_pairs(len(pairs), rank, world):
+        p0, p1, scene, targets = pairs[i]
+        u8 = torch.from_numpy(np.stack([load_bgr_u8(p0), load_bgr_u8(p1)], 0)).permute(0, 3, 1, 2).unsqueeze(0).contiguous().to(dev)
+        tg = [torch.from_numpy(load_bgr_u8(pt)).permute(2, 0, 1).unsqueeze(0).contiguous().to(dev) for pt, _ in targets]
+        for (pt, tv), (ps, ss) in zip(targets, predict(u8, [tv for _, tv in targets], tg)):
+            sums["psnr"] += ps
+            sums["ssim"] += ss if ss is not None else 0.0
+            sums["n"] += 1
+            per_t.setdefault(round(tv, 6), []).append(ps)
+            scenes.setdefault(scene, []).append(ps)
+            if log:
+                log("%s %s t=%.3f PSNR %.3f%s" % (scene, os.path.basename(pt), tv, ps, "" if ss is None else " SSIM %.5f" % ss))
+    tot = reduce_sums([sums["psnr"], sums["ssim"], sums["n"]], dev)
+    keys_t = sorted({round(float(t), 6) for t in np.linspace(1 / multiple, 1 - 1 / multiple, multiple - 1)})
+    pt = reduce_sums([sum(per_t.get(k, [])) for k in keys_t] + [len(per_t.get(k, [])) for k in keys_t], dev)
+    n = max(tot[2], 1.0)
+    return {"psnr": tot[0] / n, "ssim": (tot[1] / n) if want_ssim else None, "frames": int(tot[2]), "pairs": len(pairs),
+            "per_t": {k: pt[j] / max(pt[len(keys_t) + j], 1.0) for j, k in enumerate(keys_t)},
+            "scenes_this_rank": {k: sum(v) / len(v) for k, v in scenes.items()}}
+
+
 # ---- data-parallel helpers (one process per GPU; frame pairs are independent: SURVEY 8e) -----------------
 def shard_pairs(n_pairs, rank, world):
     """Static round-robin of frame PAIRS (not outputs) over ranks: pair i -> rank i % world, so that all t values
@@ -284,10 +388,19 @@ def shard_pairs(n_pairs, rank, world):
     return [i for i in range(n_pairs) if i % world == rank]
 
 
+def _collectives_on():
+    """True when a process group exists and its collectives should run: more than one rank, or FLDR_BENCH_FORCE_PG=1 (the
+    world-size-1 RCCL rehearsal: the same all_reduce / all_gather calls on device tensors as on an 8-GPU node)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("FLDR_BENCH_FORCE_PG") == "1"
+
+
 def max_over_ranks(value, device="cpu"):
     """MAX-reduce a Python float over the default process group (no-op without one)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return float(value)
     t = torch.tensor([value], device=device, dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -299,7 +412,7 @@ def reduce_psnr(psnr_sum, count, device="cpu"):
     evaluation loop needs (16 bytes; main.py:962 keeps these in AverageClass on a single process)."""
     import torch.distributed as dist
     t = torch.tensor([psnr_sum, float(count)], device=device, dtype=torch.float64)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _collectives_on():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return (t[0] / t[1].clamp(min=1)).item(), int(t[1].item())
 
@@ -307,7 +420,7 @@ def reduce_psnr(psnr_sum, count, device="cpu"):
 def gather_floats(value, device="cpu"):
     """One float per rank -> list over ranks (all_gather of 8 bytes; [value] without a process group)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not _collectives_on():
         return [float(value)]
     mine = torch.tensor([value], device=device, dtype=torch.float64)
     out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]

@@ -187,8 +187,9 @@ _SIGNATURES = {
 
 # The integration ABI (include/fldr_hip.h: what libfldr_hip.so exports) and the tuning / cross-check hooks that only the test
 # build libfldr_hip_test.so has (include/fldr_hip_test_hooks.h).
-EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_"))
-HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_"))
+_TEST_BUILD_ONLY = ("fldr_softsplat_tile", "fldr_softsplat_tile_strided", "fldr_softsplat_tile_prebounded")    # retired splat generation
+EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_") and n not in _TEST_BUILD_ONLY)
+HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_") or n in _TEST_BUILD_ONLY)
 TEST_LIB_PATH = os.path.join(_HERE, "libfldr_hip_test.so")
 ABI_VERSION = 102                # include/fldr_hip.h: FLDR_VERSION
 _lib = None
@@ -359,13 +360,12 @@ _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 
 
 # Forward-splat kernels (FLDR_SPLAT = auto | acc64 | strip | tile):
-#   "acc64" (= auto, default since round 3): destination-owned tiles with fp64 LDS atomics (splat_acc64_kernels.hip);
-#   "strip": global float atomics with in-register merging + a normalisation pass (warp_kernels.hip);
-#   "tile":  destination-owned bands, no atomics (splat_tile_kernels.hip): every wave owns a 128x8 band of the output in
-#            LDS, finds the sources that reach it through per-block flow bounds and adds them with plain LDS
-#            read-modify-write (register-merged fast path, claim rounds otherwise); writes the normalised band once;
-#   "auto" (default): tile for <= 3 channels (the level-0 image splats: 360 -> 190 us each incl. memset/normalisation),
-#            strip for feature maps (the 12-channel band variant needs > 256 VGPRs and is slower).
+#   "acc64" (= auto, default since round 3): destination-owned tiles with fp64 LDS atomics (splat_acc64_kernels.hip): every
+#            splat of the forward and FunctionSoftsplat;
+#   "strip": global float atomics with in-register merging + a normalisation pass (warp_kernels.hip): the raw operator
+#            _FunctionSoftsplat (fldr_softsplat_fwd accumulates into the caller's tensor) and fldr_softsplat_fused;
+#   "tile":  the destination-owned bands of rounds 1-2 (no atomics, claim rounds; splat_tile_kernels.hip) — a retired generation,
+#            compiled into the TEST build only since round 4 (cross-check of acc64): selecting it outside fldr_hip.test_hooks() raises.
 SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 # Warped feature maps of the flow estimator (fLDRnet.py:386-387): "strip" (default) = the global-atomic scatter kernel +
 # normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
@@ -446,6 +446,9 @@ def softsplat_fused(img, flow, metric, mode, out=None, scratch=None, kernel=None
         ws = bounds_ws if bounds_ws is not None else torch.empty(lib().fldr_softsplat_tile_ws_floats(N, H, W), device=img.device, dtype=torch.float32)
         if out is None:
             out = torch.empty(N, C, H, W, device=img.device, dtype=torch.float32)
+        if not hasattr(lib(), "fldr_softsplat_tile_strided"):
+            raise FldrError("the band splat (kernel='tile' / FLDR_SPLAT=tile) is a retired generation kept in the test build only: "
+                            "enter fldr_hip.test_hooks() (tests, tools) — the product splats run on fldr_softsplat_acc64")
         fn = lib().fldr_softsplat_tile_prebounded if bounds_ws is not None else lib().fldr_softsplat_tile_strided
         _check(fn(ctypes.c_void_p(img.data_ptr()), ibs, ics, _dev(flow, "flow"), _dev(metric, "metric") if metric is not None else None,
                   _dev(out, "out"), _dev(ws, "ws"), N, C, H, W, _MODES[mode], _stream()), "fldr_softsplat_tile")

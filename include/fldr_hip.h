@@ -81,7 +81,7 @@ int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stre
 
 /* FunctionSoftsplat (softSplat.py:320-352) with destination-owned tiles and fp64 LDS atomics (csrc/splat_acc64_kernels.hip):
  * every workgroup owns an output tile as fp64 accumulators in LDS, the sources that can reach it (flow-bounds tables, as for
- * fldr_softsplat_tile) add the reference kernel's fp32 corner products (softSplat.py:40-51) with ds_add_f64, and the
+ * the retired fldr_softsplat_tile of the test build) add the reference kernel's fp32 corner products (softSplat.py:40-51) with ds_add_f64, and the
  * normalised tile is written once: no global atomics, no accumulator tensor / memset / normalisation pass; exact for any
  * flow; independent of the summation order to ~1e-16 (the reference's own fp32 atomics are unordered).  One or
  * two problems of the same shape per call (the two image splats of fLDRnet.py:449-450, the two feature splats of :386-387).
@@ -115,21 +115,11 @@ int fldr_softsplat_acc64(const fldr_splat_acc_desc* desc, fldr_stream_t stream);
 int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric_or_null, void* out_spk,
                              float* scratch, int N, int C, int H, int W, int mode, fldr_stream_t stream);
 
-/* The same operator with destination-owned tiles (csrc/splat_tile_kernels.hip): each workgroup owns an output tile,
- * accumulates the sources that reach it with LDS atomics and writes the normalised tile once — no global atomics, no
- * accumulator tensor, no normalisation pass; exact for arbitrary flows (flow bounds per 64x4 block and 256x64
- * super-block select the candidate sources; a full scan is the fallback).  ws: fldr_softsplat_tile_ws_floats(N,H,W)
- * floats of workspace.  Results equal fldr_softsplat_fused up to fp32 summation order (the reference's own atomics are
- * unordered). */
+/* Floats of ONE flow-bounds table (intervals of the flow per 64x4 block and 256x64 super-block: what selects a destination tile's
+ * candidate sources) for N samples of an H x W map: the workspace unit of fldr_splat_bounds_upsampled[_pair] / fldr_softsplat_acc64.
+ * (The destination-owned splats of rounds 1-2 that shared these tables — fldr_softsplat_tile* — live in the test build only since
+ * round 4: include/fldr_hip_test_hooks.h.) */
 int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W);
-int fldr_softsplat_tile(const float* img, const float* flow, const float* metric_or_null, float* out, float* ws,
-                        int N, int C, int H, int W, int mode, fldr_stream_t stream);
-/* The same with a strided image: sample n, channel c at img + n*img_bstride + c*img_cstride (floats), each [H,W] plane
- * contiguous — the frames I0 / I1 are the views x_l[0][:, :, 0] / [:, :, 1] of the [B,3,2,H,W] input (fLDRnet.py:130-131)
- * and need no copy. */
-int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
-                                const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
-                                fldr_stream_t stream);
 
 /* The level-0 image splats (fLDRnet.py:449-450) take flows that are bilinear upsamplings of a low-resolution field
  * (flow_t = F.interpolate(scale * flow_lo, (H, W)) * mul, fLDRnet.py:404-405,419-422).  Their bounds table follows from the
@@ -137,15 +127,10 @@ int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t i
  * its roundings), so the pre-pass over the two full-resolution flow planes is not needed:
  *   fldr_splat_bounds_upsampled  fills ws (fldr_softsplat_tile_ws_floats(N,H,W) floats) from flow_lo — sample n at
  *                                flow_lo + n*lo_bstride, [2,h,w] contiguous; scale_mode 0: 1, 1: t[n], 2: 1 - t[n];
- *   fldr_softsplat_tile_prebounded = fldr_softsplat_tile_strided that takes the table in ws as given.  Any table whose block /
- *                                super-block intervals contain the flow values of their pixels gives the exact result (the
- *                                table only selects candidate sources); summation order, and with it the last bits, may
- *                                differ from the exact-bounds call. */
+ * Any table whose block / super-block intervals contain the flow values of their pixels gives the exact result (the table only
+ * selects candidate sources). */
 int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstride, const float* t_or_null, int scale_mode, float mul,
                                 float* ws, int N, int h, int w, int H, int W, fldr_stream_t stream);
-int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
-                                   const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
-                                   fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * PWC cost volume — replaces OpticalFlow/correlation.py (forward only).

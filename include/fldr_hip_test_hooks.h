@@ -36,7 +36,21 @@ int fldr_debug_dec3_xshift(int v);                                 /* tile-grid 
 int fldr_debug_splat_group_fold(int v);                            /* fldr_softsplat_acc64, > 3 channels: 1 all channel groups of a tile in one workgroup where the map is large enough, 0 (default) one group per workgroup; other: query.  Same results */
 int fldr_debug_prep_quad(int v);                                  /* fldr_level0_prep: 1 (default) runs of four pixels per thread where x8-or-more upsampling, W % 4 == 0 and 16-byte aligned planes allow, 0 one pixel per thread; other: query.  Bit-identical results */
 int fldr_debug_prep_xcd(int v);                                   /* tile order of fldr_level0_prep: 1 (default) a contiguous band of tile rows per XCD, 0 row-major deal; other: query.  Identical results */
-int fldr_debug_conv_occupancy(int* out4);                          /* occupancy query of the fp32-MFMA convolution kernels */
+int fldr_debug_conv_occupancy(int* out4);
+
+/* The destination-owned splats of rounds 1-2 (csrc/splat_tile_kernels.hip: claim-and-add bands without atomics; the LDS-f32-atomic
+ * tiles behind fldr_debug_splat_tile_variant(0)), retired from the product in round 4 — every splat of the forward and
+ * FunctionSoftsplat run on fldr_softsplat_acc64.  Kept as cross-checks of it (tests, tools/stress_shapes.py).  FunctionSoftsplat
+ * end to end; ws: fldr_softsplat_tile_ws_floats(N,H,W) floats; _strided reads sample n, channel c at img + n*img_bstride +
+ * c*img_cstride; _prebounded takes the bounds table in ws as given (fldr_splat_bounds_upsampled). */
+int fldr_softsplat_tile(const float* img, const float* flow, const float* metric_or_null, float* out, float* ws,
+                        int N, int C, int H, int W, int mode, fldr_stream_t stream);
+int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                fldr_stream_t stream);
+int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
+                                   const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
+                                   fldr_stream_t stream);                          /* occupancy query of the fp32-MFMA convolution kernels */
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,56 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 WEIGHTS = os.path.join(PKG, "weights", "fLDRnet_X4K1000FPS_exp1_best_PSNR.npz")
 
 
+# A GPU-clean launcher for tests that must start OTHER GPU programs (the world-size-1 RCCL rehearsal of bench.py): a process that
+# has initialised the GPU must not fork + exec another program on this pool, so the helper is started here, in pytest_configure,
+# before any test or fixture has touched the GPU; it never imports torch, only runs the commands it is sent and returns their output.
+_LAUNCHER_CODE = r"""
+import json, subprocess, sys
+for line in sys.stdin:
+    req = json.loads(line)
+    try:
+        r = subprocess.run(req["cmd"], capture_output=True, text=True, timeout=req.get("timeout", 600), env=req.get("env"))
+        out = {"rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr}
+    except Exception as e:                                  # timeout etc.
+        out = {"rc": -999, "stdout": "", "stderr": repr(e)}
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
+"""
+_launcher = None
+
+
 def pytest_configure(config):
+    global _launcher
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    expr = config.getoption("markexpr", "") or ""
+    if "gpu" in expr and "not gpu" not in expr and _launcher is None:
+        import subprocess
+        _launcher = subprocess.Popen([sys.executable, "-c", _LAUNCHER_CODE], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+
+
+def pytest_unconfigure(config):
+    global _launcher
+    if _launcher is not None:
+        try:
+            _launcher.stdin.close()
+            _launcher.wait(timeout=30)
+        except Exception:
+            _launcher.kill()
+        _launcher = None
+
+
+@pytest.fixture(scope="session")
+def clean_launcher():
+    """run(cmd, env, timeout) -> dict(rc, stdout, stderr), executed by the GPU-clean helper process started in pytest_configure."""
+    import json
+    if _launcher is None or _launcher.poll() is not None:
+        pytest.skip("the GPU-clean launcher only exists in `-m gpu` sessions")
+
+    def run(cmd, env=None, timeout=600):
+        _launcher.stdin.write(json.dumps({"cmd": cmd, "env": env, "timeout": timeout}) + "\n")
+        _launcher.stdin.flush()
+        return json.loads(_launcher.stdout.readline())
+    return run
 
 
 @pytest.fixture(scope="session")

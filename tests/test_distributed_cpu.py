@@ -92,3 +92,24 @@ def test_bench_launcher_failure_modes():
     assert r.returncode != 0 and not js                     # a failing child fails the parent, no result line
     r, js = _run_bench(["--gpus", "2", "--dry"], {"WORLD_SIZE": "3", "RANK": "0"})
     assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_bench_forced_process_group_world_size_one_gloo_dry():
+    """FLDR_BENCH_FORCE_PG=1 under `torch.distributed.run --nproc-per-node 1`: the process group, barriers, MAX reduction and
+    all_gather of the multi-GPU path run at world size 1 (CPU twin — gloo, --dry — of the RCCL test in tests/test_gpu_parity.py)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["FLDR_BENCH_FORCE_PG"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--backend", "gloo", "--dry", "--steps", "3",
+           "--warmup", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    js = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(js) == 1 and js[0]["n_gpus"] == 1
+    pg = js[0]["config"]["process_group"]
+    assert pg["backend"] == "gloo" and pg["world_size"] == 1 and pg["forced_at_world_size_1"] is True
+    assert len(js[0]["config"]["per_rank_pairs_per_s"]) == 1

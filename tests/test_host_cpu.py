@@ -30,7 +30,8 @@ def test_library_exports_every_declared_symbol():
     assert exported == declared, sorted(exported ^ declared)
     # ... the TEST build adds exactly the hooks of include/fldr_hip_test_hooks.h (minus those of the stamp builds)
     hooks_hdr = open(os.path.join(ROOT, "include", "fldr_hip_test_hooks.h")).read()
-    hooks_decl = set(re.findall(r"\b(fldr_debug_[a-z0-9_]+)\s*\(", hooks_hdr))
+    hooks_decl = set(re.findall(r"\b(fldr_[a-z0-9_]+)\s*\(", hooks_hdr))        # fldr_debug_* and the retired fldr_softsplat_tile*
+    assert not [n for n in exported if n.startswith("fldr_softsplat_tile") and n != "fldr_softsplat_tile_ws_floats"], sorted(exported)
     tsyms = subprocess.run(["nm", "-D", "--defined-only", fldr_hip.TEST_LIB_PATH], capture_output=True, text=True, check=True).stdout
     texported = set(re.findall(r"\b(fldr_[a-z0-9_]+)\b", tsyms))
     assert declared <= texported and texported - declared <= hooks_decl, sorted(texported - declared - hooks_decl)
@@ -292,3 +293,49 @@ def test_synthetic_pairs_are_seeded_and_differ_by_motion_model():
     assert torch.equal(a, b) and torch.equal(v, w)
     assert not torch.equal(Hn.synthetic_pair(64, 96, seed=4), a)
     assert (v[0].float() - v[1].float()).abs().mean().item() > 1.0 and (a[0].float() - a[1].float()).abs().mean().item() > 1.0
+
+
+def _write_scene(folder, n_frames, h=24, w=40, seed=0):
+    from PIL import Image
+    os.makedirs(folder, exist_ok=True)
+    g = np.random.default_rng(seed)
+    base = g.integers(0, 256, size=(h, w + n_frames, 3), dtype=np.uint8)
+    paths = []
+    for k in range(n_frames):
+        bgr = base[:, k:k + w]                                             # a scene sliding by one pixel per frame
+        Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(os.path.join(folder, "%05d.png" % k))   # PNG stores RGB
+        paths.append(bgr)
+    return paths
+
+
+def test_evaluate_dir_walk_sharding_and_reduction(tmp_path):
+    """fldr_harness.evaluate_dir on a 3-triplet X-Test-style folder written here (main.py:815-911, utils.py:414-432): the sample list
+    is the reference's (pairs t_step_size apart, targets in between, grouped by pair), frames come back in cv2's BGR order, the
+    PSNR mean is the mean over triplets, and the shares of two ranks add up to the single-rank result.  The model is replaced by
+    a stub (mean of the two frames) so that this runs without a GPU; the GPU suite runs the real thing."""
+    import fldr_harness as Hn
+    root = str(tmp_path)
+    a = _write_scene(os.path.join(root, "Type1", "TEST01"), 5, seed=1)     # pairs (0,2), (2,4): 2 triplets at multiple=2
+    b = _write_scene(os.path.join(root, "Type2", "TEST02"), 3, seed=2)     # pair (0,2): 1 triplet
+    pairs = Hn.list_xtest_triplets(root, multiple=2, t_step_size=2)
+    assert [(os.path.basename(p0), os.path.basename(p1), sc, [(os.path.basename(t), tv) for t, tv in tg]) for p0, p1, sc, tg in pairs] == [
+        ("00000.png", "00002.png", "Type1/TEST01", [("00001.png", 0.5)]), ("00002.png", "00004.png", "Type1/TEST01", [("00003.png", 0.5)]),
+        ("00000.png", "00002.png", "Type2/TEST02", [("00001.png", 0.5)])]
+    assert np.array_equal(Hn.load_bgr_u8(pairs[0][0]), a[0])              # BGR, as cv2.imread
+    p8 = Hn.list_xtest_triplets(os.path.join(root, "none"), 8, 32)
+    assert p8 == []
+    with pytest.raises(RuntimeError):
+        Hn.evaluate_dir(os.path.join(root, "none"), predict=lambda *x: [])
+
+    def stub(frames_u8, ts, targets):
+        pred = frames_u8.float().mean(1).round()                           # [1,3,H,W]
+        return [(Hn.psnr(t[0].permute(1, 2, 0).numpy(), pred[0].permute(1, 2, 0).numpy()), 0.5) for t in targets]
+    full = Hn.evaluate_dir(root, multiple=2, t_step_size=2, predict=stub)
+    want = [Hn.psnr(tgt, np.round((x0.astype(np.float32) + x1.astype(np.float32)) / 2)) for x0, x1, tgt in ((a[0], a[2], a[1]), (a[2], a[4], a[3]), (b[0], b[2], b[1]))]
+    assert full["frames"] == 3 and full["pairs"] == 3 and full["psnr"] == pytest.approx(sum(want) / 3, rel=1e-12) and full["ssim"] == 0.5
+    assert full["per_t"] == {0.5: pytest.approx(sum(want) / 3)}
+    r0 = Hn.evaluate_dir(root, multiple=2, t_step_size=2, predict=stub, rank=0, world=2)    # no process group: each rank's own share
+    r1 = Hn.evaluate_dir(root, multiple=2, t_step_size=2, predict=stub, rank=1, world=2)
+    assert r0["frames"] == 2 and r1["frames"] == 1
+    assert (r0["psnr"] * 2 + r1["psnr"] * 1) / 3 == pytest.approx(full["psnr"], rel=1e-12)
+    assert Hn.reduce_sums([1.5, 2.0, 3.0]) == [1.5, 2.0, 3.0]
