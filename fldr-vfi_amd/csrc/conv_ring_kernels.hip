@@ -687,9 +687,7 @@ static int ring_launch_levels(SpkArgs& a, int n_units, int wgs_per_xcd_max, hipS
     a.n_units = n_units;
     a.units_per_xcd = (a.n_units + 7) / 8;
     a.units_per_xcd = (a.units_per_xcd + a.groups - 1) / a.groups * a.groups;
-    a.wgs_per_xcd = a.units_per_xcd < wgs_per_xcd_max ? a.units_per_xcd : wgs_per_xcd_max;
-    a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;
-    if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
+    a.wgs_per_xcd = spk_right_size(a.units_per_xcd, wgs_per_xcd_max, a.groups);
     if (((int64_t)a.n_units + 8 * a.units_per_xcd) * a.groups >= (1ll << 32)) return FLDR_E_SHAPE;
     a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
     hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, 8, 32, true>), dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);

@@ -118,6 +118,27 @@ __device__ __forceinline__ void spk_step_pattern(int s) {            // s is a c
     else spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 2>(reads);
 }
 
+// Persistent workgroups per XCD for `upx` units per XCD on at most `wpx_max` workgroups, a multiple of `groups` (one output group per
+// workgroup: bias kept in registers).  RIGHT-SIZED (round 4): the launch takes R = ceil(upx / wpx_max) rounds whatever the grid, so it
+// only starts the ceil(upx / R) workgroups that keep every workgroup busy for all R rounds — the 96 -> 96 convolution at 288x480 has
+// 136 units per XCD = 4.25 rounds of 32: 28 workgroups of <= 5 units finish when 32 workgroups (8 with 5 units, 24 with 4) would, and the
+// 32 CUs of the chip it leaves alone run the other streams' kernels meanwhile (a workgroup occupies its CU's whole LDS).
+#ifndef SPK_RIGHT_SIZE
+#define SPK_RIGHT_SIZE 1
+#endif
+static inline int spk_right_size(int upx, int wpx_max, int groups) {
+    int w = upx < wpx_max ? upx : wpx_max;
+    w = w / groups * groups;
+    if (w < groups) w = groups;
+#if SPK_RIGHT_SIZE
+    const int rounds = (upx + w - 1) / w;
+    int need = (upx + rounds - 1) / rounds;
+    need = (need + groups - 1) / groups * groups;
+    if (need < w) w = need;
+#endif
+    return w;
+}
+
 // Launch geometry shared by both pipelines: tiles, (sample, tile, group) units, XCD-contiguous unit ranges, persistent
 // workgroups per XCD (a multiple of `groups`: one output group per workgroup) and the magic numbers of spk_div.
 static inline int spk_fill_geometry(SpkArgs& a, int N, int wgs_per_xcd_max, int tile_w = SPK_TW) {
@@ -126,9 +147,7 @@ static inline int spk_fill_geometry(SpkArgs& a, int N, int wgs_per_xcd_max, int 
     a.n_units = N * a.n_tiles * a.groups;
     a.units_per_xcd = (a.n_units + 7) / 8;
     a.units_per_xcd = (a.units_per_xcd + a.groups - 1) / a.groups * a.groups;      // whole tiles per XCD
-    a.wgs_per_xcd = a.units_per_xcd < wgs_per_xcd_max ? a.units_per_xcd : wgs_per_xcd_max;
-    a.wgs_per_xcd = a.wgs_per_xcd / a.groups * a.groups;                           // one output group per workgroup (bias kept in registers)
-    if (a.wgs_per_xcd < a.groups) a.wgs_per_xcd = a.groups;
+    a.wgs_per_xcd = spk_right_size(a.units_per_xcd, wgs_per_xcd_max, a.groups);
     const int64_t dmax = a.n_tiles > a.groups ? a.n_tiles : a.groups;
     if (((int64_t)a.n_units + 8 * a.units_per_xcd) * dmax >= (1ll << 32)) return FLDR_E_SHAPE;      // exactness of spk_div
     a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
