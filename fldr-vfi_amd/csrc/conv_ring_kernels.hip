@@ -342,10 +342,28 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             po[q] = (oy < uH && ox < uW) ? (uint32_t)(oy * uW + ox) : ~0u;
         }
     };
+    // The residual of the unit's outputs, prefetched one iteration ahead: fp32 NCHW (4 loads of 4 bytes per block and lane), or —
+    // a.res_spk, round 4: rec_ctx_ds.2 adds the PCA features, which then exist split-packed only — the hi and lo halves of the
+    // lane's 4 channels (2 loads of 8 bytes), value = hi + lo: the fp32 value up to the split's 2^-22 relative rounding of lo.
     float res_r[HAS_RES ? NMT : 1][HAS_RES ? NQ : 1][4];
     auto residual_prefetch = [&]() {
         uint32_t po[NQ]; int n;
         unit_pixels(cur_u, po, n);
+        if (a.res_spk) {
+            const char* resn = reinterpret_cast<const char*>(a.residual) + u_res_off + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HW * 16;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    int co0 = cbase + m * 16 + lg * 4;
+                    co0 = co0 < a.cout_store ? co0 : 0;                 // (channels past cout_store are never stored)
+                    const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + (po[q] != ~0u ? po[q] : 0u)) * 16u + (uint32_t)((co0 >> 2) & 1) * 8u;
+                    const h4 hi = *reinterpret_cast<const h4*>(resn + off), lo = *reinterpret_cast<const h4*>(resn + (off + HW32 * 16u));
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r] = (float)hi[r] + (float)lo[r];
+                }
+            return;
+        }
         const float* resn = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.residual) + u_res_off) + (int64_t)n * a.cout_store * HW;
 #pragma unroll
         for (int m = 0; m < NMT; ++m)

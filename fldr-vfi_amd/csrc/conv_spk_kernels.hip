@@ -614,9 +614,11 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     FLDR_CHECK_ARG(d && d->wpack && (d->out_f32 || d->out_spk) && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
     FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= SPK_MAX_GROUPS * 8 && d->cout > 0 && d->cout <= 96);
     FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->H > 0 && d->W > 0);
-    FLDR_CHECK_ARG(!d->residual || d->out_f32);
+    FLDR_CHECK_ARG(!d->residual || d->out_f32 || (d->precision & 2));           // (an fp32 residual comes with the fp32 output)
+    FLDR_CHECK_ARG(!(d->precision & ~3) && (!(d->precision & 2) || (d->residual && g_spk_variant == 1)));
     if ((int64_t)d->cout_store * d->H * d->W * 4 >= (1ll << 32) || fldr_spk_bytes(96, d->H, d->W) >= (1ll << 32)) return FLDR_E_SHAPE;
     SpkArgs a;
+    a.res_spk = (d->precision & 2) ? 1 : 0;
     int gsum = 0, csum = 0;
     for (int s = 0; s < d->n_src; ++s) {
         FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0);
@@ -651,11 +653,11 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
         if (units <= g_spk_small_units) { a.groups = (d->cout + 15) / 16; nmt = 1; }
     }
     hipStream_t s = fldr_s(stream);
-    if (g_spk_variant == 1) return fldr_spk_ring_dispatch(a, d->N, nmt, d->precision == 1 ? 1 : 3, g_spk_wgs_per_xcd, s);
+    if (g_spk_variant == 1) return fldr_spk_ring_dispatch(a, d->N, nmt, (d->precision & 1) ? 1 : 3, g_spk_wgs_per_xcd, s);
 #ifndef FLDR_TEST_HOOKS
     return FLDR_E_ARG;                                               // (unreachable: the variant switch is a test-build hook)
 #else
-    if (d->precision == 1) {
+    if (d->precision & 1) {
         if (nmt == 1) return spk_launch<1, 1>(a, d->N, s);
         if (nmt == 2) return spk_launch<2, 1>(a, d->N, s);
         return spk_launch<3, 1>(a, d->N, s);
@@ -679,8 +681,10 @@ extern "C" int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_lev
     const fldr_spk_conv_desc& d0 = descs[0];
     FLDR_CHECK_ARG(d0.wpack && (d0.out_f32 || d0.out_spk) && d0.n_src == 1 && d0.src[0] && d0.N == 1);
     FLDR_CHECK_ARG(d0.cin > 0 && d0.cin <= SPK_MAX_GROUPS * 8 && d0.cout > 0 && d0.cout <= 96 && d0.cout_store > 0 && d0.cout_store <= d0.cout);
-    FLDR_CHECK_ARG(!d0.residual || d0.out_f32);
+    FLDR_CHECK_ARG(!d0.residual || d0.out_f32 || (d0.precision & 2));
+    FLDR_CHECK_ARG(!(d0.precision & ~3) && (!(d0.precision & 2) || d0.residual));
     SpkArgs a;
+    a.res_spk = (d0.precision & 2) ? 1 : 0;
     const int ng = (d0.cin + 7) / 8;
     for (int g = 0; g < SPK_MAX_GROUPS; ++g) { a.grp_ptr[g] = g < ng ? (unsigned long long)reinterpret_cast<uintptr_t>(d0.src[0]) : 0ull; a.grp_bstride[g] = 0; }
     a.wpack = d0.wpack; a.bias = d0.bias; a.residual = d0.residual;

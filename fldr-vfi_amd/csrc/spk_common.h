@@ -33,6 +33,7 @@ struct SpkArgs {
     int32_t n_chunks, cout, cout_store;
     int32_t H, W;
     int32_t relu;
+    int32_t res_spk;                              // 1: `residual` is a split-packed tensor of cout_store channels (value = hi + lo), ring pipeline only
     int32_t tiles_x, n_tiles, groups;             // groups: output-channel groups of 16*NMT channels the launch is split into
     int32_t pack_nmt;                             // 16-channel blocks per weight-pack group (>= NMT, a multiple of it: small
                                                   // launches run the NMT=1 kernel on sub-groups of an NMT=3 pack)

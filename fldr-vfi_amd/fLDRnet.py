@@ -141,21 +141,27 @@ class DCTXVFInet(nn.Module):
             B = x_l[0].shape[0]
             nch = a.dctvfi_nf * 6
             # all six projections in two launches (pass A: per-level min / max, pass B: emit): fLDRnet.py:133-146
+            # rec_ctx_ds of ALL levels in two launches needs the features split-packed only: the second convolution adds them back
+            # from the packed tensor (hi + lo: the fp32 feature up to 2^-22 relative, |x| <= 1), so the rescale launch writes no fp32
+            # copy (71 MB of 141 per 4K forward, round 4).  FLDR_PCA_F32=1 keeps the fp32 residual (bit-identical to the per-level path).
+            levels_batched = bool(a.ref_feat_extrac and spk and B == 1 and fldr_hip.LEVEL_BATCH and fldr_hip.spk_variant() == 1)
+            packed_only = levels_batched and not fldr_hip.PCA_F32
             r = to_pca_diff_f32_pyramid([x_l[i].reshape(B * 6, x_l[i].shape[3], x_l[i].shape[4]) for i in range(n_levels)],
-                                        self.params, a, self.pca_means[i8], self.EVs[i8], self.mean_vecs[i8], want_spk=spk)
+                                        self.params, a, self.pca_means[i8], self.EVs[i8], self.mean_vecs[i8], want_spk=spk,
+                                        want_f32=not packed_only)
             pcas, pcas_p = r if spk else (r, [None] * n_levels)
             feats = []
             pv, pp = [], []
             for i in range(n_levels):
                 h, w = x_l[i].shape[3], x_l[i].shape[4]
-                pv.append(pcas[i].view(B, nch, h // 8, w // 8))
+                pv.append(pcas[i].view(B, nch, h // 8, w // 8) if pcas is not None else None)
                 # [1, 96B, h, w] packed == [B, 96, h, w] packed (12 whole groups per sample)
                 pp.append(fldr_hip.Spk(pcas_p[i].buf, (B, nch, h // 8, w // 8)) if spk else None)
-            if a.ref_feat_extrac and spk and B == 1 and fldr_hip.LEVEL_BATCH and fldr_hip.spk_variant() == 1:
+            if levels_batched:
                 # rec_ctx_ds(x) + x of ALL levels in two launches (the weights are shared, the levels independent: fLDRnet.py:148-162)
                 c0, c2 = self.rec_ctx_ds[0], self.rec_ctx_ds[2]
                 ys = fldr_hip.conv2d_spk_levels(pp, c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
-                feats = fldr_hip.conv2d_spk_levels(ys, c2.weight, c2.bias, relu=True, residuals=pv, want_f32=True, want_spk=True)
+                feats = fldr_hip.conv2d_spk_levels(ys, c2.weight, c2.bias, relu=True, residuals=pp if packed_only else pv, want_f32=True, want_spk=True)
             else:
                 for i in range(n_levels):
                     feats.append(self._extract_features(pv[i], pp[i]) if a.ref_feat_extrac else (pv[i], pp[i]))

@@ -378,6 +378,9 @@ SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (defau
 PREP_SPLIT = os.environ.get("FLDR_PREP_SPLIT", "0") == "1"
 # rec_ctx_ds of all pyramid levels in two launches (fldr_conv2d_spk_levels) instead of two per level (FLDR_LEVEL_BATCH=0)
 LEVEL_BATCH = os.environ.get("FLDR_LEVEL_BATCH", "1") != "0"
+# 1: the PCA features are also written as fp32 and rec_ctx_ds.2 adds the fp32 tensor (rounds 1-3); default: split-packed only, the
+# residual is hi + lo of the packed feature (<= 2^-22 relative: 2.4e-7 for |x| <= 1) and the rescale launch writes half the bytes
+PCA_F32 = os.environ.get("FLDR_PCA_F32", "0") == "1"
 
 
 # Bounds table of the level-0 image splats: "lowres" (default) = from the low-resolution flow the upsampled flow_t is made of
@@ -1091,9 +1094,13 @@ def conv2d_spk(srcs, weight, bias, relu=False, residual=None, cout_store=None, u
     wp = conv_spk_prepack(weight)
     d.wpack = wp.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
-    out32 = torch.empty(N, cs, H, W, device=dev, dtype=torch.float32) if (want_f32 or residual is not None) else None
+    res_packed = isinstance(residual, Spk)          # packed residual (value = hi + lo): no fp32 output needed for it
+    out32 = torch.empty(N, cs, H, W, device=dev, dtype=torch.float32) if (want_f32 or (residual is not None and not res_packed)) else None
     outp = _spk_alloc(N, cs, H, W, dev) if want_spk else None
-    if residual is not None:
+    if res_packed:
+        assert tuple(residual.shape) == (N, cs, H, W)
+        d.residual = residual.ptr
+    elif residual is not None:
         residual = residual.contiguous()
         assert residual.shape == out32.shape
         d.residual = residual.data_ptr()
@@ -1101,7 +1108,7 @@ def conv2d_spk(srcs, weight, bias, relu=False, residual=None, cout_store=None, u
     d.out_spk = outp.buf.data_ptr() if outp is not None else None
     prec = precision or CONV_PRECISION
     d.N, d.cin, d.cout, d.cout_store, d.H, d.W = N, cin, cout, cs, H, W
-    d.relu, d.precision = int(bool(relu)), (1 if prec == "fp16" else 0)
+    d.relu, d.precision = int(bool(relu)), (1 if prec == "fp16" else 0) | (2 if res_packed else 0)
     _check(lib().fldr_conv2d_spk(ctypes.byref(d), _stream()), "fldr_conv2d_spk")
     if want_f32 and want_spk:
         return out32, outp
@@ -1162,9 +1169,14 @@ def conv2d_spk_levels(srcs, weight, bias, relu=False, residuals=None, want_f32=T
         d.wpack = wp.data_ptr()
         d.bias = bias.data_ptr() if bias is not None else None
         res = residuals[l] if residuals is not None else None
-        o32 = torch.empty(1, cout, h, w, device=sp.device, dtype=torch.float32) if (want_f32 or res is not None) else None
+        res_packed = isinstance(res, Spk)           # split-packed residual (value = hi + lo; every level or none)
+        o32 = torch.empty(1, cout, h, w, device=sp.device, dtype=torch.float32) if (want_f32 or (res is not None and not res_packed)) else None
         osp = _spk_alloc(1, cout, h, w, sp.device) if want_spk else None
-        if res is not None:
+        if res_packed:
+            assert tuple(res.shape) == (1, cout, h, w)
+            keep.append(res)
+            d.residual = res.ptr
+        elif res is not None:
             res = res.contiguous()
             assert res.shape == o32.shape
             keep.append(res)
@@ -1172,7 +1184,7 @@ def conv2d_spk_levels(srcs, weight, bias, relu=False, residuals=None, want_f32=T
         d.out_f32 = o32.data_ptr() if o32 is not None else None
         d.out_spk = osp.buf.data_ptr() if osp is not None else None
         d.N, d.cin, d.cout, d.cout_store, d.H, d.W = 1, cin, cout, cout, h, w
-        d.relu, d.precision = int(bool(relu)), (1 if prec == "fp16" else 0)
+        d.relu, d.precision = int(bool(relu)), (1 if prec == "fp16" else 0) | (2 if res_packed else 0)
         outs.append((o32, osp) if (want_f32 and want_spk) else (osp if want_spk else o32))
     _check(lib().fldr_conv2d_spk_levels(descs, len(packed), _stream()), "fldr_conv2d_spk_levels")
     return outs

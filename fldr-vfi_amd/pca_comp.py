@@ -46,16 +46,17 @@ def to_pca_diff_f32(im, params, args, mean, EV, mean_vec, want_spk=False):
     return (o32, spk) if want_spk else o32
 
 
-def to_pca_diff_f32_pyramid(ims, params, args, mean, EV, mean_vec, want_spk=False):
+def to_pca_diff_f32_pyramid(ims, params, args, mean, EV, mean_vec, want_spk=False, want_f32=True):
     """to_pca_diff(...).float() for ALL pyramid levels of a forward (the loop of fLDRnet.py:133-146) in two launches:
     ims = [x_l[i].reshape(B*6, h_i, w_i)]; the same EV8 / Mean8 / meanVec8 at every level (fLDRnet.py:135).
-    -> list of fp32 [P*K,h,w] (and, with want_spk, the list of split-packed twins)."""
+    -> list of fp32 [P*K,h,w] (and, with want_spk, the list of split-packed twins; want_f32=False: (None, twins) — the rescale
+    launch then writes half the bytes)."""
     k = _check(ims[0], params[0], args, mean_vec)
     for p in params[:len(ims)]:
         if _check(ims[0], p, args, mean_vec) != k:
             raise NotImplementedError("pyramid levels with different numbers of components")
     o32, spk, _ = fldr_hip.pca_project_pyramid(ims, EV.detach()[:k].contiguous(), mean.detach(), mean_vec.detach()[:k].contiguous(),
-                                               want_f32=True, want_spk=want_spk)
+                                               want_f32=want_f32, want_spk=want_spk)
     return (o32, spk) if want_spk else o32
 
 

@@ -330,13 +330,15 @@ typedef struct fldr_spk_conv_desc {
     int32_t      n_src;
     const float* wpack;        /* from fldr_conv_spk_prepack */
     const float* bias;         /* [cout] or NULL */
-    const float* residual;     /* fp32 [N,cout_store,H,W], added after the activation (needs out_f32), or NULL */
+    const float* residual;     /* added after the activation, or NULL: fp32 [N,cout_store,H,W] (needs out_f32), or — precision bit 1 — a split-packed
+                                  tensor of cout_store channels (fldr_spk_bytes per sample): value = hi + lo, i.e. the packed fp32 value up to the
+                                  split's rounding of lo (<= 2^-22 relative); cout_store % 4 == 0 */
     float*       out_f32;      /* [N,cout_store,H,W] or NULL */
     void*        out_spk;      /* packed [N, cout_store channels, H, W] (fldr_spk_bytes per sample) or NULL */
     int32_t N, cin, cout, cout_store;
     int32_t H, W;
     int32_t relu;
-    int32_t precision;         /* 0: 3 x fp16 split (fp32-equivalent); 1: hi halves only (plain fp16 inputs) */
+    int32_t precision;         /* bit 0: 0 = 3 x fp16 split (fp32-equivalent), 1 = hi halves only (plain fp16 inputs); bit 1: `residual` is split-packed */
 } fldr_spk_conv_desc;
 
 int64_t fldr_spk_bytes(int C, int H, int W);                       /* bytes of one packed sample */

@@ -386,6 +386,36 @@ def test_multi_level_conv_launch(hip, dev, case):
         assert all(o.shape == (1, cout, h, w) for o, (h, w) in zip(only, sizes))
 
 
+@pytest.mark.parametrize("case", [(96, 96, (72, 120)), (48, 40, (19, 45)), (32, 16, (8, 32))])
+def test_conv_split_packed_residual(hip, dev, case):
+    """Round 4: the residual of fldr_conv2d_spk[_levels] given as a split-packed tensor (rec_ctx_ds.2 adds the PCA features, which
+    then exist packed only).  The kernel adds hi + lo: (1) with an fp32 residual that IS hi + lo (unpack(pack(x))) the outputs are the
+    bits of the fp32-residual call, single launch and multi-level launch; (2) with an arbitrary fp32 x in [-1, 1] the result differs
+    from the fp32-residual one by at most 2^-22 |x| + the output's own rounding (asserted: 2.4e-7 + 1 ulp)."""
+    cin, cout, (h, w) = case
+    g = _gen(91)
+    sizes = [(h, w), (max(h // 2, 1), max(w // 2, 1)), (3, 5)]
+    xs = [torch.randn(1, cin, a, b, generator=g).to(dev) for a, b in sizes]
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 20).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    raw = [(torch.rand(1, cout, a, b, generator=g) * 2 - 1).to(dev) for a, b in sizes]
+    packed = [hip.spk_pack(r) for r in raw]
+    exact = [p.float() for p in packed]                                     # hi + lo as fp32: exactly what the kernel adds
+    for l, x in enumerate(xs):
+        assert (exact[l] - raw[l]).abs().max().item() <= 2.4e-7
+        a32, asp = hip.conv2d_spk([x], wt, bias, relu=True, residual=exact[l], want_f32=True, want_spk=True)
+        b32, bsp = hip.conv2d_spk([x], wt, bias, relu=True, residual=packed[l], want_f32=True, want_spk=True)
+        assert torch.equal(a32, b32) and torch.equal(asp.buf, bsp.buf), l
+        only = hip.conv2d_spk([x], wt, bias, relu=True, residual=packed[l], want_f32=False, want_spk=True)   # no fp32 output needed
+        assert torch.equal(only.buf, bsp.buf)
+        c32, _ = hip.conv2d_spk([x], wt, bias, relu=True, residual=raw[l], want_f32=True, want_spk=True)
+        assert (c32 - b32).abs().max().item() <= 2.4e-7 + 1.2e-7 * float(c32.abs().max())
+    lv_a = hip.conv2d_spk_levels(xs, wt, bias, relu=True, residuals=exact, want_f32=True, want_spk=True)
+    lv_b = hip.conv2d_spk_levels(xs, wt, bias, relu=True, residuals=packed, want_f32=True, want_spk=True)
+    for (a32, asp), (b32, bsp) in zip(lv_a, lv_b):
+        assert torch.equal(a32, b32) and torch.equal(asp.buf, bsp.buf)
+
+
 @pytest.mark.parametrize("shape", [([3, 3, 2, 5], 16, 40, 72, 1), ([16], 32, 34, 70, 2), ([32], 64, 48, 64, 1), ([26], 16, 50, 38, 1)])
 def test_stride2_split_conv_is_fp32_equivalent(hip, dev, shape):
     """The 3 x fp16-split stride-2 4x4 convolution (UNet encoders) against an fp64 reference: error at the level of the exact
@@ -910,6 +940,17 @@ def test_model_matches_reference_golden(hip, oracle, golden, dev, model, case):
             flow = m.vfinet(feat, flow, t.view(1, 1, 1, 1), level=level, is_training=False, normInput=pyr[level])
             _cmp(flow, torch.from_numpy(g["flow%d" % level]), atol=2e-4, rtol=1e-4, what="flow L%d" % level)
         out = Hn.interpolate(m, a, frames, t, pyramid=pyr)
+        # the forward's own feature path (round 4): PCA features split-packed only, rec_ctx_ds of all levels in two launches, the
+        # second one adding the features back from the packed tensor (hi + lo) — against the reference's features of every level
+        import pca_comp
+        _, pcs = pca_comp.to_pca_diff_f32_pyramid([pyr[i].reshape(6, pyr[i].shape[3], pyr[i].shape[4]) for i in range(6)], m.params, a,
+                                                  m.Mean8, m.EV8, m.meanVec8, want_spk=True, want_f32=False)
+        pp = [hip.Spk(pcs[i].buf, (1, 96, pyr[i].shape[3] // 8, pyr[i].shape[4] // 8)) for i in range(6)]
+        c0, c2 = m.rec_ctx_ds[0], m.rec_ctx_ds[2]
+        ys = hip.conv2d_spk_levels(pp, c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
+        fl = hip.conv2d_spk_levels(ys, c2.weight, c2.bias, relu=True, residuals=pp, want_f32=True, want_spk=True)
+        for level in range(1, 6):
+            _cmp(fl[level][0], torch.from_numpy(g["feat%d" % level]), atol=2e-5, what="feat L%d, packed residual" % level)
     assert out.dtype == torch.float64
     H, W = frames.shape[3:]
     ref = torch.from_numpy(g["out"]).double()[:, :, :H, :W]
