@@ -27,22 +27,7 @@ struct PrepArgs {
     int phase;                     // bit 0: z0 / z1 + flow_t0 / flow_t1; bit 1: flowback_0 / _1 + im0_tot / im1_tot (3 = everything)
     int kx, ky;                    // sx == 2^-kx / sy == 2^-ky exactly (integer source-index arithmetic), else -1
     float rkx, rky;                // 2^-(kx+1), 2^-(ky+1)
-    // 1-D grid, XCD-aware (round 4): workgroups b and b + 8 share an XCD (and its L2), so XCD x = b & 7 walks the CONTIGUOUS
-    // range of tiles [x * tiles_per_xcd, (x + 1) * tiles_per_xcd) in row-major order — a band of rows.  Every frame plane is read
-    // twice directly and eight times through gathers a few pixels away: dealt round-robin, each of the 8 L2s fetched nearly the
-    // whole frame again (647 MB fetched for 212 MB of planes, profiles/r03_forward_pmc.txt).
-    int tiles_x, n_tiles, tiles_per_xcd;
-    uint32_t m_tiles_x;            // floor(2^32 / tiles_x) + 1
 };
-// tile index of this workgroup, or -1
-__device__ __forceinline__ int prep_tile(const PrepArgs& a, int& bx, int& by) {
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    const int tile = a.tiles_per_xcd ? xcd * a.tiles_per_xcd + k : (int)blockIdx.x;     // (0: row-major deal, the A/B setting)
-    if ((a.tiles_per_xcd && k >= a.tiles_per_xcd) || tile >= a.n_tiles) return -1;
-    by = a.tiles_x == 1 ? tile : (int)__umulhi((uint32_t)tile, a.m_tiles_x);
-    bx = tile - by * a.tiles_x;
-    return tile;
-}
 
 // Uniform base pointer + 32-bit byte offset: one global_load / global_store with an SGPR base and a VGPR offset, no 64-bit
 // address arithmetic per access (the kernel is bound by its VALU instruction count).  Planes are < 4 GB (host-checked).
@@ -181,17 +166,18 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 // the pixel's thread — was built and measured in round 2: the kernel alone 316 vs 321 us, but 433 vs 439 pairs/s with three pairs in
 // flight; the kernel is bound by its ~1,000 vector instructions per pixel, not by its stores.  Removed.)
 #define PREP_NPL 16                // z0, z1, flow_t0 (x, y), flow_t1, flowback_0, flowback_1, im0_tot (3), im1_tot (3)
+// PH: the phases this instantiation carries (1: z0 / z1 + flow_t; 2: flowback + im_tot; 3: both) — a template parameter so that a
+// one-phase launch has the registers (and with them the waves in flight: the kernel waits on chains of dependent gathers) of its phase
+template <int PH>
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    int bx, by;
-    if (prep_tile(a, bx, by) < 0) return;
-    const int px = bx * 64 + tx;
-    const int py = by * 4 + ty;
-    const int n = blockIdx.y;
+    const int px = blockIdx.x * 64 + tx;
+    const int py = blockIdx.y * 4 + ty;
+    const int n = blockIdx.z;
     const bool live = px < a.W && py < a.H;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
-    const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;        // uniform
+    constexpr bool ph1 = (PH & 1) != 0, ph2 = (PH & 2) != 0;
     const int64_t o1 = (int64_t)n * HW, o2 = (int64_t)n * 2 * HW, o3 = (int64_t)n * 3 * HW;
     float* const dst[PREP_NPL] = {
         a.z0 ? a.z0 + o1 : nullptr, a.z1 ? a.z1 + o1 : nullptr,
@@ -273,158 +259,245 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
     }
 }
 
-// ---- runs of four pixels (round 4) -------------------------------------------------------------------------------------
-// The thread-per-pixel kernel above moves its 6 + 16 planes through 4-byte lanes, and this chip streams planes at 3.9-4.1 TB/s
-// that way against 5.2-6.0 TB/s through 16-byte lanes (tools/ubench/plane_bw_bench): its 1.21 GB in 311 us sat exactly on that
-// cap.  Here a thread owns FOUR horizontally adjacent pixels (x = 4 m .. 4 m + 3): the frames at the run are six 16-byte loads,
-// every output plane one 16-byte streaming store, and everything that is constant over the run is evaluated once — the row's
-// vertical source indices, and, for upsampling factors >= 8, the horizontal ones too: with sx = 2^-k, k >= 3, the source index
-// (2 x + 1 - 2^k) >> (k + 1) is the same for the four pixels of an aligned run (2 x + 1 = 8 m + r, r in {1,3,5,7}: the shift drops
-// r), so the 2x2 low-resolution neighbourhood — 8 loads and their addresses — is shared and only the fraction differs.  The
-// per-pixel arithmetic (taps, gathers, sums) is the SAME device functions in the same order: bit-identical outputs.
-// Requirements (else the kernel above runs): W % 4 == 0, kx >= 3, every plane base / stride a multiple of 16 bytes.
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef float f2v __attribute__((ext_vector_type(2)));
-template <int R> struct PrepVec;
-template <> struct PrepVec<4> { typedef f4v T; };
-template <> struct PrepVec<2> { typedef f2v T; };
-template <int R>
-__device__ __forceinline__ typename PrepVec<R>::T prep_ldv(const float* __restrict__ base, uint32_t boff) {
-    return *reinterpret_cast<const typename PrepVec<R>::T*>(reinterpret_cast<const char*>(base) + boff);
-}
-template <int R>
-__device__ __forceinline__ void prep_stv(float* __restrict__ base, uint32_t boff, const float (&v)[R]) {
-    typename PrepVec<R>::T x;
-#pragma unroll
-    for (int j = 0; j < R; ++j) x[j] = v[j];
-#if PREP_NT
-    __builtin_nontemporal_store(x, reinterpret_cast<typename PrepVec<R>::T*>(reinterpret_cast<char*>(base) + boff));
-#else
-    *reinterpret_cast<typename PrepVec<R>::T*>(reinterpret_cast<char*>(base) + boff) = x;
+#ifdef FLDR_TEST_HOOKS
+// ---- LDS-staged gather windows (round 4; measured, not faster on coherent flows: TEST BUILD ONLY, cross-check of the kernel above) ----
+// Hypothesis: the kernel above is bound by its 48 four-byte image gathers per pixel (with the lanes of a gather 2 / 4 pixels apart —
+// a thread owning a run of 2 / 4 pixels for 16-byte plane loads / stores — it takes 395 / 518 us instead of 328: the time follows
+// the cache lines per gather instruction).  So here the gathers leave the vector-memory path: a workgroup owns a 64 x 16 tile; for each
+// of its four backward taps it finds the exact bounding box of the tile's corner pixels (packed-int16 min / max reduction over the
+// workgroup), stages that box of the three planes — tile + flow SPREAD, not magnitude: (64 + 16) x (16 + 8) — in LDS with 16-byte
+// LDS-DMA and samples from LDS; a box that does not fit falls back to global gathers for that tile and tap pair.  Same device
+// functions, operands and operation order per value: bit-identical planes (test_level0_prep_lds_windows_bit_identical).
+// MEASURED (tools/kernel_bench.py prep, 2304x3840): rigid-shift flows 350 us (global gathers) vs 368-380 us (this kernel, tiles of
+// 8 / 16 rows, windows 72 / 80 wide; 32 rows: 471); incoherent flows (low-resolution noise 0.3 px) 495 vs 385 us.  Per phase:
+// z + flow_t 148-157 vs 160-169 us, flowback + im_tot 237-241 vs 237-250 us — i.e. on coherent flows the image gathers are NOT
+// what bounds the kernel (they hit L1 / L2 lines the direct reads brought in), and staging them costs what it saves.  Kept out of
+// the product; the hypothesis stands only for incoherent flows.
+#define PL_TW 64
+#ifndef PL_TH
+#define PL_TH 16
 #endif
+#ifndef PL_WW
+#define PL_WW 80                              // window width (floats): tile + 16
+#endif
+#ifndef PL_WH
+#define PL_WH (PL_TH + 8)                     // window height: tile + 8
+#endif
+#define PL_PLANE (PL_WW * PL_WH)              // floats per window plane (7,680 B)
+#define PL_RPT (PL_TH / 4)                    // rows per thread
+#define PL_LDS_BYTES (6 * PL_PLANE * 4 + 256)
+
+typedef __attribute__((address_space(1))) const void* pl_gptr_t;
+typedef __attribute__((address_space(3))) void* pl_lptr_t;
+typedef short pl_s2 __attribute__((ext_vector_type(2)));
+
+// componentwise min / max of two int16 pairs (x in the low half, y in the high half; coordinates < 32768, host-checked)
+__device__ __forceinline__ uint32_t pl_min2(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(pl_s2, a), __builtin_bit_cast(pl_s2, b))); }
+__device__ __forceinline__ uint32_t pl_max2(uint32_t a, uint32_t b) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(pl_s2, a), __builtin_bit_cast(pl_s2, b))); }
+__device__ __forceinline__ uint32_t pl_pack(int x, int y) { return ((uint32_t)y << 16) | (uint32_t)(x & 0xffff); }
+
+// the clamped corner box of a tap (fldr_tap_prepare's xa, xb, ya, yb)
+struct PlBox { int xa, xb, ya, yb; };
+__device__ __forceinline__ PlBox pl_box(const FldrTap& t, int W, int H) {
+    PlBox b;
+    b.xa = min(max(t.x0, 0), W - 1); b.xb = min(max(t.x0 + 1, 0), W - 1);
+    b.ya = min(max(t.y0, 0), H - 1); b.yb = min(max(t.y0 + 1, 0), H - 1);
+    return b;
+}
+// fldr_tap_sample_p on a window: corner (x, y) of the image is cell (y - oy) * PL_WW + (x - ox); same products, same order
+__device__ __forceinline__ float pl_sample(const FldrTap& t, const PlBox& b, const float* __restrict__ win, int ox, int oy) {
+#pragma clang fp contract(off)
+    const float* ra = win + (b.ya - oy) * PL_WW - ox;
+    const float* rb = win + (b.yb - oy) * PL_WW - ox;
+    const float pnw = ra[b.xa], pne = ra[b.xb], psw = rb[b.xa], pse = rb[b.xb];
+    const float wnw = t.vnw ? t.wnw : 0.0f, wne = t.vne ? t.wne : 0.0f, wsw = t.vsw ? t.wsw : 0.0f, wse = t.vse ? t.wse : 0.0f;
+    float v = 0.0f;
+    v += pnw * wnw;
+    v += pne * wne;
+    v += psw * wsw;
+    v += pse * wse;
+    return v;
 }
 
-#ifndef PREP_QUAD_WAVES
-#define PREP_QUAD_WAVES 2                        // minimum waves per SIMD the register allocation is held to
-#endif
-// R: pixels per thread (4: 16-byte lanes; 2: 8-byte lanes, half the registers, lanes of a gather two pixels apart instead of four)
-template <int R>
-__global__ __launch_bounds__(256, R == 4 ? PREP_QUAD_WAVES : 4) void level0_prep_run_kernel(PrepArgs a) {
+__global__ __launch_bounds__(256) void level0_prep_lds_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    int bx, by;
-    if (prep_tile(a, bx, by) < 0) return;
-    const int px0 = (bx * 64 + tx) * R;
-    const int py = by * 4 + ty;
-    const int n = blockIdx.y;
-    if (px0 >= a.W || py >= a.H) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char pl_smem[];
+    float* const win = reinterpret_cast<float*>(pl_smem);                    // [6][PL_PLANE]: planes 0-2 window A, 3-5 window B
+    uint32_t* const red_base = reinterpret_cast<uint32_t*>(pl_smem + 6 * PL_PLANE * 4);   // 2 x [4 waves][4] packed corner bounds (one set per phase)
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6, lane = tx;
+    const int px = blockIdx.x * PL_TW + tx;
+    const int py0 = blockIdx.y * PL_TH + ty;                                 // this thread's rows: py0 + 4 k
+    const int n = blockIdx.z;
+    const bool xin = px < a.W;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
-    const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;        // uniform
+    const bool ph1 = (a.phase & 1) != 0, ph2 = (a.phase & 2) != 0;           // uniform
     const int64_t o1 = (int64_t)n * HW, o2 = (int64_t)n * 2 * HW, o3 = (int64_t)n * 3 * HW;
-    const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px0) * 4u;      // byte offset of the run inside a plane
     const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;
     const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;
     const float* i0 = a.I0 + (int64_t)n * a.i0_bstride;
     const float* i1 = a.I1 + (int64_t)n * a.i1_bstride;
     const float tv = a.t[n], omt = 1.0f - tv;
     const bool want_z = ph1 && a.z0;
+    const float fpx = (float)px;
 
-    // the frames at the run (direct reads, issued first; only the splat metrics use them)
-    typename PrepVec<R>::T c0[3], c1[3];
-    if (want_z) {
+    // upsampled flows at this thread's pixels (fLDRnet.py:419-422); out-of-image pixels of a partial tile idle (live[k] false)
+    float f10x[PL_RPT], f10y[PL_RPT], f01x[PL_RPT], f01y[PL_RPT];
+    bool live[PL_RPT];
+    const PrepLin lx = prep_lin(xin ? px : 0, a.sx, a.w, a.kx, a.rkx);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { c0[c] = prep_ldv<R>(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldv<R>(i1 + (int64_t)c * a.i1_cstride, pixb); }
+    for (int k = 0; k < PL_RPT; ++k) {
+        const int py = py0 + 4 * k;
+        live[k] = xin && py < a.H;
+        const PrepLin ly = prep_lin(live[k] ? py : 0, a.sy, a.h, a.ky, a.rky);
+        const PrepQuad q = prep_quad(lo10, lo01, a.w, lx, ly);
+        f10x[k] = prep_up(q, 0, lx, ly, a.mul, 0, 1.0f); f10y[k] = prep_up(q, 1, lx, ly, a.mul, 0, 1.0f);
+        f01x[k] = prep_up(q, 2, lx, ly, a.mul, 0, 1.0f); f01y[k] = prep_up(q, 3, lx, ly, a.mul, 0, 1.0f);
+        if (ph1 && live[k]) {                                               // t-scaled forward flows (fLDRnet.py:404-405,419-422)
+            const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;
+            prep_stf(a.flow_t0 + o2, pixb, prep_up(q, 2, lx, ly, a.mul, 1, tv));
+            prep_stf(a.flow_t0 + o2 + HW, pixb, prep_up(q, 3, lx, ly, a.mul, 1, tv));
+            prep_stf(a.flow_t1 + o2, pixb, prep_up(q, 0, lx, ly, a.mul, 1, omt));
+            prep_stf(a.flow_t1 + o2 + HW, pixb, prep_up(q, 1, lx, ly, a.mul, 1, omt));
+        }
     }
 
-    // upsampled flows at the run: one neighbourhood (see above), R fractions
-    const PrepLin ly = prep_lin(py, a.sy, a.h, a.ky, a.rky);
-    PrepLin lx[R];
+    // Workgroup-wide corner box of two taps (A, B): packed (x, y) min of the north-west corners, max of the south-east ones
+    // -> window origins (x a multiple of 4: 16-byte chunks) and whether both boxes fit their windows.
+    int oxA = 0, oyA = 0, oxB = 0, oyB = 0;
+    auto reduce_boxes = [&](uint32_t* red, uint32_t mnA, uint32_t mxA, uint32_t mnB, uint32_t mxB) -> bool {
 #pragma unroll
-    for (int j = 0; j < R; ++j) lx[j] = prep_lin(px0 + j, a.sx, a.w, a.kx, a.rkx);
-    const PrepQuad q = prep_quad(lo10, lo01, a.w, lx[0], ly);
-    float f10x[R], f10y[R], f01x[R], f01y[R];
+        for (int off = 32; off >= 1; off >>= 1) {
+            mnA = pl_min2(mnA, (uint32_t)__shfl_xor((int)mnA, off)); mxA = pl_max2(mxA, (uint32_t)__shfl_xor((int)mxA, off));
+            mnB = pl_min2(mnB, (uint32_t)__shfl_xor((int)mnB, off)); mxB = pl_max2(mxB, (uint32_t)__shfl_xor((int)mxB, off));
+        }
+        if (lane == 0) { red[ty * 4 + 0] = mnA; red[ty * 4 + 1] = mxA; red[ty * 4 + 2] = mnB; red[ty * 4 + 3] = mxB; }
+        __syncthreads();                                                     // (also: every wave is done with the previous windows)
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-        f10x[j] = prep_up(q, 0, lx[j], ly, a.mul, 0, 1.0f); f10y[j] = prep_up(q, 1, lx[j], ly, a.mul, 0, 1.0f);
-        f01x[j] = prep_up(q, 2, lx[j], ly, a.mul, 0, 1.0f); f01y[j] = prep_up(q, 3, lx[j], ly, a.mul, 0, 1.0f);
-    }
-    const float fpy = (float)py;
+        for (int w = 0; w < 4; ++w) {
+            mnA = pl_min2(mnA, red[w * 4 + 0]); mxA = pl_max2(mxA, red[w * 4 + 1]);
+            mnB = pl_min2(mnB, red[w * 4 + 2]); mxB = pl_max2(mxB, red[w * 4 + 3]);
+        }
+        oxA = (int)(mnA & 0xffffu) & ~3; oyA = (int)(mnA >> 16);
+        oxB = (int)(mnB & 0xffffu) & ~3; oyB = (int)(mnB >> 16);
+        return (int)(mxA & 0xffffu) - oxA < PL_WW && (int)(mxA >> 16) - oyA < PL_WH &&
+               (int)(mxB & 0xffffu) - oxB < PL_WW && (int)(mxB >> 16) - oyB < PL_WH;
+    };
+    // stage window A <- planes of imgA at (oxA, oyA), window B <- imgB at (oxB, oyB): 16-byte LDS-DMA chunks, clamped into the image
+    auto fill_windows = [&](const float* imgA, int64_t csA, const float* imgB, int64_t csB) {
+        constexpr int CH = PL_PLANE / 4;                                    // 16-byte chunks per plane (480)
+#pragma unroll
+        for (int j = 0; j < (CH + 255) / 256; ++j) {
+            const int c = tid + 256 * j;
+            const int row = c / (PL_WW / 4), col = (c - row * (PL_WW / 4)) * 4;
+            if (c < CH) {                                                    // (wave-uniform except in the last, partial wave)
+                const uint32_t ga = (uint32_t)(min(oyA + row, a.H - 1) * a.W + min(oxA + col, a.W - 4)) * 4u;
+                const uint32_t gb = (uint32_t)(min(oyB + row, a.H - 1) * a.W + min(oxB + col, a.W - 4)) * 4u;
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    __builtin_amdgcn_global_load_lds((pl_gptr_t)(reinterpret_cast<const char*>(imgA + (int64_t)p * csA) + ga),
+                                                     (pl_lptr_t)(win + p * PL_PLANE + (c & ~63) * 4), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((pl_gptr_t)(reinterpret_cast<const char*>(imgB + (int64_t)p * csB) + gb),
+                                                     (pl_lptr_t)(win + (3 + p) * PL_PLANE + (c & ~63) * 4), 16, 0, 0);
+                }
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                  // vmcnt(0): my chunks have landed
+        __syncthreads();
+    };
 
+    // ---- phase 1: splat metrics (fLDRnet.py:442-446): z0 from I0 and bwarp(I1, flow_01); z1 from I1 and bwarp(I0, flow_10) ----
     if (want_z) {
-        float z0v[R], z1v[R];
+        uint32_t mnA = 0x7fff7fffu, mxA = 0u, mnB = 0x7fff7fffu, mxB = 0u;   // A: I1 at flow_01, B: I0 at flow_10
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const float fpx = (float)(px0 + j);
-            const FldrTapP t0 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, f01x[j], f01y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-            const FldrTapP t1 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, f10x[j], f10y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-            const float m0 = fldr_tap_mask_p(t0), m1 = fldr_tap_mask_p(t1);
+        for (int k = 0; k < PL_RPT; ++k) {
+            if (!live[k]) continue;
+            const float fpy = (float)(py0 + 4 * k);
+            const PlBox b0 = pl_box(fldr_grid_tap(fpx, fpy, f01x[k], f01y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            const PlBox b1 = pl_box(fldr_grid_tap(fpx, fpy, f10x[k], f10y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+            mnA = pl_min2(mnA, pl_pack(b0.xa, b0.ya)); mxA = pl_max2(mxA, pl_pack(b0.xb, b0.yb));
+            mnB = pl_min2(mnB, pl_pack(b1.xa, b1.ya)); mxB = pl_max2(mxB, pl_pack(b1.xb, b1.yb));
+        }
+        const bool fit = reduce_boxes(red_base, mnA, mxA, mnB, mxB);         // workgroup-uniform
+        if (fit) fill_windows(i1, a.i1_cstride, i0, a.i0_cstride);
+#pragma unroll
+        for (int k = 0; k < PL_RPT; ++k) {
+            if (!live[k]) continue;
+            const int py = py0 + 4 * k;
+            const float fpy = (float)py;
+            const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;
+            const FldrTap t0 = fldr_grid_tap(fpx, fpy, f01x[k], f01y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+            const FldrTap t1 = fldr_grid_tap(fpx, fpy, f10x[k], f10y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+            const FldrTapP t0p = fldr_tap_prepare(t0, a.W, a.H), t1p = fldr_tap_prepare(t1, a.W, a.H);
+            const PlBox b0 = pl_box(t0, a.W, a.H), b1 = pl_box(t1, a.W, a.H);
+            const float m0 = fldr_tap_mask_p(t0p), m1 = fldr_tap_mask_p(t1p);
             float acc0 = 0.0f, acc1 = 0.0f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float w0 = fldr_tap_sample_p(t0, i1 + (int64_t)c * a.i1_cstride) * m0;
-                const float w1 = fldr_tap_sample_p(t1, i0 + (int64_t)c * a.i0_cstride) * m1;
-                acc0 += a.za0 * fabsf(c0[c][j] - w0);
-                acc1 += a.za1 * fabsf(c1[c][j] - w1);
+                const float c0 = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb), c1 = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb);
+                const float w0 = (fit ? pl_sample(t0, b0, win + c * PL_PLANE, oxA, oyA) : fldr_tap_sample_p(t0p, i1 + (int64_t)c * a.i1_cstride)) * m0;
+                const float w1 = (fit ? pl_sample(t1, b1, win + (3 + c) * PL_PLANE, oxB, oyB) : fldr_tap_sample_p(t1p, i0 + (int64_t)c * a.i0_cstride)) * m1;
+                acc0 += a.za0 * fabsf(c0 - w0);
+                acc1 += a.za1 * fabsf(c1 - w1);
             }
-            z0v[j] = fldr_div_by(acc0, 3.0f, 1.0f / 3.0f);
-            z1v[j] = fldr_div_by(acc1, 3.0f, 1.0f / 3.0f);
+            prep_stf(a.z0 + o1, pixb, fldr_div_by(acc0, 3.0f, 1.0f / 3.0f));
+            prep_stf(a.z1 + o1, pixb, fldr_div_by(acc1, 3.0f, 1.0f / 3.0f));
         }
-        prep_stv<R>(a.z0 + o1, pixb, z0v);
-        prep_stv<R>(a.z1 + o1, pixb, z1v);
     }
-    if (ph1) {
-        float v[4][R];
+    if (!ph2) return;
+
+    // ---- phase 2: backward flows (fLDRnet.py:474-475) from the low-resolution field, then the backward-warped frames (:478-479) ----
+    float fb0x[PL_RPT], fb0y[PL_RPT], fb1x[PL_RPT], fb1y[PL_RPT];
+    uint32_t mnA = 0x7fff7fffu, mxA = 0u, mnB = 0x7fff7fffu, mxB = 0u;       // A: I0 at flowback_0, B: I1 at flowback_1
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            v[0][j] = prep_up(q, 2, lx[j], ly, a.mul, 1, tv);  v[1][j] = prep_up(q, 3, lx[j], ly, a.mul, 1, tv);
-            v[2][j] = prep_up(q, 0, lx[j], ly, a.mul, 1, omt); v[3][j] = prep_up(q, 1, lx[j], ly, a.mul, 1, omt);
-        }
-        prep_stv<R>(a.flow_t0 + o2, pixb, v[0]); prep_stv<R>(a.flow_t0 + o2 + HW, pixb, v[1]);
-        prep_stv<R>(a.flow_t1 + o2, pixb, v[2]); prep_stv<R>(a.flow_t1 + o2 + HW, pixb, v[3]);
+    for (int k = 0; k < PL_RPT; ++k) {
+        fb0x[k] = fb0y[k] = fb1x[k] = fb1y[k] = 0.0f;
+        if (!live[k]) continue;
+        const int py = py0 + 4 * k;
+        const float fpy = (float)py;
+        const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;
+        const FldrTap tb0 = fldr_grid_tap(fpx, fpy, omt * f01x[k], omt * f01y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+        const FldrTap tb1 = fldr_grid_tap(fpx, fpy, tv * f10x[k], tv * f10y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+        const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
+        const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
+        float x0, y0, x1, y1;
+        prep_sample_up2(tb0, tb0p, lo10, a, tv, x0, y0);
+        prep_sample_up2(tb1, tb1p, lo01, a, omt, x1, y1);
+        x0 = x0 * mb0; y0 = y0 * mb0; x1 = x1 * mb1; y1 = y1 * mb1;
+        fb0x[k] = x0; fb0y[k] = y0; fb1x[k] = x1; fb1y[k] = y1;
+        prep_stf(a.flowback_0 + o2, pixb, x0); prep_stf(a.flowback_0 + o2 + HW, pixb, y0);
+        prep_stf(a.flowback_1 + o2, pixb, x1); prep_stf(a.flowback_1 + o2 + HW, pixb, y1);
+        const PlBox b0 = pl_box(fldr_grid_tap(fpx, fpy, x0, y0, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+        const PlBox b1 = pl_box(fldr_grid_tap(fpx, fpy, x1, y1, a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
+        mnA = pl_min2(mnA, pl_pack(b0.xa, b0.ya)); mxA = pl_max2(mxA, pl_pack(b0.xb, b0.yb));
+        mnB = pl_min2(mnB, pl_pack(b1.xa, b1.ya)); mxB = pl_max2(mxB, pl_pack(b1.xb, b1.yb));
     }
-    if (ph2) {
-        float fb[4][R];                                                    // flowback_0 (x, y), flowback_1 (x, y) of the run's pixels
+    const bool fit = reduce_boxes(red_base + 16, mnA, mxA, mnB, mxB);
+    if (fit) fill_windows(i0, a.i0_cstride, i1, a.i1_cstride);
 #pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const float fpx = (float)(px0 + j);
-            const FldrTap tb0 = fldr_grid_tap(fpx, fpy, omt * f01x[j], omt * f01y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
-            const FldrTap tb1 = fldr_grid_tap(fpx, fpy, tv * f10x[j], tv * f10y[j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
-            const FldrTapP tb0p = fldr_tap_prepare(tb0, a.W, a.H), tb1p = fldr_tap_prepare(tb1, a.W, a.H);
-            const float mb0 = a.withmask ? fldr_tap_mask_p(tb0p) : 1.0f, mb1 = a.withmask ? fldr_tap_mask_p(tb1p) : 1.0f;
-            float fb0x, fb0y, fb1x, fb1y;
-            prep_sample_up2(tb0, tb0p, lo10, a, tv, fb0x, fb0y);
-            prep_sample_up2(tb1, tb1p, lo01, a, omt, fb1x, fb1y);
-            fb[0][j] = fb0x * mb0; fb[1][j] = fb0y * mb0; fb[2][j] = fb1x * mb1; fb[3][j] = fb1y * mb1;
-        }
-        prep_stv<R>(a.flowback_0 + o2, pixb, fb[0]); prep_stv<R>(a.flowback_0 + o2 + HW, pixb, fb[1]);
-        prep_stv<R>(a.flowback_1 + o2, pixb, fb[2]); prep_stv<R>(a.flowback_1 + o2 + HW, pixb, fb[3]);
-        float im[6][R];
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-            const float fpx = (float)(px0 + j);
-            const FldrTapP ti0 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, fb[0][j], fb[1][j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-            const FldrTapP ti1 = fldr_tap_prepare(fldr_grid_tap(fpx, fpy, fb[2][j], fb[3][j], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1), a.W, a.H);
-            const float mi0 = a.withmask ? fldr_tap_mask_p(ti0) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1) : 1.0f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                im[c][j] = fldr_tap_sample_p(ti0, i0 + (int64_t)c * a.i0_cstride) * mi0;
-                im[3 + c][j] = fldr_tap_sample_p(ti1, i1 + (int64_t)c * a.i1_cstride) * mi1;
-            }
-        }
+    for (int k = 0; k < PL_RPT; ++k) {
+        if (!live[k]) continue;
+        const int py = py0 + 4 * k;
+        const float fpy = (float)py;
+        const uint32_t pixb = (__umul24((uint32_t)py, (uint32_t)a.W) + (uint32_t)px) * 4u;
+        const FldrTap ti0 = fldr_grid_tap(fpx, fpy, fb0x[k], fb0y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+        const FldrTap ti1 = fldr_grid_tap(fpx, fpy, fb1x[k], fb1y[k], a.W, a.H, a.inv_wm1, a.inv_hm1, a.r_wm1, a.r_hm1);
+        const FldrTapP ti0p = fldr_tap_prepare(ti0, a.W, a.H), ti1p = fldr_tap_prepare(ti1, a.W, a.H);
+        const PlBox b0 = pl_box(ti0, a.W, a.H), b1 = pl_box(ti1, a.W, a.H);
+        const float mi0 = a.withmask ? fldr_tap_mask_p(ti0p) : 1.0f, mi1 = a.withmask ? fldr_tap_mask_p(ti1p) : 1.0f;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            prep_stv<R>(a.im0_tot + o3 + (int64_t)c * HW, pixb, im[c]);
-            prep_stv<R>(a.im1_tot + o3 + (int64_t)c * HW, pixb, im[3 + c]);
+            const float v0 = (fit ? pl_sample(ti0, b0, win + c * PL_PLANE, oxA, oyA) : fldr_tap_sample_p(ti0p, i0 + (int64_t)c * a.i0_cstride)) * mi0;
+            const float v1 = (fit ? pl_sample(ti1, b1, win + (3 + c) * PL_PLANE, oxB, oyB) : fldr_tap_sample_p(ti1p, i1 + (int64_t)c * a.i1_cstride)) * mi1;
+            prep_stf(a.im0_tot + o3 + (int64_t)c * HW, pixb, v0);
+            prep_stf(a.im1_tot + o3 + (int64_t)c * HW, pixb, v1);
         }
     }
 }
 
-static int g_prep_quad = 0;                      // pixels per thread where the geometry allows: 0 / 1 one (the kernel above), 2, 4
-static int g_prep_xcd = 0;                       // 0: tiles dealt to the workgroups in row-major order (cross-check / A-B)
-FLDR_HOOK int fldr_debug_prep_xcd(int v) { if (v == 0 || v == 1) g_prep_xcd = v; return g_prep_xcd; }
-FLDR_HOOK int fldr_debug_prep_quad(int v) { if (v == 0 || v == 1 || v == 2 || v == 4) g_prep_quad = v; return g_prep_quad; }
+#endif  // FLDR_TEST_HOOKS (LDS-staged gather windows)
 
-static inline bool prep_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static int g_prep_variant = 0;                   // test build: 1 = LDS-staged gather windows where the geometry allows; 0 (default, product): the kernel with global gathers
+FLDR_HOOK int fldr_debug_prep_variant(int v) { if (v == 0 || v == 1) g_prep_variant = v; return g_prep_variant; }
 
 extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->ws && d->flow_lo && d->I0 && d->I1 && d->t && d->flow_t0 && d->flow_t1 && d->flowback_0 && d->flowback_1);
@@ -452,21 +525,21 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
     if (!(d->phase & 4))                                          // bit 2: d->ws already holds the interleaved flow (second phase of a split call)
         hipLaunchKernelGGL(prep_interleave_kernel, dim3(fldr_cdiv(hw, 256), d->N), dim3(256), 0, fldr_s(stream), d->flow_lo,
                            reinterpret_cast<float2*>(d->ws), hw);
-    const int64_t HW = (int64_t)d->H * d->W;
-    const int R = g_prep_quad == 2 ? 2 : 4;
-    const bool quad = g_prep_quad > 1 && a.kx >= 3 && !(d->W & 3) && !(HW & 3) && !(a.i0_cstride & 3) && !(a.i1_cstride & 3) && !(a.i0_bstride & 3) &&
-                      !(a.i1_bstride & 3) && prep_al16(a.I0) && prep_al16(a.I1) && (!a.z0 || (prep_al16(a.z0) && prep_al16(a.z1))) && prep_al16(a.flow_t0) &&
-                      prep_al16(a.flow_t1) && prep_al16(a.flowback_0) && prep_al16(a.flowback_1) && prep_al16(a.im0_tot) && prep_al16(a.im1_tot);
-    a.tiles_x = fldr_cdiv(d->W, quad ? 64 * R : 64);
-    a.n_tiles = a.tiles_x * fldr_cdiv(d->H, 4);
-    if ((int64_t)a.n_tiles * a.tiles_x >= (1ll << 32)) return FLDR_E_SHAPE;                      // exactness of the umulhi division
-    a.m_tiles_x = (uint32_t)((1ull << 32) / (uint32_t)a.tiles_x) + 1u;
-    // whole tile rows per XCD (a band of rows); g_prep_xcd == 0: tiles dealt round-robin as before (tiles_per_xcd = n_tiles on "XCD" 0 .. 7
-    // is expressed by one tile per step: see prep_tile)
-    a.tiles_per_xcd = g_prep_xcd ? fldr_cdiv(fldr_cdiv(a.n_tiles, a.tiles_x), 8) * a.tiles_x : 0;
-    dim3 grid(8 * (g_prep_xcd ? a.tiles_per_xcd : fldr_cdiv(a.n_tiles, 8)), d->N);
-    if (quad && R == 4) hipLaunchKernelGGL(level0_prep_run_kernel<4>, grid, dim3(256), 0, fldr_s(stream), a);
-    else if (quad) hipLaunchKernelGGL(level0_prep_run_kernel<2>, grid, dim3(256), 0, fldr_s(stream), a);
-    else hipLaunchKernelGGL(level0_prep_kernel, grid, dim3(256), 0, fldr_s(stream), a);
+    // LDS windows: 16-byte DMA chunks need W % 4 == 0 and 16-byte aligned planes; corner coordinates are packed as int16
+    const bool al16 = !((reinterpret_cast<uintptr_t>(a.I0) | reinterpret_cast<uintptr_t>(a.I1)) & 15) && !((a.i0_cstride | a.i1_cstride | a.i0_bstride | a.i1_bstride) & 3);
+#ifdef FLDR_TEST_HOOKS
+    if (g_prep_variant == 1 && !(d->W & 3) && d->W >= 4 && d->W < 32768 && d->H < 32768 && al16) {
+        static std::atomic<uint64_t> attr_done{0};
+        if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&level0_prep_lds_kernel), PL_LDS_BYTES, attr_done)) return e;
+        dim3 grid(fldr_cdiv(d->W, PL_TW), fldr_cdiv(d->H, PL_TH), d->N);
+        hipLaunchKernelGGL(level0_prep_lds_kernel, grid, dim3(256), PL_LDS_BYTES, fldr_s(stream), a);
+        FLDR_LAUNCH_RET();
+    }
+#endif
+    (void)al16;
+    dim3 grid(fldr_cdiv(d->W, 64), fldr_cdiv(d->H, 4), d->N);
+    if (a.phase == 1) hipLaunchKernelGGL(level0_prep_kernel<1>, grid, dim3(256), 0, fldr_s(stream), a);
+    else if (a.phase == 2) hipLaunchKernelGGL(level0_prep_kernel<2>, grid, dim3(256), 0, fldr_s(stream), a);
+    else hipLaunchKernelGGL(level0_prep_kernel<3>, grid, dim3(256), 0, fldr_s(stream), a);
     FLDR_LAUNCH_RET();
 }

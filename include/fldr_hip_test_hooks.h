@@ -34,8 +34,7 @@ int fldr_debug_s2_xshift(int v);                                   /* tile-grid 
 int fldr_debug_s2_vec4(int v);                                     /* 16-byte staging loads of the persistent stride-2 kernel: 1 (default) / 0 */
 int fldr_debug_dec3_xshift(int v);                                 /* tile-grid shift of dec3_synth (low-resolution columns; -1: default) */
 int fldr_debug_splat_group_fold(int v);                            /* fldr_softsplat_acc64, > 3 channels: 1 all channel groups of a tile in one workgroup where the map is large enough, 0 (default) one group per workgroup; other: query.  Same results */
-int fldr_debug_prep_quad(int v);                                  /* fldr_level0_prep: 1 (default) runs of four pixels per thread where x8-or-more upsampling, W % 4 == 0 and 16-byte aligned planes allow, 0 one pixel per thread; other: query.  Bit-identical results */
-int fldr_debug_prep_xcd(int v);                                   /* tile order of fldr_level0_prep: 1 (default) a contiguous band of tile rows per XCD, 0 row-major deal; other: query.  Identical results */
+int fldr_debug_prep_variant(int v);                               /* fldr_level0_prep: 0 (default = the product's kernel) global gathers, 1 backward-warp gathers from LDS-staged windows (64 x 16 tiles; W % 4 == 0, 16-byte aligned frames; measured not faster on coherent flows: test build only); other: query.  Bit-identical results */
 int fldr_debug_conv_occupancy(int* out4);
 
 /* The destination-owned splats of rounds 1-2 (csrc/splat_tile_kernels.hip: claim-and-add bands without atomics; the LDS-f32-atomic

@@ -114,43 +114,58 @@ def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
     assert torch.equal(r["im0_tot"], hip.bwarp(I0, fb0, True)) and torch.equal(r["im1_tot"], hip.bwarp(I1, fb1, True))
 
 
-@pytest.mark.parametrize("shape", [(1, 20, 70, 8, 0.5, 6.0), (2, 9, 33, 8, 0.125, 60.0), (1, 6, 40, 16, 0.75, 3.0), (1, 37, 45, 8, 0.3, 400.0)])
-def test_level0_prep_runs_of_four_bit_identical(hip, hooks, dev, shape):
-    """Round 4: the level-0 prep kernel with a run of four pixels per thread (16-byte loads / streaming stores, the low-resolution
-    neighbourhood shared by the run) and XCD-banded tiles against the thread-per-pixel kernel in row-major order: every plane
-    bit-identical — contiguous frames, frames read in place as channel-strided views, the two-phase call, wild flows, partial
-    tiles (W = 560: 2.19 tiles of 256 pixels) — and the fallback on planes that are not 16-byte aligned."""
-    N, h, w, up, tv, amp = shape
+@pytest.mark.parametrize("shape", [(1, 20, 70, 8, 0.5, 1.0, "shift"), (2, 9, 33, 8, 0.125, 6.0, "noise"), (1, 6, 40, 16, 0.75, 3.0, "noise"), (1, 37, 45, 8, 0.3, 400.0, "noise"),
+                                   (1, 24, 32, 8, 0.5, 0.2, "zoom"), (1, 11, 14, 3, 0.3, 2.0, "noise"), (1, 20, 21, 4, 0.6, 30.0, "edge")])
+def test_level0_prep_lds_windows_bit_identical(hip, hooks, dev, shape):
+    """Round 4: fldr_level0_prep with the backward-warp gathers served from LDS-staged windows (64 x 16 tiles; the exact corner box of
+    each tap pair found by a workgroup reduction, staged by 16-byte LDS-DMA) against the thread-per-pixel kernel with global gathers:
+    every plane bit-identical — rigid shifts (every window fits), smooth zoom, noise and 400 px wild flows (windows that do not fit fall
+    back per tile), a motion edge, frames read in place as channel-strided views, the two-phase call, partial tiles, W % 4 != 0 and
+    frames at a 4-byte offset (whole call falls back)."""
+    N, h, w, up, tv, amp, kind = shape
     H, W = h * up, w * up
     g = _gen(77)
-    flow_lo = ((torch.rand(N, 4, h, w, generator=g) - 0.5) * amp).to(dev)
+    if kind == "shift":
+        flow_lo = (torch.tensor([-0.75, -0.5, 0.75, 0.5]).view(1, 4, 1, 1) + (torch.rand(N, 4, h, w, generator=g) - 0.5) * 0.02 * amp)
+    elif kind == "zoom":
+        ys, xs = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+        fx, fy = (xs - w / 2) * 0.03 * amp, (ys - h / 2) * 0.03 * amp
+        flow_lo = torch.stack([fx, fy, -fx, -fy], 0).unsqueeze(0).repeat(N, 1, 1, 1)
+    elif kind == "edge":
+        flow_lo = torch.zeros(N, 4, h, w)
+        flow_lo[:, :, :, w // 2:] = torch.tensor([amp / up, 1.0, -amp / up, -1.0]).view(1, 4, 1, 1)
+    else:
+        flow_lo = (torch.rand(N, 4, h, w, generator=g) - 0.5) * amp
+    flow_lo = flow_lo.to(dev)
     x = (torch.rand(N, 3, 2, H, W, generator=g) * 2 - 1).to(dev)
     t4 = torch.full((N, 1, 1, 1), tv).to(dev)
     keys = ("z0", "z1", "flow_t0", "flow_t1", "flowback_0", "flowback_1", "im0_tot", "im1_tot")
     I0, I1 = x[:, :, 0], x[:, :, 1]                                       # strided views: read in place
-    hooks.fldr_debug_prep_quad(0); hooks.fldr_debug_prep_xcd(0)
-    ref = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
     try:
-        for quad, xcd in ((0, 1), (2, 0), (4, 0), (4, 1)):
-            hooks.fldr_debug_prep_quad(quad); hooks.fldr_debug_prep_xcd(xcd)
-            r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
-            for k in keys:
-                assert torch.equal(r[k], ref[k]), (quad, xcd, k)
-            rc = hip.level0_prep(flow_lo, I0.contiguous(), I1.contiguous(), t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
-            st = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True, phase=1)
-            st = hip.level0_prep(None, None, None, None, H, W, 0, 0, state=st)
-            for k in keys:
-                assert torch.equal(rc[k], ref[k]) and torch.equal(st[k], ref[k]), (quad, xcd, k)
-        # frames at a 4-byte offset: the run kernel's 16-byte loads do not apply, the call must fall back and still agree
-        hooks.fldr_debug_prep_quad(4)
+        hooks.fldr_debug_prep_variant(0)
+        ref = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+        hooks.fldr_debug_prep_variant(1)
+        r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+        rc = hip.level0_prep(flow_lo, I0.contiguous(), I1.contiguous(), t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+        st = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True, phase=1)
+        st = hip.level0_prep(None, None, None, None, H, W, 0, 0, state=st)
+        nz = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=False, want_z=False)
+        hooks.fldr_debug_prep_variant(0)
+        nz0 = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=False, want_z=False)
+        for k in keys:
+            assert torch.equal(r[k], ref[k]) and torch.equal(rc[k], ref[k]) and torch.equal(st[k], ref[k]), k
+            if not k.startswith("z"):
+                assert torch.equal(nz[k], nz0[k]), k
+        # frames at a 4-byte offset: no 16-byte chunks — the call falls back to the global-gather kernel and still agrees
+        hooks.fldr_debug_prep_variant(1)
         buf = torch.empty(x.numel() + 1, device=dev)
         buf[1:] = x.reshape(-1)
         xo = buf[1:].view_as(x)
-        r = hip.level0_prep(flow_lo, xo[:, :, 0], xo[:, :, 1], t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
+        ro = hip.level0_prep(flow_lo, xo[:, :, 0], xo[:, :, 1], t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
         for k in keys:
-            assert torch.equal(r[k], ref[k]), ("misaligned", k)
+            assert torch.equal(ro[k], ref[k]), ("misaligned", k)
     finally:
-        hooks.fldr_debug_prep_quad(0); hooks.fldr_debug_prep_xcd(0)
+        hooks.fldr_debug_prep_variant(0)
 
 
 @pytest.mark.parametrize("shape", [(1, 27, 60, 8, 0.5, 6.0), (2, 13, 21, 8, 0.25, 40.0), (1, 9, 15, 4, 1.0, 2.0), (1, 34, 40, 8, 0.0, 10.0)])
