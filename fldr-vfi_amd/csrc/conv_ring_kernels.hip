@@ -23,7 +23,9 @@
 //     runs on): the grid always drains.
 #include "spk_common.h"
 
-#define RING_SLOTS 3
+#ifndef RING_SLOTS
+#define RING_SLOTS 3                            // stages of the LDS ring (2: 105 KB for the 48-channel kernel, 55 KB of the CU left to other kernels)
+#endif
 #define RING_NLOAD 4
 #define RING_SPIN_LIMIT (1 << 21)
 #ifndef RING_LOADER_PRIO

@@ -50,6 +50,11 @@ struct S2Args {
     int32_t tiles_x, n_tiles, tiles_per_xcd;
     int32_t N, wgs_per_xcd;    // persistent kernel: samples (tiles are numbered over all samples), workgroups per XCD
     int32_t x_shift;           // persistent kernel: the tile grid starts x_shift output columns left of the image (see s2_launch_pers)
+    // second problem of a pair launch (conv4x4s2_pers_spk_kernel, gridDim.y == 2): the same source and geometry, other output channels
+    const float* wpack2;
+    const float* bias2;
+    float* out2;
+    unsigned char* out_spk2;
 };
 
 // kernel tap (dy, dx) of k slot j (0..7) within row pair rp (0..1): dword d = j / 2 -> (parity, index offset); half j % 2 -> row
@@ -638,6 +643,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // ------------------------------------------------------------------------------------------------
 template <int MT, int NMT, int PT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void conv4x4s2_pers_spk_kernel(S2Args a) {
+    if (blockIdx.y) { a.wpack = a.wpack2; a.bias = a.bias2; a.out = a.out2; a.out_spk = a.out_spk2; }      // pair launch: the second half (uniform)
     using Cfg = S2Cfg<MT, NMT>;
     constexpr int KL = Cfg::KL, STEPS = Cfg::STEPS, IWHP = Cfg::IWHP, KIND = Cfg::KIND, CHS = Cfg::CHS;
     constexpr int TPR = S2_TW / MT, RPW = PT / TPR;
@@ -1047,7 +1053,7 @@ extern "C" int fldr_conv2d_s2_split(const fldr_conv_desc* d, fldr_stream_t strea
 // tensor, d->src_c[0] = cin with cin % 8 == 0, d->src_bstride[0] in BYTES (0 for N = 1); d->wpack from fldr_conv_s2_prepack).
 // Persistent kernel only: cin <= 64 and every chunk's weights in LDS; FLDR_E_SHAPE otherwise.
 template <int MT, int NMT, int PT>
-static int s2_launch_pers_spk(S2Args& a, int N, hipStream_t s, int lds_bytes) {
+static int s2_launch_pers_spk(S2Args& a, int N, hipStream_t s, int lds_bytes, int pair = 1) {
     static std::atomic<uint64_t> attr_done{0};
     if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv4x4s2_pers_spk_kernel<MT, NMT, PT>), lds_bytes, attr_done)) return e;
     a.x_shift = 0;                                                            // (pixels are 16-byte records: every window start is aligned)
@@ -1057,13 +1063,13 @@ static int s2_launch_pers_spk(S2Args& a, int N, hipStream_t s, int lds_bytes) {
     const int64_t total = (int64_t)N * a.n_tiles;
     if (total >= (1ll << 30)) return FLDR_E_SHAPE;
     a.tiles_per_xcd = (int)((total + 7) / 8);
-    const int cap = lds_bytes > 80 * 1024 ? 32 : 64;                         // workgroups per XCD that fit: one or two per CU
+    const int cap = (lds_bytes > 80 * 1024 ? 32 : 64) / pair;                // workgroups per XCD that fit: one or two per CU (a pair launch: shared by the two problems)
     a.wgs_per_xcd = a.tiles_per_xcd < cap ? a.tiles_per_xcd : cap;
-    hipLaunchKernelGGL((conv4x4s2_pers_spk_kernel<MT, NMT, PT>), dim3(8 * a.wgs_per_xcd), dim3(256), lds_bytes, s, a);
+    hipLaunchKernelGGL((conv4x4s2_pers_spk_kernel<MT, NMT, PT>), dim3(8 * a.wgs_per_xcd, pair), dim3(256), lds_bytes, s, a);
     FLDR_LAUNCH_RET();
 }
 
-extern "C" int fldr_conv2d_s2_spk(const fldr_conv_desc* d, fldr_stream_t stream) {
+static int s2_spk_run(const fldr_conv_desc* d, const fldr_conv_desc* d2, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->wpack && (d->out || d->out_spk) && d->n_src == 1 && d->src[0] && !d->src_up2[0] && !d->residual);
     FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= 64 && (d->cin & 7) == 0 && d->src_c[0] == d->cin && d->cout > 0 && d->cout <= 64);
     FLDR_CHECK_ARG(d->cout_store > 0 && d->cout_store <= d->cout && d->ksize == 4 && d->stride == 2);
@@ -1073,13 +1079,32 @@ extern "C" int fldr_conv2d_s2_spk(const fldr_conv_desc* d, fldr_stream_t stream)
     for (int s = 0; s < FLDR_CONV_MAX_SRC; ++s) { a.src[s] = nullptr; a.src_bstride[s] = 0; a.src_cstride[s] = 0; a.src_cbegin[s] = 0; }
     a.src[0] = d->src[0]; a.src_bstride[0] = d->src_bstride[0]; a.src_cbegin[FLDR_CONV_MAX_SRC] = d->cin; a.n_src = 1;
     a.wpack = d->wpack; a.bias = d->bias; a.out = d->out; a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
+    a.wpack2 = nullptr; a.bias2 = nullptr; a.out2 = nullptr; a.out_spk2 = nullptr;
+    int pair = 1;
+    if (d2) {                                                            // the same convolution geometry on the same source, other weights / outputs
+        FLDR_CHECK_ARG(d2->wpack && (d2->out || d2->out_spk) && d2->n_src == 1 && d2->src[0] == d->src[0] && d2->src_bstride[0] == d->src_bstride[0]);
+        FLDR_CHECK_ARG(d2->N == d->N && d2->cin == d->cin && d2->src_c[0] == d->cin && d2->cout == d->cout && d2->cout_store == d->cout_store && !d2->residual);
+        FLDR_CHECK_ARG(d2->Hin == d->Hin && d2->Win == d->Win && d2->Hout == d->Hout && d2->Wout == d->Wout && d2->relu == d->relu && d2->ksize == 4 && d2->stride == 2);
+        FLDR_CHECK_ARG(!d2->bias == !d->bias && !d2->out == !d->out && !d2->out_spk == !d->out_spk);
+        a.wpack2 = d2->wpack; a.bias2 = d2->bias; a.out2 = d2->out; a.out_spk2 = reinterpret_cast<unsigned char*>(d2->out_spk);
+        pair = 2;
+    }
     a.cin = d->cin; a.cout = d->cout; a.cout_store = d->cout_store;
     a.Hin = d->Hin; a.Win = d->Win; a.Hout = d->Hout; a.Wout = d->Wout; a.relu = d->relu; a.tiles_x = 0;
     int mt, nmt;
     s2_geometry(d->cout, mt, nmt);
     const int n_chunks = d->cin / S2_CC;
     hipStream_t s = fldr_s(stream);
-    if (mt == 16) { const int lds = n_chunks * S2Cfg<16, 1>::W_BYTES + 2 * S2Cfg<16, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<16, 1, 4>(a, d->N, s, lds); }
-    else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 156 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds); }   // (> 80 KB: one workgroup per CU)
+    if (mt == 16) { const int lds = n_chunks * S2Cfg<16, 1>::W_BYTES + 2 * S2Cfg<16, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<16, 1, 4>(a, d->N, s, lds, pair); }
+    else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 156 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds, pair); }   // (> 80 KB: one workgroup per CU)
     return FLDR_E_SHAPE;
+}
+
+extern "C" int fldr_conv2d_s2_spk(const fldr_conv_desc* d, fldr_stream_t stream) { return s2_spk_run(d, nullptr, stream); }
+
+// Two stride-2 convolutions of the SAME packed source with the same geometry in ONE launch (gridDim.y = 2): the two 32-channel halves of
+// enc3 (32 -> 64; one half's 64 KB of weights per workgroup in LDS, fLDRnet.py:617) — the bits of two fldr_conv2d_s2_spk calls.
+extern "C" int fldr_conv2d_s2_spk_pair(const fldr_conv_desc* d0, const fldr_conv_desc* d1, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d0 && d1);
+    return s2_spk_run(d0, d1, stream);
 }

@@ -432,7 +432,10 @@ class PCARefineUNet(nn.Module):
                 # enc3 (32 -> 64) as two persistent launches of 32 output channels on enc2's PACKED output (64 KB of weights each in
                 # LDS; the whole layer's 128 KB only fit the per-tile kernel, which exposes a load round trip per 4-channel chunk):
                 # enc2 writes no fp32 copy either; dec0 reads the two halves as two sources
-                out = [fldr_hip.conv2d_s2_spk(enc2p, w, b, relu=True, want_f32=False, want_spk=True) for (w, b) in halves]
+                if fldr_hip.ENC3_PAIR:                       # ... both halves in ONE launch (round 4)
+                    out = fldr_hip.conv2d_s2_spk_pair(enc2p, halves, relu=True)
+                else:
+                    out = [fldr_hip.conv2d_s2_spk(enc2p, w, b, relu=True, want_f32=False, want_spk=True) for (w, b) in halves]
             else:
                 out = [cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)]
             out = cs(out, self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)

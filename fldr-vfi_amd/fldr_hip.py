@@ -143,6 +143,7 @@ _SIGNATURES = {
     "fldr_conv_s2_prepack": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p]),
     "fldr_conv2d_s2_split": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_conv2d_s2_spk": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
+    "fldr_conv2d_s2_spk_pair": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_debug_s2_persistent": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_s2_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_dec3_xshift": (ctypes.c_int, [ctypes.c_int]),
@@ -667,7 +668,8 @@ def pca_table(ev, mean, meanvec):
     return tab
 
 
-ENC3_SPLIT = os.environ.get("FLDR_ENC3_SPLIT", "1") != "0"    # enc3 as two 32-channel persistent launches on enc2's packed output
+ENC3_SPLIT = os.environ.get("FLDR_ENC3_SPLIT", "1") != "0"    # enc3 as two 32-channel persistent problems on enc2's packed output
+ENC3_PAIR = os.environ.get("FLDR_ENC3_PAIR", "1") != "0"      # ... in ONE launch (fldr_conv2d_s2_spk_pair); 0: two launches
 DEC3_MFMA = os.environ.get("FLDR_DEC3_MFMA", "1") != "0"      # the fused dec3 + blend kernel reads dec2's packed output (matrix-core phase convolutions)
 PCA_RAW_MIN_BYTES = int(os.environ.get("FLDR_PCA_RAW_MIN_BYTES", "0"))      # levels of at least this many projection bytes are parked between the two passes (4K pyramid: 196.9 us none, 186.7 from 4 MB, 168.4 all)
 
@@ -1139,6 +1141,33 @@ def conv2d_s2_spk(src, weight, bias, relu=False, want_f32=True, want_spk=False):
     if want_spk:
         return (out, outp) if out is not None else outp
     return out
+
+
+def conv2d_s2_spk_pair(src, halves, relu=False):
+    """Two stride-2 4x4 convolutions of the SAME packed source in ONE launch (fldr_conv2d_s2_spk_pair): halves = [(weight, bias), (weight,
+    bias)] with equal shapes — enc3's two 32-channel halves.  -> [Spk, Spk], the bits of two conv2d_s2_spk(..., want_spk=True) calls."""
+    assert isinstance(src, Spk) and len(halves) == 2
+    N, cin, Hin, Win = src.shape
+    Hout, Wout = (Hin + 2 - 4) // 2 + 1, (Win + 2 - 4) // 2 + 1
+    descs, outs, keep = [], [], []
+    for weight, bias in halves:
+        cout, ci, k, _ = weight.shape
+        assert k == 4 and ci == cin and tuple(weight.shape) == tuple(halves[0][0].shape)
+        d = ConvDesc()
+        d.src[0], d.src_bstride[0], d.src_c[0], d.src_up2[0], d.n_src = src.ptr, (src.bstride if N > 1 else 0), cin, 0, 1
+        outp = _spk_alloc(N, cout, Hout, Wout, src.device)
+        wp = conv_s2_prepack(weight)
+        keep.append(wp)
+        d.wpack = wp.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.out, d.out_spk = None, outp.buf.data_ptr()
+        d.N, d.cin, d.cout, d.cout_store = N, cin, cout, cout
+        d.Hin, d.Win, d.Hout, d.Wout = Hin, Win, Hout, Wout
+        d.ksize, d.stride, d.relu, d.precision = 4, 2, int(bool(relu)), 0
+        descs.append(d)
+        outs.append(outp)
+    _check(lib().fldr_conv2d_s2_spk_pair(ctypes.byref(descs[0]), ctypes.byref(descs[1]), _stream()), "fldr_conv2d_s2_spk_pair")
+    return outs
 
 
 def s2_spk_ok(weight):

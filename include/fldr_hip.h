@@ -314,6 +314,9 @@ int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, f
  * of hi: same value, other split), so the results agree with that function to fp32 accumulation rounding.  Shapes whose
  * weights do not fit the persistent kernel's LDS return FLDR_E_SHAPE (use fldr_spk_unpack + fldr_conv2d_s2_split). */
 int fldr_conv2d_s2_spk(const fldr_conv_desc* desc, fldr_stream_t stream);
+/* Two such convolutions of the SAME packed source (same geometry, channel counts, relu; other weights / bias / outputs) in ONE launch:
+ * the two 32-channel halves of enc3 (fLDRnet.py:617).  The bits of two fldr_conv2d_s2_spk calls. */
+int fldr_conv2d_s2_spk_pair(const fldr_conv_desc* desc0, const fldr_conv_desc* desc1, fldr_stream_t stream);
 int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.

@@ -372,6 +372,11 @@ def test_stride2_conv_on_packed_source(hip, dev, shape):
     assert torch.equal(hip.spk_pack(got32).buf, gotp.buf)
     only = hip.conv2d_s2_spk(xp, wt, b, relu=True, want_f32=False, want_spk=True)
     assert torch.equal(only.buf, gotp.buf)
+    # two convolutions of the same packed source in one launch (enc3's halves): the bits of the two separate calls
+    wt2 = (torch.rand(*wt.shape, generator=_gen(8)) - 0.5).to(dev) * 0.1
+    b2 = (torch.rand(wt.shape[0], generator=_gen(9)) - 0.5).to(dev)
+    pa, pb = hip.conv2d_s2_spk_pair(xp, [(wt, b), (wt2, b2)], relu=True)
+    assert torch.equal(pa.buf, gotp.buf) and torch.equal(pb.buf, hip.conv2d_s2_spk(xp, wt2, b2, relu=True, want_f32=False, want_spk=True).buf)
     ref = F.relu(F.conv2d(xv.double().cpu(), wt.double().cpu(), b.double().cpu(), stride=2, padding=1))
     a32 = hip.conv2d([xv], wt, b, stride=2, relu=True, precision="fp32").double().cpu()
     e32, esp = (a32 - ref).abs().mean().item(), (got32.double().cpu() - ref).abs().mean().item()
