@@ -425,9 +425,13 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                         for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[r];
                     }
                     if (spkn) {
+#if defined(RING_ABLATE) && RING_ABLATE == 6                          // diagnostic: the finish without its packed stores
+                        asm volatile("" :: "v"(ohi), "v"(olo));
+#else
                         const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)(lg & 1) * 8u;
                         *reinterpret_cast<h4*>(spkn + off) = ohi;
                         *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+#endif
                     }
                 }
             }
