@@ -125,7 +125,7 @@ def dominant_conv_roofline(model, h, w, device, steps):
 def _measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate --pmc passes); newest round first."""
-    for name in ("r03_conv96_spk_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
+    for name in ("r04_conv96_spk_traffic.json", "r03_conv96_spk_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
             return v, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_round.sh; not measured in this run)" % name
