@@ -50,6 +50,107 @@ __global__ __launch_bounds__(256) void pyramid_bicubic_kernel(const float* __res
     dst[((int64_t)plane * Hd + y) * Wd + x] = ((r[0] * c0 + r[1] * c1) + r[2] * c1) + r[3] * c0;
 }
 
+// ---- ingest + the whole pyramid in ONE pass (round 4) ---------------------------------------------------------------------
+// The two kernels above move 262 MB (ingest: one byte load and one 4-byte store per thread, >= 124 us at 4K) and then read level 0
+// once per pyramid level (five launches, ~2.3 x 212 MB).  For power-of-two factors s <= 64 the 4x4 bicubic footprint of a level-i
+// pixel lies inside one s x s cell of level 0 (taps at s x + s/2 - 2 ... s x + s/2 + 1), except for level 1 (one pixel of halo).
+// So a workgroup stages ONE 64 x 64 tile (+ halo) of one level-0 plane in LDS — uint8 in, four pixels per dword load, normalised
+// and reflect-padded on the way — writes it out with 16-byte stores and produces the tile's pixels of EVERY level from LDS:
+// 50 MB in, 283 MB out, one launch.  Same expressions and operation order as ingest_kernel / pyramid_bicubic_kernel: the same bits.
+#define IP_T 64                               // level-0 tile edge
+#define IP_LW 72                              // LDS row: columns X0 - 4 ... X0 + 67 (16-byte aligned pieces)
+#define IP_LH 66                              // LDS rows: Y0 - 1 ... Y0 + 64
+#define IP_MAX_LEVELS 7                       // level 0 + factors 2 ... 64
+struct IpArgs {
+    const uint8_t* u8;
+    float* lv[IP_MAX_LEVELS];
+    int n_levels, H, W, Hp, Wp;
+};
+__device__ __forceinline__ float ip_norm(uint8_t v) {
+#pragma clang fp contract(off)
+    float f = (float)v / 255.0f;
+    f = f * 2.0f;
+    return f - 1.0f;
+}
+__global__ __launch_bounds__(256) void ingest_pyramid_kernel(IpArgs a) {
+#pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) float tile[IP_LH * IP_LW];
+    const int tid = threadIdx.x;
+    const int X0 = blockIdx.x * IP_T, Y0 = blockIdx.y * IP_T;
+    const int bct = blockIdx.z;                                          // ((b*3 + c)*2 + t) in the output
+    const int t = bct & 1, c = (bct >> 1) % 3, b = bct / 6;
+    const uint8_t* src = a.u8 + ((int64_t)(b * 2 + t) * 3 + c) * a.H * a.W;
+    // stage: one item = 4 columns of one row; level-0 coordinates clamped to the padded image (the pyramid's tap clamp), then
+    // reflected into the frame (F.pad(mode='reflect'), main.py:848)
+    for (int e = tid; e < IP_LH * (IP_LW / 4); e += 256) {
+        const int r = e / (IP_LW / 4), q = e - r * (IP_LW / 4);
+        const int yc = min(max(Y0 - 1 + r, 0), a.Hp - 1);
+        const int sy = yc < a.H ? yc : 2 * (a.H - 1) - yc;
+        const int x = X0 - 4 + 4 * q;
+        float4 v;
+        if (x >= 0 && x + 3 < a.W && !(a.W & 3) && !((uintptr_t)a.u8 & 3)) {       // aligned dword of four frame pixels
+            const uint32_t w = *reinterpret_cast<const uint32_t*>(src + (int64_t)sy * a.W + x);
+            v = make_float4(ip_norm((uint8_t)w), ip_norm((uint8_t)(w >> 8)), ip_norm((uint8_t)(w >> 16)), ip_norm((uint8_t)(w >> 24)));
+        } else {
+            float f[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int xc = min(max(x + k, 0), a.Wp - 1);
+                const int sx = xc < a.W ? xc : 2 * (a.W - 1) - xc;
+                f[k] = ip_norm(src[(int64_t)sy * a.W + sx]);
+            }
+            v = make_float4(f[0], f[1], f[2], f[3]);
+        }
+        *reinterpret_cast<float4*>(tile + r * IP_LW + 4 * q) = v;
+    }
+    __syncthreads();
+    // level 0: the tile itself (rows 1 .. 64, columns 4 .. 67 of the LDS image), 16-byte stores
+    {
+        float* out = a.lv[0] + (int64_t)bct * a.Hp * a.Wp;
+        for (int e = tid; e < IP_T * (IP_T / 4); e += 256) {
+            const int r = e / (IP_T / 4), q = e - r * (IP_T / 4);
+            const int y = Y0 + r, x = X0 + 4 * q;
+            if (y < a.Hp && x < a.Wp)                                    // (Wp % 4 == 0: host-checked)
+                *reinterpret_cast<float4*>(out + (int64_t)y * a.Wp + x) = *reinterpret_cast<const float4*>(tile + (r + 1) * IP_LW + 4 + 4 * q);
+        }
+    }
+    // levels 1 ..: pyramid_bicubic_kernel's arithmetic on the staged tile (cubic convolution, A = -0.75, fraction 0.5)
+    const float c0 = -0.09375f, c1 = 0.59375f;
+    for (int l = 1; l < a.n_levels; ++l) {
+        const int s = 1 << l, n = IP_T >> l;                             // n x n outputs of this level in the tile
+        const int Hd = a.Hp >> l, Wd = a.Wp >> l;
+        float* out = a.lv[l] + (int64_t)bct * Hd * Wd;
+        for (int e = tid; e < n * n; e += 256) {
+            const int oy = e / n, ox = e - oy * n;
+            const int gy = (Y0 >> l) + oy, gx = (X0 >> l) + ox;
+            if (gy >= Hd || gx >= Wd) continue;
+            const int lr = oy * s + s / 2 - 1, lc = ox * s + s / 2 + 2;  // LDS row / column of tap (0, 0): fy - 1 - (Y0 - 1), fx - 1 - (X0 - 4)
+            float r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float* row = tile + (lr + j) * IP_LW + lc;
+                r[j] = ((row[0] * c0 + row[1] * c1) + row[2] * c1) + row[3] * c0;
+            }
+            out[(int64_t)gy * Wd + gx] = ((r[0] * c0 + r[1] * c1) + r[2] * c1) + r[3] * c0;
+        }
+    }
+}
+
+// frames_u8 [B,2,3,H,W] -> levels[i] = [B,3,2,Hp >> i,Wp >> i] fp32 for i < n_levels (1 .. 7): fldr_ingest_u8 + fldr_pyramid_bicubic for every
+// level (main.py:840-856) in one launch, the same bits.  Hp, Wp multiples of 2^(n_levels-1) and of 4; pad < size.
+extern "C" int fldr_ingest_pyramid_u8(const uint8_t* frames_u8, float* const* levels, int n_levels, int B, int H, int W, int Hp, int Wp,
+                                      fldr_stream_t stream) {
+    FLDR_CHECK_ARG(frames_u8 && levels && n_levels >= 1 && n_levels <= IP_MAX_LEVELS && B > 0 && H > 1 && W > 1 && Hp >= H && Wp >= W);
+    if (Hp - H >= H || Wp - W >= W) return FLDR_E_SHAPE;            // reflect padding needs pad < size
+    if ((Wp & 3) || (Hp & ((1 << (n_levels - 1)) - 1)) || (Wp & ((1 << (n_levels - 1)) - 1))) return FLDR_E_SHAPE;
+    IpArgs a;
+    a.u8 = frames_u8; a.n_levels = n_levels; a.H = H; a.W = W; a.Hp = Hp; a.Wp = Wp;
+    for (int i = 0; i < IP_MAX_LEVELS; ++i) { a.lv[i] = i < n_levels ? levels[i] : nullptr; FLDR_CHECK_ARG(i >= n_levels || levels[i]); }
+    dim3 grid(fldr_cdiv(Wp, IP_T), fldr_cdiv(Hp, IP_T), B * 6);
+    hipLaunchKernelGGL(ingest_pyramid_kernel, grid, dim3(256), 0, fldr_s(stream), a);
+    FLDR_LAUNCH_RET();
+}
+
 extern "C" int fldr_ingest_u8(const uint8_t* frames_u8, float* level0, int B, int H, int W, int Hp, int Wp,
                               fldr_stream_t stream) {
     FLDR_CHECK_ARG(frames_u8 && level0 && B > 0 && H > 1 && W > 1 && Hp >= H && Wp >= W);

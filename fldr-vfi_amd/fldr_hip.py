@@ -179,6 +179,7 @@ _SIGNATURES = {
                                            _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
+    "fldr_ingest_pyramid_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
     "fldr_ssim_y_ws_doubles": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_ssim_y_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_frame_metrics": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -1296,6 +1297,9 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
     return (out, refine) if want_refine else out
 
 
+INGEST_FUSED = os.environ.get("FLDR_INGEST_FUSED", "1") != "0"     # ingest + all pyramid levels in one launch (0: one launch per level)
+
+
 def ingest_pyramid(frames_u8, n_levels=6):
     """uint8 frames [B,2,3,H,W] on the device -> the model's normInput list (level i: [B,3,2,Hp/2^i,Wp/2^i] fp32):
     normalisation, reflect padding and the direct bicubic pyramid of main.py:840-856, all on the GPU."""
@@ -1304,6 +1308,12 @@ def ingest_pyramid(frames_u8, n_levels=6):
     div = (2 ** (n_levels - 1)) * 8
     Hp, Wp = (H + div - 1) // div * div, (W + div - 1) // div * div
     u8 = frames_u8.contiguous()
+    if INGEST_FUSED and n_levels <= 7 and Wp % 4 == 0:
+        # one launch: the uint8 frames are read once, every level is written from a staged 64 x 64 tile (fldr_ingest_pyramid_u8)
+        pyr = [torch.empty(B, 3, 2, Hp >> i, Wp >> i, device=u8.device, dtype=torch.float32) for i in range(n_levels)]
+        ptrs = (ctypes.c_void_p * n_levels)(*[p.data_ptr() for p in pyr])
+        _check(lib().fldr_ingest_pyramid_u8(_dev(u8, "frames", torch.uint8), ptrs, n_levels, B, H, W, Hp, Wp, _stream()), "fldr_ingest_pyramid_u8")
+        return pyr
     lv0 = torch.empty(B, 3, 2, Hp, Wp, device=u8.device, dtype=torch.float32)
     code = lib().fldr_ingest_u8(_dev(u8, "frames", torch.uint8), _dev(lv0, "level0"), B, H, W, Hp, Wp, _stream())
     _check(code, "fldr_ingest_u8")

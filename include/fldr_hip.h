@@ -416,6 +416,12 @@ int fldr_ingest_u8(const uint8_t* frames_u8, float* level0, int B, int H, int W,
  * (main.py:855-856), factor a power of two >= 2.  level0 [planes,Hp,Wp] -> level_i [planes,Hp/factor,Wp/factor]. */
 int fldr_pyramid_bicubic(const float* level0, float* level_i, int planes, int Hp, int Wp, int factor, fldr_stream_t stream);
 
+/* Both of the above for every level in ONE launch (one read of the uint8 frames, every level written from a staged 64 x 64 tile):
+ * levels[i] = [B,3,2,Hp >> i,Wp >> i] for i < n_levels <= 7; Hp, Wp multiples of 2^(n_levels-1) and of 4.  The bits of fldr_ingest_u8 +
+ * fldr_pyramid_bicubic (main.py:840-856). */
+int fldr_ingest_pyramid_u8(const uint8_t* frames_u8, float* const* levels, int n_levels, int B, int H, int W, int Hp, int Wp,
+                           fldr_stream_t stream);
+
 /* main.py:885-911 on the device: crop pred [B,3,Hp,Wp] (fp64 if pred_is_f64 else fp32) to H x W, (x+1)/2 clipped to
  * [0,1] * 255, rounded half-to-even; optionally written as uint8 [B,3,H,W]; when target_u8 [B,3,H,W] is given,
  * sse[b] (zeroed by the caller) accumulates the squared error, so PSNR = 10 log10(255^2 * 3HW / sse[b]). */

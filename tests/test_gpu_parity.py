@@ -1355,6 +1355,27 @@ def test_gpu_ingest_matches_cpu_caller(hip, oracle, dev, size):
         _cmp(got[i], ref[i], atol=2e-6, what="bicubic level %d" % i)
 
 
+@pytest.mark.parametrize("case", [(200, 328, 6, 1), (260, 515, 6, 2), (130, 258, 4, 1), (300, 522, 7, 1), (64, 70, 3, 1), (2160, 3840, 6, 1)])
+def test_fused_ingest_pyramid_bit_identical(hip, dev, case):
+    """Round 4: fldr_ingest_pyramid_u8 (the uint8 frames read once, every pyramid level written from a staged 64 x 64 tile, one launch)
+    against fldr_ingest_u8 + one fldr_pyramid_bicubic per level: every level bit for bit — widths that are not multiples of 4 (byte
+    path), reflect padding across tile borders, batch of 2, 3 ... 7 levels, the 4K geometry."""
+    import fldr_harness as Hn
+    H, W, nl, B = case
+    u8 = torch.stack([Hn.synthetic_pair(H, W, seed=20 + k, quadrant=True) for k in range(B)], 0).to(dev)
+    prev = hip.INGEST_FUSED
+    try:
+        hip.INGEST_FUSED = False
+        ref = hip.ingest_pyramid(u8, nl)
+        hip.INGEST_FUSED = True
+        got = hip.ingest_pyramid(u8, nl)
+    finally:
+        hip.INGEST_FUSED = prev
+    assert len(got) == len(ref) == nl
+    for i in range(nl):
+        assert got[i].shape == ref[i].shape and torch.equal(got[i], ref[i]), (i, (got[i] - ref[i]).abs().max().item())
+
+
 def test_interpolate_u8_reports_psnr_and_ssim(hip, oracle, dev, model):
     """uint8 in -> uint8 out with PSNR and SSIM-Y against a ground truth, all on the device (main.py:885-911)."""
     import fldr_harness as Hn
