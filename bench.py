@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--xtest-dir", default=None, help="X-Test style folder (<dir>/<type>/<scene>/*.png, 33 frames per scene): after the timed region every rank "
                                                       "evaluates its share of the pairs (8x: 7 outputs per pair) and parity.x_test_psnr / x_test carry the mean PSNR / SSIM-Y")
     ap.add_argument("--xtest-multiple", type=int, default=8)
+    ap.add_argument("--no-graphs", action="store_true", help="enqueue every step eagerly (default: each (stream, pair) forward is captured once in a hipGraph and replayed: "
+                                                             "the same kernels, ~0.03 instead of ~1 ms of host time per step)")
     ap.add_argument("--height", type=int, default=H4K)
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -244,7 +246,7 @@ def main():
 
     npairs = max(a.pairs, a.streams, 1)
     my_pairs = shard_pairs(world * npairs, rank, world)          # pair index = seed; disjoint across ranks
-    latency_ms = dt_e2e = sustained = fp16_mode = varying = incl = multi_t = None
+    latency_ms = latency_eager_ms = dt_e2e = sustained = fp16_mode = varying = incl = multi_t = None
     if gpu:
         import fldr_harness as Hn
         model, _, args = Hn.prepare_model(device)
@@ -263,28 +265,73 @@ def main():
         for s_ in streams:
             s_.wait_stream(torch.cuda.current_stream())
 
-        def step(i):
+        def eager_step(i):
             k = i % npairs
             with torch.cuda.stream(streams[i % len(streams)]), torch.no_grad():
                 return Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k])
+
+        # hipGraph replay (the contract's "capture launch-bound inner loops in hipGraphs"): after the eager priming below, the forward
+        # of every (stream, pair) combination is captured ONCE (the same kernels through the same C ABI on that stream; one memory pool
+        # per stream) and a step is one replay: ~0.03 ms of host time instead of ~1 ms (64 launches from Python), which keeps the loop
+        # GPU-bound on hosts that are slow or busy.  On a fast host both forms give the same rate (tools/graph_probe.py: 2.03 vs 2.04 ms;
+        # replayed frames == eager frames bit for bit).  Any capture failure falls back to eager steps and is reported.
+        graphs, graph_outs, graph_state = {}, {}, {"on": False, "why": "disabled (--no-graphs)" if a.no_graphs else "not captured yet"}
+
+        def capture_graphs():
+            try:
+                pools = [torch.cuda.graph_pool_handle() for _ in streams]
+                for s_i, st in enumerate(streams):
+                    for k in range(npairs):
+                        g = torch.cuda.CUDAGraph()
+                        with torch.no_grad(), torch.cuda.graph(g, pool=pools[s_i], stream=st):
+                            graph_outs[(s_i, k)] = Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k])
+                        graphs[(s_i, k)] = g
+                torch.cuda.synchronize()
+                # one replay against one eager forward: the same bits, or no graphs
+                with torch.cuda.stream(streams[0]), torch.no_grad():
+                    ref = Hn.interpolate(model, args, frames[0], t, pyramid=pyrs[0]).clone()
+                    graphs[(0, 0)].replay()
+                torch.cuda.synchronize()
+                if not torch.equal(ref, graph_outs[(0, 0)]):
+                    raise RuntimeError("replayed frame differs from the eager frame")
+                graph_state.update(on=True, why="%d graphs (streams x pairs), replay == eager bit for bit" % len(graphs))
+            except Exception as e:                                   # eager steps still work
+                graphs.clear(); graph_outs.clear()
+                graph_state.update(on=False, why="capture failed: %r" % (e,))
+                torch.cuda.synchronize()
+
+        def step(i):
+            if graph_state["on"]:
+                s_i, k = i % len(streams), i % npairs
+                with torch.cuda.stream(streams[s_i]):
+                    graphs[(s_i, k)].replay()
+                return graph_outs[(s_i, k)]
+            return eager_step(i)
     else:
         def step(i):
             time.sleep(1e-3)
             return None
+        eager_step = step
 
     out = None
     for i in range(max(len(streams) if gpu else 1, npairs)):      # prime every stream's allocator pool once (untimed)
-        out = step(i)
+        out = eager_step(i)
     sync()
+    if gpu and not a.no_graphs:
+        capture_graphs()
     for i in range(a.warmup):
         out = step(i)
     sync()
     if gpu:
-        tl = time.perf_counter()                                   # single-stream latency of one forward (informational)
-        for k in range(3):
-            Hn.interpolate(model, args, frames[k % npairs], t, pyramid=pyrs[k % npairs])
-        sync()
-        latency_ms = (time.perf_counter() - tl) / 3 * 1e3
+        def one_at_a_time(fn, reps=6):                            # single-stream latency: a forward alone on the GPU, host waits for it
+            for k in range(2):
+                fn(k * len(streams)); sync()
+            tl = time.perf_counter()
+            for k in range(reps):
+                fn(k * len(streams)); sync()                     # (multiples of the stream count: always stream 0)
+            return (time.perf_counter() - tl) / reps * 1e3
+        latency_ms = one_at_a_time(step)
+        latency_eager_ms = one_at_a_time(eager_step) if graph_state["on"] else latency_ms
     # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides -------------
     barrier()
     sync()
@@ -308,6 +355,18 @@ def main():
         d_s = max_over_ranks(time.perf_counter() - t1, device)
         sustained = {"seconds": round(d_s, 3), "steps": n_s, "ms_per_step": round(d_s / n_s * 1e3, 3),
                      "value": round(world * n_s / d_s, 3)}
+    if gpu and graph_state["on"]:                                  # the same loop enqueued eagerly, for the record (untimed for `value`)
+        n_e = max(a.steps, 40)
+        barrier()
+        sync()
+        t1 = time.perf_counter()
+        for i in range(n_e):
+            out = eager_step(i)
+        t_host = time.perf_counter() - t1
+        sync()
+        barrier()
+        graph_state["eager_ms_per_step"] = round((time.perf_counter() - t1) / n_e * 1e3, 3)
+        graph_state["eager_host_enqueue_ms_per_step"] = round(t_host / n_e * 1e3, 3)
     if gpu:
         # end-to-end on the device (informational, single stream): uint8 frames -> ingest kernels (normalise, reflect
         # pad, bicubic pyramid) -> forward -> rounded uint8 frame (fldr_frame_metrics)
@@ -411,11 +470,11 @@ def main():
             try:
                 fldr_hip.CONV_PRECISION = "fp16"
                 for i in range(npairs):
-                    step(i)
+                    eager_step(i)                        # (eager: the captured graphs hold the split-precision forward)
                 sync()
                 t1 = time.perf_counter()
                 for i in range(a.fp16_mode_steps):
-                    step(i)
+                    eager_step(i)
                 sync()
                 d5 = time.perf_counter() - t1
                 fp16_mode = {"what": "3x3 convolutions on plain fp16 inputs (FLDR_CONV_PRECISION=fp16, BASELINE config 5): not fp32-equivalent, "
@@ -443,6 +502,8 @@ def main():
                        "pairs_in_flight": a.streams, "distinct_pairs_per_gpu": npairs,
                        "per_rank_pairs_per_s": [round(x, 2) for x in per_rank]},
         }
+        if gpu:
+            res["config"]["hip_graphs"] = dict(graph_state)
         if use_pg:
             res["config"]["process_group"] = {"backend": pg_backend + (" (RCCL)" if pg_backend == "nccl" else ""), "world_size": dist.get_world_size(),
                                               "forced_at_world_size_1": world == 1}
@@ -450,7 +511,7 @@ def main():
             res["dry"] = True
             res["data"] = "none (dry run: 1 ms sleep per step)"
         if gpu:
-            res["config"].update({"pyramid_bytes_per_pair": pyr_bytes, "single_stream_latency_ms": round(latency_ms, 3),
+            res["config"].update({"pyramid_bytes_per_pair": pyr_bytes, "single_stream_latency_ms": round(latency_ms, 3), "single_stream_latency_eager_ms": round(latency_eager_ms, 3),
                                   "ms_uint8_in_to_uint8_out_single_stream": round(dt_e2e * 1e3, 3)})
             if sustained:
                 res["sustained"] = sustained
