@@ -20,7 +20,10 @@ def eager(i):
         return Hn.interpolate(model, args, fr, t, pyramid=pyr)
 for i in range(12): ref = eager(i)
 torch.cuda.synchronize()
-refs = [eager(k).clone() for k in range(NP)]
+refs = []
+for k in range(NP):
+    with torch.cuda.stream(streams[k % NS]):
+        refs.append(eager(k).clone())            # (cloned on the stream that produced it)
 torch.cuda.synchronize()
 def loop(fn, n):
     for i in range(12): fn(i)
