@@ -104,86 +104,12 @@ void fldr_splat_bounds_launch(const float* flow, int64_t flow_bstride, float* bl
 // block's low-resolution footprint (all loads of a wave's four blocks are independent), wave shuffles reduce, LDS joins the
 // 64 block bounds into the super-block's.  (The first version ran one LANE per block over its footprint — 99 dependent
 // iterations for a x2 upsampling: 12-22 us per launch whatever the size, rocprofv3 round 3; this one is ~3 us.)
-#define ST_UP_WAVES 16
 __global__ __launch_bounds__(64 * ST_UP_WAVES) void splat_bounds_up_kernel(const float* __restrict__ lo, int64_t lo_bstride, const float* __restrict__ tv,
                                                              int smode, float mul, float* __restrict__ blk, float* __restrict__ sbt,
                                                              int h, int w, int H, int W, float sy, float sx, int nsb_x, int nsb,
                                                              int pair, int N) {
-#pragma clang fp contract(off)
     __shared__ float red[ST_UP_WAVES][4];
-    const int sb = blockIdx.x, lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    int n = blockIdx.y;
-    const int tab = n;                                                  // table sample
-    if (pair) {
-        const int k = n / N;
-        n -= k * N;
-        const bool second_half = (pair == 1) == (k == 0);             // channels 2-3 (flow_01)
-        lo += second_half ? 2 * (int64_t)h * w : 0;
-        smode = pair == 1 ? (k == 0 ? 1 : 2) : 0;
-    }
-    const float INF = __builtin_inff();
-    const float scale = smode == 0 ? 1.0f : (smode == 1 ? tv[n] : 1.0f - tv[n]);
-    const float* px = lo + (int64_t)n * lo_bstride;
-    const float* py = px + (int64_t)h * w;
-    float sxmin = INF, sxmax = -INF, symin = INF, symax = -INF;
-    // Footprint of a block: at most ST_BH + 1 rows and ST_BW + 2 columns when upsampling (H >= h, W >= w: host-checked).  The
-    // loads of ALL FOUR blocks of the wave go out first, from clamped indices instead of loop bounds (a repeated pixel does not
-    // change a minimum; blocks outside the image read block 0's footprint and are discarded): with data-dependent loop bounds, or
-    // with the blocks one after the other, every round waited for its own loads.  (A workgroup still needs ~10 us whatever
-    // its footprint — sixteen waves, four shuffle reductions each, one barrier — see the lane-per-block kernel below.)
-    constexpr int NBW = ST_SB_BLOCKS / ST_UP_WAVES, NV = (ST_BH + 1) * 2;
-    float vx[NBW][NV], vy[NBW][NV];
-    bool live[NBW];
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const int b = wv + j * ST_UP_WAVES;                             // block of the super-block (wave-uniform)
-        int X0 = ((sb % nsb_x) * ST_SBX + b % ST_SBX) * ST_BW, Y0 = ((sb / nsb_x) * ST_SBY + b / ST_SBX) * ST_BH;
-        live[j] = X0 < W && Y0 < H;
-        if (!live[j]) { X0 = 0; Y0 = 0; }
-        int c0, c1, r0, r1, d0, d1; float l;
-        fldr_lin_src(X0, sx, w, c0, d0, l); fldr_lin_src(min(X0 + ST_BW - 1, W - 1), sx, w, d1, c1, l);
-        fldr_lin_src(Y0, sy, h, r0, d0, l); fldr_lin_src(min(Y0 + ST_BH - 1, H - 1), sy, h, d1, r1, l);
-#pragma unroll
-        for (int k = 0; k < ST_BH + 1; ++k) {
-            const int r = min(r0 + k, r1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int c = min(c0 + lane + 64 * i, c1);
-                vx[j][k * 2 + i] = px[(int64_t)r * w + c]; vy[j][k * 2 + i] = py[(int64_t)r * w + c];
-            }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NBW; ++j) {
-        const int b = wv + j * ST_UP_WAVES;
-        float xmin = INF, xmax = -INF, ymin = INF, ymax = -INF;
-        if (live[j]) {                                                  // wave-uniform
-#pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const float ax = (scale * vx[j][k]) * mul, ay = (scale * vy[j][k]) * mul;
-                xmin = fminf(xmin, ax); xmax = fmaxf(xmax, ax); ymin = fminf(ymin, ay); ymax = fmaxf(ymax, ay);
-            }
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                xmin = fminf(xmin, __shfl_xor(xmin, o)); xmax = fmaxf(xmax, __shfl_xor(xmax, o));
-                ymin = fminf(ymin, __shfl_xor(ymin, o)); ymax = fmaxf(ymax, __shfl_xor(ymax, o));
-            }
-            const float ex = fmaxf(fabsf(xmin), fabsf(xmax)) * 2.0e-6f, ey = fmaxf(fabsf(ymin), fabsf(ymax)) * 2.0e-6f;
-            xmin -= ex; xmax += ex; ymin -= ey; ymax += ey;
-        }
-        if (lane == 0) *reinterpret_cast<float4*>(blk + (((int64_t)tab * nsb + sb) * ST_SB_BLOCKS + b) * 4) = make_float4(xmin, xmax, ymin, ymax);
-        sxmin = fminf(sxmin, xmin); sxmax = fmaxf(sxmax, xmax); symin = fminf(symin, ymin); symax = fmaxf(symax, ymax);
-    }
-    if (lane == 0) { red[wv][0] = sxmin; red[wv][1] = sxmax; red[wv][2] = symin; red[wv][3] = symax; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 1; k < ST_UP_WAVES; ++k) {
-            sxmin = fminf(sxmin, red[k][0]); sxmax = fmaxf(sxmax, red[k][1]); symin = fminf(symin, red[k][2]); symax = fmaxf(symax, red[k][3]);
-        }
-        *reinterpret_cast<float4*>(sbt + ((int64_t)tab * nsb + sb) * 4) = make_float4(sxmin, sxmax, symin, symax);
-    }
+    splat_bounds_up_body(lo, lo_bstride, tv, smode, mul, blk, sbt, h, w, H, W, sy, sx, nsb_x, nsb, pair, N, blockIdx.x, blockIdx.y, red);
 }
 
 // The same table with ONE LANE per block and one wave per super-block (no LDS, no barrier): the better shape when the

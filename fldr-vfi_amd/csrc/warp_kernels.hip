@@ -4,6 +4,7 @@
 // 64 consecutive x of one row, so loads are 256-B coalesced and the float atomics of the splat go out as
 // (near-)contiguous 256-B wave-instructions, the shape the gfx950 memory-side atomic units run at full rate.
 #include "common.h"
+#include "splat_common.h"
 
 // ------------------------------------------------------------------------------------------------
 // softmax splatting (softSplat.py)
@@ -454,15 +455,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
 
 // The same resize for a tensor of C <= 8 channels that also emits its split-packed twin (one group): the upsampled flow of
 // fLDRnet.py:384-385 is consumed as fp32 (splats, residual) AND as the third packed source of conv_flow2.0.
-__global__ __launch_bounds__(256) void resize_bilinear_spk_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                                  unsigned char* __restrict__ spk, int C, int h, int w,
-                                                                  int H, int W, float sy, float sx, float mul) {
+__device__ __forceinline__ void resize_spk_pixel(const float* __restrict__ in, float* __restrict__ out, unsigned char* __restrict__ spk,
+                                                 int C, int h, int w, int H, int W, float sy, float sx, float mul, int n, int X, int Y) {
 #pragma clang fp contract(off)
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    const int n = blockIdx.z;
-    if (X >= W || Y >= H) return;
     int x0, x1, y0, y1; float lx, ly;
     fldr_lin_src(X, sx, w, x0, x1, lx);
     fldr_lin_src(Y, sy, h, y0, y1, ly);
@@ -490,12 +486,65 @@ __global__ __launch_bounds__(256) void resize_bilinear_spk_kernel(const float* _
     *reinterpret_cast<h8*>(d + HW * 16) = lo;
 }
 
+__global__ __launch_bounds__(256) void resize_bilinear_spk_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                  unsigned char* __restrict__ spk, int C, int h, int w,
+                                                                  int H, int W, float sy, float sx, float mul) {
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int Y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (X >= W || Y >= H) return;
+    resize_spk_pixel(in, out, spk, C, h, w, H, W, sy, sx, mul, blockIdx.z, X, Y);
+}
+
+// The upsampled [N,4,H,W] flow of a pyramid level (fp32 + packed twin, as above) AND the two flow-bounds tables of the feature splats
+// that consume it (fldr_splat_bounds_upsampled_pair, pair 2), in ONE launch: both read only the low-resolution flow, and the bounds
+// pass was a 10 us launch of 2 N nsb workgroups between the resize and the splat on every level.  The first n_bounds workgroups run
+// the bounds body (splat_common.h), the others resize a 64 x 16 pixel tile each with the pixel function of the kernel above —
+// the same instructions on the same operands as the two separate launches, so both outputs are bit-identical to them.
+__global__ __launch_bounds__(64 * ST_UP_WAVES) void resize_spk_bounds_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                             unsigned char* __restrict__ spk, float* __restrict__ blk,
+                                                                             float* __restrict__ sbt, int N, int h, int w, int H, int W,
+                                                                             float sy, float sx, float mul, int nsb_x, int nsb,
+                                                                             int n_bounds, int tiles_x, int tiles_y) {
+    __shared__ float red[ST_UP_WAVES][4];
+    int b = blockIdx.x;
+    if (b < n_bounds) {                                                 // workgroup-uniform
+        splat_bounds_up_body(in, 4 * (int64_t)h * w, nullptr, 0, mul, blk, sbt, h, w, H, W, sy, sx, nsb_x, nsb, 2, N, b % nsb, b / nsb, red);
+        return;
+    }
+    b -= n_bounds;
+    const int tx = b % tiles_x, ty = (b / tiles_x) % tiles_y, n = b / (tiles_x * tiles_y);
+    const int X = tx * 64 + (threadIdx.x & 63);
+    const int Y = ty * ST_UP_WAVES + (threadIdx.x >> 6);
+    if (X >= W || Y >= H) return;
+    resize_spk_pixel(in, out, spk, 4, h, w, H, W, sy, sx, mul, n, X, Y);
+}
+
 extern "C" int fldr_resize_bilinear_spk(const float* in, float* out, void* out_spk, int N, int C, int h, int w, int H, int W,
                                         float mul, fldr_stream_t stream) {
     FLDR_CHECK_ARG(in && out && out_spk && N > 0 && C > 0 && C <= 8 && h > 0 && w > 0 && H > 0 && W > 0);
     dim3 grid(fldr_cdiv(W, 64), fldr_cdiv(H, 4), N);
     hipLaunchKernelGGL(resize_bilinear_spk_kernel, grid, dim3(256), 0, fldr_s(stream), in, out, reinterpret_cast<unsigned char*>(out_spk),
                        C, h, w, H, W, (float)h / (float)H, (float)w / (float)W, mul);
+    FLDR_LAUNCH_RET();
+}
+
+// fldr_resize_bilinear_spk (C = 4) + fldr_splat_bounds_upsampled_pair (pair 2) of the same low-resolution flow in one launch.
+// ws: 2 * fldr_softsplat_tile_ws_floats(N, H, W) floats, laid out as fldr_splat_bounds_upsampled_pair leaves them.  W < 4 w (the
+// workgroup-per-super-block bounds body; the model upsamples by 2), else FLDR_E_SHAPE: call the two entry points instead.
+extern "C" int fldr_resize_bilinear_spk_bounds(const float* in, float* out, void* out_spk, float* ws, int N, int h, int w, int H, int W,
+                                               float mul, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(in && out && out_spk && ws && N > 0 && h > 0 && w > 0 && H >= h && W >= w && mul > 0.0f);
+    if ((int64_t)W >= 4 * (int64_t)w) return FLDR_E_SHAPE;
+    if (W > 65535 * ST_BW || H > 32767 * ST_BH) return FLDR_E_SHAPE;
+    const int nsb_x = fldr_cdiv(W, ST_SBX * ST_BW), nsb = nsb_x * fldr_cdiv(H, ST_SBY * ST_BH);
+    const int tiles_x = fldr_cdiv(W, 64), tiles_y = fldr_cdiv(H, ST_UP_WAVES);
+    const int64_t n_bounds = (int64_t)2 * N * nsb, blocks = n_bounds + (int64_t)N * tiles_x * tiles_y;
+    if (blocks > 0x7fffffff) return FLDR_E_SHAPE;
+    float* blk = ws;
+    float* sbt = ws + (int64_t)2 * N * nsb * ST_SB_BLOCKS * 4;
+    hipLaunchKernelGGL(resize_spk_bounds_kernel, dim3((unsigned)blocks), dim3(64 * ST_UP_WAVES), 0, fldr_s(stream), in, out,
+                       reinterpret_cast<unsigned char*>(out_spk), blk, sbt, N, h, w, H, W, (float)h / (float)H, (float)w / (float)W, mul,
+                       nsb_x, nsb, (int)n_bounds, tiles_x, tiles_y);
     FLDR_LAUNCH_RET();
 }
 

@@ -250,8 +250,10 @@ class DCTVFInet(nn.Module):
         if flow_l_prev is None:
             flow_l = self._chain([feat_p if spk else feat_x], self.conv_flow_bottom, (0, 2, 4, 6, 8), final_store=4)   # :379-380
         else:
-            up_p = None
-            if spk:       # the upsampled flow is consumed as fp32 (splats, residual) and packed (conv_flow2.0): one kernel writes both
+            up_p = bw = None
+            if spk and fldr_hip.SPLAT_FEATURES == "acc64" and H * W > 2304:     # ... and the bounds tables of the two feature splats below come out of the same launch
+                up, up_p, bw = fldr_hip.resize_bilinear_spk_bounds(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])   # :384-385
+            elif spk:     # the upsampled flow is consumed as fp32 (splats, residual) and packed (conv_flow2.0): one kernel writes both
                 up, up_p = fldr_hip.resize_bilinear_spk(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])   # :384-385
             else:
                 up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])         # :384-385
@@ -262,7 +264,6 @@ class DCTVFInet(nn.Module):
             elif spk and B == 1 and half % 8 == 0 and fldr_hip.SPLAT_FEATURES == "acc64":
                 # both directions in one launch of the fp64-LDS-atomic tile splat: no accumulator, memset or normalisation pass
                 # (maps of <= 2304 pixels need no table: every tile walks the whole map)
-                bw = fldr_hip.splat_bounds_upsampled_pair(flow_l_prev, None, "features", W / flow_l_prev.shape[3], H, W) if H * W > 2304 else None
                 wpair = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False,
                                                  want_spk=True, spk_batch=True, bounds_ws=bw)          # :386-387
                 w1, w0 = wpair.sample(0), wpair.sample(1)
@@ -271,7 +272,6 @@ class DCTVFInet(nn.Module):
                 w1, w0 = wpair.sample(0), wpair.sample(1)
             elif spk and fldr_hip.SPLAT_FEATURES == "acc64":
                 wpair = None
-                bw = fldr_hip.splat_bounds_upsampled_pair(flow_l_prev, None, "features", W / flow_l_prev.shape[3], H, W) if H * W > 2304 else None
                 w1, w0 = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True,
                                                    bounds_ws=bw)
             elif spk:

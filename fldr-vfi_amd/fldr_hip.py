@@ -99,6 +99,7 @@ _SIGNATURES = {
     "fldr_softsplat_fused_spk": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_softsplat_pair_spk": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_resize_bilinear_spk": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_float, ctypes.c_void_p]),
+    "fldr_resize_bilinear_spk_bounds": (ctypes.c_int, [_c_float_p] * 2 + [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_float, ctypes.c_void_p]),
     "fldr_softsplat_gather_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 4),
     "fldr_softsplat_gather": (ctypes.c_int, [ctypes.POINTER(SplatGatherDesc), ctypes.c_void_p]),
     "fldr_softsplat_tile_ws_floats": (ctypes.c_int64, [ctypes.c_int] * 3),
@@ -758,6 +759,28 @@ def resize_bilinear_spk(x, H, W, mul=1.0):
     _check(lib().fldr_resize_bilinear_spk(_dev(x, "in"), _dev(out, "out"), ctypes.c_void_p(sp.ptr), N, C, h, w, H, W, float(mul), _stream()),
            "fldr_resize_bilinear_spk")
     return out, sp
+
+
+# The upsampled level flow and the bounds tables of the feature splats that consume it in ONE launch (fldr_resize_bilinear_spk_bounds);
+# 0: the two launches.  Bit-identical either way.
+RESIZE_BOUNDS = os.environ.get("FLDR_RESIZE_BOUNDS", "1") != "0"
+
+
+def resize_bilinear_spk_bounds(x, H, W, mul=1.0):
+    """resize_bilinear_spk(x, H, W, mul) + splat_bounds_upsampled_pair(x, None, "features", mul, H, W) of a [N,4,h,w] level flow
+    in one launch: -> (fp32 [N,4,H,W], Spk, bounds workspace).  Falls back to the two launches when W >= 4 w or FLDR_RESIZE_BOUNDS=0."""
+    N, C, h, w = x.shape
+    assert C == 4
+    x = x.contiguous()
+    if not RESIZE_BOUNDS or W >= 4 * w:
+        out, sp = resize_bilinear_spk(x, H, W, mul)
+        return out, sp, splat_bounds_upsampled_pair(x, None, "features", mul, H, W)
+    out = torch.empty(N, C, H, W, device=x.device, dtype=torch.float32)
+    sp = _spk_alloc(N, C, H, W, x.device)
+    ws = torch.empty(2 * lib().fldr_softsplat_tile_ws_floats(N, H, W), device=x.device, dtype=torch.float32)
+    _check(lib().fldr_resize_bilinear_spk_bounds(_dev(x, "in"), _dev(out, "out"), ctypes.c_void_p(sp.ptr), _dev(ws, "ws"), N, h, w, H, W,
+                                                 float(mul), _stream()), "fldr_resize_bilinear_spk_bounds")
+    return out, sp, ws
 
 
 def level0_prep(flow_lo, I0, I1, t, H, W, za0, za1, withmask=True, want_z=True, phase=3, state=None):

@@ -222,6 +222,11 @@ int fldr_resize_bilinear_spk(const float* in, float* out, void* out_spk, int N, 
                              fldr_stream_t stream);
 int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int H, int W, float mul,
                          fldr_stream_t stream);
+/* fldr_resize_bilinear_spk of a [N,4,h,w] level flow AND fldr_splat_bounds_upsampled_pair(pair 2) of the same flow in one launch
+ * (fLDRnet.py:384-387: the upsampled flow and the tables of the two feature splats that follow); both results bit-identical to the
+ * two calls.  ws: 2 * fldr_softsplat_tile_ws_floats(N, H, W) floats.  Needs W < 4 w (FLDR_E_SHAPE otherwise: use the two calls). */
+int fldr_resize_bilinear_spk_bounds(const float* in, float* out, void* out_spk, float* ws, int N, int h, int w, int H, int W, float mul,
+                                    fldr_stream_t stream);
 
 /* Splat metric of fLDRnet.py:442-446: z[n,0,y,x] = mean_c( alpha * |self[n,c,y,x] - bwarp(other, flow)[n,c,y,x]| ).
  * self/other: [N,C,H,W]; flow [N,2,H,W]; z [N,1,H,W]. */

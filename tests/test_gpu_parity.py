@@ -712,6 +712,29 @@ def test_acc64_softsplat_frames_in_place_and_low_res_bounds(hip, oracle, dev):
     _cmp(a[0], oracle.function_softsplat(feat[:, C:].cpu(), upf[:, :2].cpu(), None, "softmax"), atol=3e-5, what="feature pair, low-res bounds")
 
 
+@pytest.mark.parametrize("shape", [(1, 23, 37, 46, 74), (2, 40, 68, 80, 136), (1, 135, 256, 270, 512), (1, 30, 50, 75, 149)])
+def test_fused_resize_and_feature_bounds_bit_identical(hip, dev, shape):
+    """fldr_resize_bilinear_spk_bounds (the level flow's upsampling and the tables of the two feature splats in one launch) against the
+    two separate launches: fp32 flow, packed twin and both tables bit for bit; ragged sizes and a non-integer ratio included."""
+    N, h, w, H, W = shape
+    g = _gen(97)
+    prev = (torch.randn(N, 4, h, w, generator=g) * 3).to(dev)
+    mul = W / w
+    up0, sp0 = hip.resize_bilinear_spk(prev, H, W, mul=mul)
+    bw0 = hip.splat_bounds_upsampled_pair(prev, None, "features", mul, H, W)
+    assert hip.RESIZE_BOUNDS
+    up1, sp1, bw1 = hip.resize_bilinear_spk_bounds(prev, H, W, mul=mul)
+    assert torch.equal(up0, up1)
+    assert torch.equal(sp0.buf.view(torch.int16), sp1.buf.view(torch.int16))
+    assert torch.equal(bw0.view(torch.int32), bw1.view(torch.int32))
+    with pytest.raises(hip.FldrError):                                  # x4 and beyond: the two entry points
+        ws = torch.empty(2 * hip.lib().fldr_softsplat_tile_ws_floats(N, 4 * h, 4 * w), device=dev)
+        o = torch.empty(N, 4, 4 * h, 4 * w, device=dev)
+        sp = hip._spk_alloc(N, 4, 4 * h, 4 * w, dev)
+        hip._check(hip.lib().fldr_resize_bilinear_spk_bounds(prev.data_ptr(), o.data_ptr(), sp.ptr, ws.data_ptr(), N, h, w, 4 * h, 4 * w, 4.0, None),
+                   "fldr_resize_bilinear_spk_bounds")
+
+
 def test_tile_softsplat_extreme_and_smooth_flows(hip, oracle, dev, hooks):
     """Band splat corner cases: a smooth flow field (trimmed candidate walk) with 1 % of the vectors thrown out to
     +-3e9 px (bounds far beyond int range: the block walk takes over where they occur) and a pure sub-pixel shift."""
