@@ -27,6 +27,20 @@
 #define RING_SLOTS 3                            // stages of the LDS ring (2: 105 KB for the 48-channel kernel, 55 KB of the CU left to other kernels)
 #endif
 #define RING_NLOAD 4
+// Resident-weight variant (test build; template flag RW; 16-output-channel launches of <= RING_RW_MAX_CHUNKS input chunks: dec2 48 -> 16,
+// conv_flow2.8 / conv_flow_bottom.8): the whole weight pack of the workgroup's output group is copied into LDS once (10 KB per chunk),
+// a ring stage is the four input planes only (22 KB instead of 32 KB) and the ring has RING_RW_SLOTS stages with two fills in flight
+// per loader wave instead of one (MI355X_MICROARCH.md, ring-gemm: "at least three slots more than the K-steps a loader keeps in flight").
+#define RING_RW_MAX_CHUNKS 4
+#ifndef RING_RW_SLOTS
+#define RING_RW_SLOTS 5
+#endif
+#ifndef RING_RW_INFLIGHT
+#define RING_RW_INFLIGHT 2
+#endif
+#ifndef RING_PD_THIN
+#define RING_PD_THIN 1                          // operand read-ahead (steps) of the 16-output-channel kernels (2: measured equal, +20-40 registers)
+#endif
 #define RING_SPIN_LIMIT (1 << 21)
 #ifndef RING_LOADER_PRIO
 #define RING_LOADER_PRIO 0                      // wave priority of the loaders (0 / 1 / 3 measured equal within noise)
@@ -69,7 +83,7 @@ int fldr_ring_timeouts_read(int reset) {
 
 // TW: tile width in pixels (32, or 16 for launches whose 8 x 32 tiles fill the last round of persistent workgroups badly:
 // see ring_pick_tile_width).  The LDS input plane is (8 + 2) x (TW + 2) pixels of 16 bytes, padded to a multiple of 256 bytes.
-template <int NMT, int TW = SPK_TW>
+template <int NMT, int TW = SPK_TW, bool RW = false>
 struct RingCfg {
     static constexpr int W_BYTES = SPK_STEPS * NMT * 2 * 1024;
     static constexpr int NBLK = SPK_STEPS * NMT * 2;                    // 1-KB weight blocks per chunk: (step, m, kind)
@@ -78,11 +92,16 @@ struct RingCfg {
     static constexpr int CB = TW / 16;                                  // 16-pixel column blocks per tile row
     static constexpr int PLANE = (SPK_IH * IW * 16 + 255) / 256 * 256;  // bytes per LDS plane (TW = 32: 5632 = SPK_PLANE)
     static constexpr int NXI = (SPK_IH * IW + 63) / 64;                 // 64-pixel DMA pieces per input plane (the last ones overlap)
-    static constexpr int K_DMA = NWL + NXI;                             // DMA instructions per loader wave and fill
-    static constexpr int STAGE = W_BYTES + 4 * PLANE;
-    static constexpr int CTR_OFF = RING_SLOTS * STAGE;                  // FULL[3] at +0, FREE[3] at +16, PROGRESS[8] (consumer iteration counters) at +32
+    static constexpr int K_DMA = (RW ? 0 : NWL) + NXI;                  // DMA instructions per loader wave and fill
+    static constexpr int IN_OFF = RW ? 0 : W_BYTES;                     // the four input planes inside a stage
+    static constexpr int STAGE = IN_OFF + 4 * PLANE;
+    static constexpr int SLOTS = RW ? RING_RW_SLOTS : RING_SLOTS;
+    static constexpr int INFLIGHT = RW ? RING_RW_INFLIGHT : 1;          // fills a loader wave has in flight behind the one it is issuing
+    static constexpr int WRES_OFF = SLOTS * STAGE;                      // RW: the weight slabs of all chunks
+    static constexpr int CTR_OFF = WRES_OFF + (RW ? RING_RW_MAX_CHUNKS * W_BYTES : 0);   // FULL[8] at +0, FREE[8] at +32
     static constexpr int BIAS_OFF = CTR_OFF + 64;                       // bias of the workgroup's 16 * NMT output channels (fp32)
     static constexpr int LDS_BYTES = BIAS_OFF + 64 * NMT;
+    static_assert(SLOTS <= 8 && INFLIGHT + 2 <= SLOTS && INFLIGHT * K_DMA <= 15, "ring shape");
     static_assert(TW == 16 || TW == 32, "tile width");
     static_assert(TW != SPK_TW || PLANE == SPK_PLANE, "the 32-pixel plane is the barrier pipeline's");
     static_assert(PLANE / 16 >= 64 && NXI * 64 >= SPK_IH * IW, "DMA pieces cover the plane");
@@ -121,10 +140,11 @@ __device__ __forceinline__ void ring_signal(uint32_t lds_addr, int lane) {
 // ML: multi-level launch (SpkArgs::lv: units of several images of different sizes, one source tensor each; rec_ctx_ds over the
 // pyramid levels).  A template parameter, not a kernel argument: the single-level kernels keep exactly their registers (with
 // the level geometry as run-time state they needed a scratch reservation, and that costs ~2 us per launch).
-template <int NMT, int TERMS, bool HAS_RES, int NC, int TW, bool ML = false>
+template <int NMT, int TERMS, bool HAS_RES, int NC, int TW, bool ML = false, bool RW = false>
 __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(SpkArgs a) {
     // NC consumer waves (4: two tile rows each, one consumer per SIMD; 8: one row each, two per SIMD)
-    using Cfg = RingCfg<NMT, TW>;
+    using Cfg = RingCfg<NMT, TW, RW>;
+    constexpr int SLOTS = Cfg::SLOTS;
     constexpr int CB = Cfg::CB;
     constexpr int RING_NCONS = NC;
     constexpr int MTOT = 16 * NMT;
@@ -132,7 +152,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_chunks = a.n_chunks;
-    const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);   // LDS byte address of FULL[0]; FREE[s] at +16 + 4 s
+    const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);   // LDS byte address of FULL[0]; FREE[s] at +32 + 4 s
 
     if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
     if (tid >= 64 && tid < 64 + 16 * NMT) {                               // (unit -> output group as below: constant over the workgroup)
@@ -141,12 +161,25 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         co = co < a.cout ? co : a.cout - 1;
         reinterpret_cast<float*>(smem + Cfg::BIAS_OFF)[tid - 64] = a.bias ? a.bias[co] : 0.0f;
     }
-    __syncthreads();                                                      // the only workgroup barrier of the kernel
-
     // Units of this workgroup: as in conv_spk_kernels.hip (XCD x owns the contiguous range [x*upx, (x+1)*upx)).
     const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
     const int u_end = min((xcd + 1) * a.units_per_xcd, a.n_units);
     const int u_first = xcd * a.units_per_xcd + slot_id;
+    if constexpr (RW) {
+        // the weight slabs of every chunk of this workgroup's output group, once: 1-KB blocks (chunk, step, m, kind) dealt to all waves
+        const int g0 = (u_first < a.n_units ? u_first : 0) % a.groups;
+        const int sub = a.pack_nmt / NMT, pgrp = g0 / sub, msel = (g0 - pgrp * sub) * NMT;
+        const int pack_w_bytes = SPK_STEPS * a.pack_nmt * 2 * 1024;
+        const char* wsrc = reinterpret_cast<const char*>(a.wpack + SPK_HDR) + (int64_t)pgrp * n_chunks * pack_w_bytes;
+        for (int b = wave; b < n_chunks * Cfg::NBLK; b += NC + RING_NLOAD) {
+            const int c = b / Cfg::NBLK, blk = b - c * Cfg::NBLK;
+            const int step = blk / (2 * NMT), mk = blk - step * 2 * NMT;
+            __builtin_amdgcn_global_load_lds((kgptr_t)(wsrc + (int64_t)c * pack_w_bytes + ((step * a.pack_nmt + msel) * 2 + mk) * 1024 + lane * 16),
+                                             (klptr_t)(smem + Cfg::WRES_OFF + c * Cfg::W_BYTES + blk * 1024), 16, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): my blocks have landed
+    }
+    __syncthreads();                                                      // the only workgroup barrier of the kernel
     if (u_first >= u_end) return;                                        // workgroup-uniform
     const int my_units = (u_end - u_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
     const int total = my_units * n_chunks;
@@ -245,22 +278,24 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
             if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
             RSTAMP(l1)
-            if (free_target) ring_wait_ge(ctr + 16 + 4 * st, free_target, lane);
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane);
             RSTAMP(l2)
             unsigned char* stage = smem + st * Cfg::STAGE;
 #if defined(RING_ABLATE) && RING_ABLATE == 3                          // diagnostic: no DMA traffic after the prologue fills
-            if (k >= RING_SLOTS) { wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR); for (int i = 0; i < Cfg::NXI; ++i) dptr[i] = zero_blk; }
+            if (k >= SLOTS) { wbase = reinterpret_cast<const char*>(a.wpack + SPK_HDR); for (int i = 0; i < Cfg::NXI; ++i) dptr[i] = zero_blk; }
 #endif
+            if constexpr (!RW) {
 #pragma unroll
-            for (int i = 0; i < Cfg::NWL; ++i)
-                __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_voff[i]), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
+                for (int i = 0; i < Cfg::NWL; ++i)
+                    __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_voff[i]), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < Cfg::NXI; ++i)
-                __builtin_amdgcn_global_load_lds((kgptr_t)dptr[i], (klptr_t)(stage + Cfg::W_BYTES + ip * Cfg::PLANE + x_piece[i] * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((kgptr_t)dptr[i], (klptr_t)(stage + Cfg::IN_OFF + ip * Cfg::PLANE + x_piece[i] * 16), 16, 0, 0);
             RSTAMP(l3)
-            if (k > 0) {                                                  // fill k-1 has landed once at most K_DMA of my loads are outstanding
-                __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_DMA);
-                ring_signal(ctr + 4 * (st == 0 ? RING_SLOTS - 1 : st - 1), lane);
+            if (k >= Cfg::INFLIGHT) {                                     // fill k-INFLIGHT has landed once at most INFLIGHT * K_DMA of my loads are outstanding
+                __builtin_amdgcn_s_waitcnt(0x0F70 | (Cfg::INFLIGHT * Cfg::K_DMA));
+                ring_signal(ctr + 4 * ((st + SLOTS - Cfg::INFLIGHT) % SLOTS), lane);
             }
             RSTAMP(l4)
 #ifdef RING_STAMPS
@@ -270,10 +305,19 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 tr[0] = l1; tr[1] = l2; tr[2] = l3; tr[3] = l4;
             }
 #endif
-            if (++st == RING_SLOTS) { st = 0; free_target += RING_NCONS; }
+            if (++st == SLOTS) { st = 0; free_target += RING_NCONS; }
+        }
+        // the last INFLIGHT fills (st = slot after the last fill), oldest first
+        if constexpr (Cfg::INFLIGHT == 2) {
+            if (total >= 2) {
+                __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_DMA);
+                ring_signal(ctr + 4 * ((st + SLOTS - 2) % SLOTS), lane);
+            }
+        } else {
+            static_assert(Cfg::INFLIGHT == 1, "drain sequence");
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0)
-        ring_signal(ctr + 4 * (st == 0 ? RING_SLOTS - 1 : st - 1), lane);
+        ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
 #ifdef RING_STAMPS
         RSTAMP(l_end)
         if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == RING_NCONS && lane == 0) {
@@ -292,7 +336,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     int boff[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q)
-        boff[q] = Cfg::W_BYTES + (lg & 1) * Cfg::PLANE + ((ROWS * cw + q / CB) * Cfg::IW + (q % CB) * 16 + lj) * 16;
+        boff[q] = Cfg::IN_OFF + (lg & 1) * Cfg::PLANE + ((ROWS * cw + q / CB) * Cfg::IW + (q % CB) * 16 + lj) * 16;
     const int tap_sel = lg >> 1;
     f4 acc[NMT][NQ];
 #pragma unroll
@@ -387,7 +431,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
     bool range_bad = false;
     const bool grp_full = cbase + MTOT <= a.cout_store && !(a.cout_store & 7);      // wave-uniform, constant over the kernel
+#ifdef RING_STAMPS
+    unsigned long long cs_f_dec = 0, cs_f_fast = 0, cs_f_b0 = 0, fq0 = 0;
+#endif
     auto finish_store = [&]() {
+        RSTAMP(f0)
         // (opaque copies of the lane coordinates: without them the compiler hoists this path's per-block offsets and
         // predicates out of the iteration loop and keeps ~20 VGPRs live across the MFMA steps, or spills them)
         int lj = lane & 15, lg = lane >> 4;
@@ -398,11 +446,15 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) + u_f32_off : nullptr;
         char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride + u_spk_off : nullptr;
         const bool inside = oy0 + ROWS <= uH && ox0 + TW <= uW;      // wave-uniform
+        RSTAMP(f1)
         if (grp_full && inside) {
             const uint32_t p0 = (uint32_t)(oy0 * uW + ox0 + lj);
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 const uint32_t pq = p0 + (uint32_t)((q / CB) * uW + (q % CB) * 16);
+#ifdef RING_STAMPS
+                if (q == 1) { RSTAMP(fq) fq0 = fq; }
+#endif
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) {
                     const int co0 = cbase + m * 16 + lg * 4;
@@ -435,6 +487,9 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     }
                 }
             }
+#ifdef RING_STAMPS
+            { RSTAMP(f2) cs_f_dec += f1 - f0; cs_f_fast += f2 - f1; cs_f_b0 += fq0 - f1; }
+#endif
             return;
         }
         uint32_t po[NQ];
@@ -496,10 +551,16 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     // the MFMA steps of one iteration on slot st_cur
     auto steps = [&]() __attribute__((always_inline)) {
         const unsigned char* sb = smem + st_cur * Cfg::STAGE;
-        const unsigned char* win = sb + lane * 16;
+        const unsigned char* win = (RW ? smem + Cfg::WRES_OFF + cur_c * Cfg::W_BYTES : sb) + lane * 16;
         // Operand registers.  The lo weights are single-buffered (they feed only the last third of a step's MFMAs and are
         // fetched at its start).
-        h8 bh[2][NQ], bl[2][NQ], ah[2][NMT], al[NMT];
+        // PD: how many steps ahead the operand reads run (RING_PD_THIN for the 16-output-channel kernels, whose 3 NQ matrix instructions per
+        // step do not cover an LDS round trip).  Reading two steps ahead, every operand triple-buffered, was built and measured EQUAL (48 -> 16
+        // at 1152x1920: 135.3 vs 134.6 us): those kernels are bound by the LDS array (one 1-KB pixel operand read feeds 1.5 matrix
+        // instructions: 8 waves x 6 reads per 192 matrix cycles = 250 of 256 B/clk) and by their epilogue, not by read latency.
+        constexpr int PD = (NMT == 1 && TERMS == 3) ? RING_PD_THIN : 1;
+        constexpr int NB = PD + 1;
+        h8 bh[NB][NQ], bl[NB][NQ], ah[NB][NMT], al[PD > 1 ? NB : 1][NMT];
         auto tap_off = [&](int s) {
             // taps of step s: 2s and 2s+1 (tap 9 = the zero-weight pad tap: re-reads tap 8's pixels, finite values)
             const int tA = 2 * s, tB = 2 * s + 1 < 9 ? 2 * s + 1 : 8;
@@ -522,10 +583,10 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 for (int q = 0; q < NQ; ++q) bl[buf][q] = *reinterpret_cast<const h8*>(sb + 2 * Cfg::PLANE + boff[q] + toff);
             }
         };
-        auto ld_al = [&](int s) {
+        auto ld_al = [&](int s, int buf = 0) {
             if constexpr (TERMS > 1) {
 #pragma unroll
-                for (int m = 0; m < NMT; ++m) al[m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+                for (int m = 0; m < NMT; ++m) al[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
             }
         };
         // issue order = consumption order of the term-major MFMA sequence (hi x hi, hi x lo, lo x hi)
@@ -538,6 +599,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
         ld(0, 0);
         ld_al(0);
+        if constexpr (PD > 1) { ld(1, 1); ld_al(1, 1); }
         __builtin_amdgcn_sched_barrier(0);                               // keep step 0's reads out of the interleave pattern below
 #pragma unroll
         for (int s = 0; s < SPK_STEPS; ++s) {
@@ -545,8 +607,12 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             if (s + 1 < SPK_STEPS) { for (int q = 0; q < NQ; ++q) { bh[(s + 1) & 1][q] = bh[s & 1][q]; bl[(s + 1) & 1][q] = bl[s & 1][q]; }
                                               for (int m = 0; m < NMT; ++m) { ah[(s + 1) & 1][m] = ah[s & 1][m]; } }
 #else
-            if (s > 0) ld_al(s);                                         // (after the previous step's last lo-weight MFMA in program order)
-            if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);                // lands while this step's MFMAs run
+            if constexpr (PD > 1) {
+                if (s + PD < SPK_STEPS) { ld((s + PD) % NB, s + PD); ld_al(s + PD, (s + PD) % NB); }   // lands while this and the next step's MFMAs run
+            } else {
+                if (s > 0) ld_al(s);                                     // (after the previous step's last lo-weight MFMA in program order)
+                if (s + 1 < SPK_STEPS) ld((s + 1) & 1, s + 1);            // lands while this step's MFMAs run
+            }
 #endif
 #pragma unroll
             for (int term = 0; term < TERMS; ++term) {
@@ -554,8 +620,8 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 for (int m = 0; m < NMT; ++m)
 #pragma unroll
                     for (int q = 0; q < NQ; ++q) {
-                        const h8 av = term == 2 ? al[m] : ah[s & 1][m];
-                        const h8 bv = term == 1 ? bl[s & 1][q] : bh[s & 1][q];
+                        const h8 av = term == 2 ? al[PD > 1 ? s % NB : 0][m] : ah[s % NB][m];
+                        const h8 bv = term == 1 ? bl[s % NB][q] : bh[s % NB][q];
 #if defined(RING_ABLATE) && RING_ABLATE == 2                          // diagnostic: no MFMAs
                         asm volatile("" :: "v"(av), "v"(bv));
 #else
@@ -564,7 +630,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     }
             }
             // spread the next step's LDS reads evenly between this step's MFMAs
-            spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < SPK_STEPS);
+            spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + PD < SPK_STEPS);
         }
     };
     // one iteration's hand-shake around `steps`: wait for the slot, run, release it, step to the next slot
@@ -577,7 +643,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         { RSTAMP(t) c0 = t; }
 #endif
 #if defined(RING_ABLATE) && RING_ABLATE == 5                          // diagnostic: consumers never look at FULL after the first fills (timing only: stale operands)
-        if (g < RING_SLOTS)
+        if (g < SLOTS)
 #endif
         ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
 #ifdef RING_STAMPS
@@ -585,7 +651,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
     };
     auto iter_end = [&]() __attribute__((always_inline)) {
-        ring_signal(ctr + 16 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
+        ring_signal(ctr + 32 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
 #ifdef RING_STAMPS
         { RSTAMP(t) c2 = t; }
 #endif
@@ -599,7 +665,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             tr[0] = c0; tr[1] = c1; tr[2] = c2; tr[3] = c3;
         }
 #endif
-        if (++st_cur == RING_SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
+        if (++st_cur == SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
         ++g;
     };
     while (g < total) {
@@ -631,7 +697,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     RSTAMP(c_end)
     if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == 0 && lane == 0) {
         unsigned long long* o = fldr_ring_stamp_buf + (blockIdx.x == 0 ? 0 : 2) * 8;
-        o[0] = cs_wait; o[1] = cs_steps; o[2] = cs_fin; o[5] = total; o[6] = c_end - c_begin;
+        o[0] = cs_wait; o[1] = cs_steps; o[2] = cs_fin; o[3] = cs_f_dec; o[4] = cs_f_fast; o[7] = cs_f_b0; o[5] = total; o[6] = c_end - c_begin;
     }
 #endif
 }
@@ -639,15 +705,27 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 static int g_ring_consumers = 8;
 FLDR_HOOK int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
 
-template <int NMT, int TERMS, bool HAS_RES, int NC, int TW>
+template <int NMT, int TERMS, bool HAS_RES, int NC, int TW, bool RW = false>
 static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
-    using Cfg = RingCfg<NMT, TW>;
+    using Cfg = RingCfg<NMT, TW, RW>;
     static std::atomic<uint64_t> attr_done{0};
-    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW>), Cfg::LDS_BYTES, attr_done)) return e;
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW, false, RW>), Cfg::LDS_BYTES, attr_done)) return e;
     if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, TW)) return e;
-    hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW>), dim3(8 * a.wgs_per_xcd), dim3((NC + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
+    hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW, false, RW>), dim3(8 * a.wgs_per_xcd), dim3((NC + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }
+
+// The resident-weight ring is bit-identical to the streamed-weight ring and measured EQUAL (48 -> 16 at 1152x1920: 134.1 vs 134.0 us with 8
+// consumer waves, 131.0 vs 134.2 with 4; 48 -> 4 at 288x480: 13.0 vs 12.4; bench 484.6 vs 487.3 pairs/s): these launches are bound by their
+// consumers (stamps at 1152x1920: the loader waits 1,300 of 2,200 cycles per fill for a FREE slot; a consumer spends 1,330 cycles per
+// iteration in its steps on an LDS array that the pixel-operand reads alone fill, and 2,300 per unit in the epilogue).  Test build only.
+#ifndef RING_RW_DEFAULT
+#define RING_RW_DEFAULT 0
+#endif
+#ifdef FLDR_TEST_HOOKS
+static int g_ring_resident = RING_RW_DEFAULT;
+FLDR_HOOK int fldr_debug_ring_resident(int v) { if (v == 0 || v == 1) g_ring_resident = v; return g_ring_resident; }
+#endif
 
 // Tile width of a launch.  Persistent workgroups (one per CU) walk the units in rounds; a launch whose 8 x 32 tiles leave the
 // last round nearly empty (the second pyramid level of a 4K pair: 288 units on 256 workgroups = two rounds for 1.13 rounds
@@ -671,6 +749,15 @@ static int ring_pick_tile_width(const SpkArgs& a, int N, int wgs_per_xcd_max) {
 
 template <int NMT, int TERMS, bool HAS_RES>
 static int ring_launch2(SpkArgs& a, int N, int wpx, hipStream_t s) {
+#ifdef FLDR_TEST_HOOKS
+    if constexpr (NMT == 1 && TERMS == 3) {
+        if (g_ring_resident && a.n_chunks <= RING_RW_MAX_CHUNKS && g_ring_tile_width != 16) {
+            const int64_t units = (int64_t)N * fldr_cdiv(a.W, SPK_TW) * fldr_cdiv(a.H, SPK_TH) * a.groups;
+            if (g_ring_consumers == 4 || (g_ring_tile_width == 0 && units >= 32ll * wpx)) return ring_launch3<NMT, TERMS, HAS_RES, 4, 32, true>(a, N, wpx, s);
+            return ring_launch3<NMT, TERMS, HAS_RES, 8, 32, true>(a, N, wpx, s);
+        }
+    }
+#endif
     if (g_ring_consumers == 4) return ring_launch3<NMT, TERMS, HAS_RES, 4, 32>(a, N, wpx, s);
     if constexpr (NMT == 1 && TERMS == 3) {
         // 16 output channels at a large resolution (dec2: 48 -> 16 at half the frame size): with one 16-channel block every MFMA

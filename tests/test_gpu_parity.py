@@ -314,7 +314,11 @@ def test_pca_pyramid_matrix_core_kernel(hip, oracle, dev, model, hooks):
                                    (1, [48, 48, 4], [0, 0, 0], 96, None, 36, 60, True, False), (1, [48], [0], 6, 4, 9, 15, False, False),
                                    (1, [64, 32], [1, 0], 32, None, 24, 40, True, False), (1, [32, 16], [1, 0], 16, None, 48, 80, True, False),
                                    (1, [96], [0], 96, None, 72, 120, True, True), (1, [96], [0], 96, None, 136, 240, True, False),
-                                   (2, [96], [0], 48, None, 136, 240, True, False), (1, [48, 48, 4], [0, 0, 0], 96, None, 136, 250, True, True)])
+                                   (2, [96], [0], 48, None, 136, 240, True, False), (1, [48, 48, 4], [0, 0, 0], 96, None, 136, 250, True, True),
+                                   # 16-output-channel launches of <= 4 input chunks: the resident-weight ring (5 slots, two fills in flight)
+                                   (1, [32, 16], [1, 0], 16, None, 272, 480, True, False), (1, [48], [0], 4, None, 136, 250, True, True),
+                                   (2, [64], [0], 16, None, 70, 100, False, False), (1, [16], [0], 16, None, 40, 64, True, False),
+                                   (1, [16], [0], 12, None, 8, 20, True, True)])
 def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape, hooks):
     """The persistent split-packed convolution (fldr_conv2d_spk) against the register-staged split convolution
     (fldr_conv2d_split): same hi/lo split, same MFMA order => bit-identical fp32 output; its packed output equals
@@ -331,17 +335,20 @@ def test_spk_conv_bit_identical_to_split_conv(hip, dev, shape, hooks):
     try:
         # every pipeline of fldr_conv2d_spk: barrier pipeline; loader/consumer ring with 4 consumer waves, with 8 (default) on
         # 8x32 and on 8x16 tiles, and with the tile width picked per launch (the default)
-        for variant, cons, tw in ((0, 8, 0), (1, 4, 0), (1, 8, 32), (1, 8, 16), (1, 8, 0)):
+        # (last column: the resident-weight ring of the test build where it applies — 16 output channels, <= 4 input chunks)
+        for variant, cons, tw, resident in ((0, 8, 0, 1), (1, 4, 0, 1), (1, 8, 32, 1), (1, 8, 16, 1), (1, 8, 0, 1), (1, 8, 0, 0), (1, 4, 0, 0)):
             L.fldr_debug_spk_variant(variant)
             L.fldr_debug_ring_consumers(cons)
             L.fldr_debug_ring_tile_width(tw)
+            L.fldr_debug_ring_resident(resident)
             got, gp = hip.conv2d_spk(srcs, wt, b, relu=relu, residual=rs, cout_store=cst, up2=up2, want_f32=True, want_spk=True)
-            assert torch.equal(ref, got), (variant, cons, tw)
-            assert torch.equal(hip.spk_pack(ref).buf, gp.buf), (variant, cons, tw)
+            assert torch.equal(ref, got), (variant, cons, tw, resident)
+            assert torch.equal(hip.spk_pack(ref).buf, gp.buf), (variant, cons, tw, resident)
     finally:
         L.fldr_debug_spk_variant(1)
         L.fldr_debug_ring_consumers(8)
         L.fldr_debug_ring_tile_width(0)
+        L.fldr_debug_ring_resident(0)
     assert L.fldr_debug_ring_timeouts() == 0
     if len(cs) == 1 and cst is None and cout % 8 == 0:
         w2 = (torch.randn(48, cout, 3, 3, generator=g) / 20).to(dev)

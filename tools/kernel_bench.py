@@ -35,7 +35,14 @@ def conv():
         for var in (0, 1, 2):
             L.fldr_debug_spk_variant(min(var, 1)); L.fldr_debug_ring_consumers(8 if var == 1 else 4)
             t.append(timeit(lambda i: hip.conv2d_spk([xp], w2, None, relu=True, want_f32=False, want_spk=True), 40))
-        print("%3d->%2d @%4dx%4d: barrier %.1f us, ring8 %.1f us, ring4 %.1f us" % (cin, cout, h, w, t[0], t[1], t[2]), flush=True)
+        extra = ""
+        if cout <= 16 and cin <= 64:                         # the resident-weight ring applies (test build, off by default): beside the default
+            L.fldr_debug_ring_resident(1)
+            for cons in (8, 4):
+                L.fldr_debug_ring_consumers(cons)
+                extra += ", resident weights ring%d %.1f us" % (cons, timeit(lambda i: hip.conv2d_spk([xp], w2, None, relu=True, want_f32=False, want_spk=True), 40))
+            L.fldr_debug_ring_resident(0)
+        print("%3d->%2d @%4dx%4d: barrier %.1f us, ring8 %.1f us, ring4 %.1f us%s" % (cin, cout, h, w, t[0], t[1], t[2], extra), flush=True)
     L.fldr_debug_spk_variant(1); L.fldr_debug_ring_consumers(8)
     print("ring timeouts:", L.fldr_debug_ring_timeouts())
 
