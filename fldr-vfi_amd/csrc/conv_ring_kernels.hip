@@ -38,6 +38,9 @@
 #ifndef RING_RW_INFLIGHT
 #define RING_RW_INFLIGHT 2
 #endif
+#ifndef RING_NT_STORES
+#define RING_NT_STORES 0                        // 1: packed outputs of the fast epilogue leave with non-temporal stores — alone 48 -> 48 24.7 -> 22.8 us, dec1 91.7 -> 87.1, 96 -> 96 equal; in the forward the next layer reads them: bench 484.6-487.2 vs 488.1-489.6 with 0
+#endif
 #ifndef RING_PD_THIN
 #define RING_PD_THIN 1                          // operand read-ahead (steps) of the 16-output-channel kernels (2: measured equal, +20-40 registers)
 #endif
@@ -481,8 +484,13 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                         asm volatile("" :: "v"(ohi), "v"(olo));
 #else
                         const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)(lg & 1) * 8u;
+#if RING_NT_STORES
+                        __builtin_nontemporal_store(ohi, reinterpret_cast<h4*>(spkn + off));
+                        __builtin_nontemporal_store(olo, reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)));
+#else
                         *reinterpret_cast<h4*>(spkn + off) = ohi;
                         *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+#endif
 #endif
                     }
                 }
