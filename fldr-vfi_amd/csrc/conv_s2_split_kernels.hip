@@ -863,14 +863,248 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     issue_loads();                                                            // group iteration 1 (or the last tile again)
     __syncthreads();                                                          // (drains the weight DMA too)
     for (int j = 0; j < total; ++j) {
+#if !(defined(S2P_ABLATE) && S2P_ABLATE == 2)                             // diagnostic builds (tools/stamps/build_variant.sh): 1 no LDS staging, 2 no MFMAs, 3 no loads, 4 no epilogue
         mfma_phase(xs0, 2 * cur_g);
         mfma_phase(xs1, 2 * cur_g + 1);
+#endif
         __syncthreads();                                                      // both stages consumed by everybody
         const bool tile_done = cur_g == n_groups - 1;
+#if defined(S2P_ABLATE) && S2P_ABLATE == 1
+        if (j + 1 < total) { issue_loads(); for (int i = 0; i < NIT; ++i) for (int k = 0; k < 4; ++k) asm volatile("" :: "v"(R[i][k])); }
+#elif defined(S2P_ABLATE) && S2P_ABLATE == 3
+        if (j + 1 < total) { store_inputs(); }
+#else
         if (j + 1 < total) { store_inputs(); issue_loads(); }                 // group j + 1 into the stages; request group j + 2
+#endif
+#if defined(S2P_ABLATE) && S2P_ABLATE == 4
+        if (tile_done) { cur_g = 0; ++cur_k; } else ++cur_g;
+#else
         if (tile_done) { epilogue(); cur_g = 0; ++cur_k; } else ++cur_g;
+#endif
         __syncthreads();
     }
+    fldr_note_range(range_bad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-DMA kernel on a SPLIT-PACKED source, 17..32 output channels (round 4: enc2 16 -> 32 and the two 32-channel halves of enc3).
+//
+// The kernel above transposes the packed records into its fp32-source LDS image: 48 v_perm + 48 ds_write_b32 per thread and group
+// iteration, ~700 vector instructions for 48 matrix instructions, two barriers, no operand read-ahead — ablations at 576x960
+// (tools/kernel_bench.py s2spk): enc3 73.9 us = 33 us with the MFMAs compiled out + 41 us of matrix phase for 13-19 us of matrix work.
+// A packed pixel IS a matrix operand: its 16-byte record holds 8 channels of one pixel, i.e. 8 consecutive k of
+// v_mfma_f32_32x32x16_f16 when k = (tap of a pair, channel).  So here
+//   * the (18 x 66 pixel) input window of a (tile, 8-channel group) goes to LDS by LDS-DMA in its natural order, no register staging
+//     (a first version de-interleaved the columns by parity at DMA time so that an output row read 32 consecutive records: every DMA
+//     instruction then gathered records 32 bytes apart and the kernel ran at half the LDS-DMA rate — 168 MB in 52 us for enc2);
+//   * K = 16 = {taps (dy, 2 h) and (dy, 2 h + 1)} x 8 channels: the two lane halves read neighbouring records of the same window row —
+//     one ds_read_b128 per operand (lanes 32 bytes apart: a two-way bank conflict, 8 LDS cycles instead of 4, affordable under 48
+//     32-cycle MFMAs), 8 tap pairs x 3 split terms per group and 32-pixel block;
+//   * two stages, ONE barrier per iteration: the next group's window streams in while this one's 48 MFMAs run with their operands read
+//     two micro-steps ahead; the epilogue of a finished tile runs at the top of the next iteration (its stores have a whole iteration
+//     to drain before the counted wait in front of the barrier).
+// Weights: section D of the pack ([group][tap pair][hi, lo][lane][8 halves], fldr_conv_s2_prepack).  Different summation order than the
+// kernels above (taps outer, channels inner): equal to them to fp32 accumulation rounding, tested against fp64.
+// ------------------------------------------------------------------------------------------------
+#define S2D_NREC (S2_IH * S2_IW)                       // 1188 records per (group, kind) plane: [window row][window column]
+#define S2D_PLANE (S2D_NREC * 16)                      // 19,008 B
+#define S2D_STAGE (2 * S2D_PLANE)                      // hi plane, lo plane
+#ifndef S2D_NLOAD
+#define S2D_NLOAD 8                                    // loader waves (half of them per plane)
+#endif
+#define S2D_NP (40 / S2D_NLOAD)                        // DMA pieces of 64 records per loader wave and stage (20 per plane, the last ones overlap)
+static_assert((S2D_NLOAD / 2) * S2D_NP * 64 >= S2D_NREC, "DMA pieces cover a plane");
+__global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel(S2Args a) {
+    if (blockIdx.y) { a.wpack = a.wpack2; a.bias = a.bias2; a.out = a.out2; a.out_spk = a.out_spk2; }      // pair launch: the second half (uniform)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lj = lane & 31, lg = lane >> 5;
+    const int n_groups = a.cin / 8;
+    unsigned char* const wall = smem;                                         // [group][tap pair][kind][1 KB]
+    unsigned char* const xst = smem + n_groups * 16384;                       // two stages
+
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int total_tiles = a.N * a.n_tiles;
+    const int t_end = min((xcd + 1) * a.tiles_per_xcd, total_tiles);
+    const int t_first = xcd * a.tiles_per_xcd + slot;
+    if (t_first >= t_end) return;                                             // workgroup-uniform
+    const int my_tiles = (t_end - t_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_tiles * n_groups;                                    // iterations
+    // section D of the pack: behind the header and the [chunk][step][kind] section of the kernels above (cin * 512 floats)
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(a.wpack + S2_HDR + (int64_t)a.cin * 512);
+    for (int piece = wave * 64; piece * 16 < n_groups * 16384; piece += (4 + S2D_NLOAD) * 64)  // wave-uniform
+        __builtin_amdgcn_global_load_lds((s2_gptr_t)(wsrc + (piece + lane) * 16), (s2_lptr_t)(wall + piece * 16), 16, 0, 0);
+
+    // Waves 0-3 are CONSUMERS (MFMAs + epilogue), waves 4-11 LOADERS: an LDS-DMA instruction holds its wave's issue port for ~250 cycles
+    // here (a first version, every wave doing both, paid 10 of them = 1.25 us per iteration in front of its MFMAs; four loader waves of
+    // 10 pieces each made the loaders' issue + landing time, 2.25 us, the iteration time).
+    // ---- loader side: this wave's 5 pieces of plane `kind` ----
+    const int lw = wave >= 4 ? wave - 4 : 0;
+    const int kind = lw / (S2D_NLOAD / 2);
+    int p_rec[S2D_NP];                                                        // first record of piece i (wave-uniform)
+    int p_wr[S2D_NP], p_wc[S2D_NP];                                           // window (row, column) of this lane's record
+#pragma unroll
+    for (int i = 0; i < S2D_NP; ++i) {
+        p_rec[i] = min(((lw % (S2D_NLOAD / 2)) * S2D_NP + i) * 64, S2D_NREC - 64);
+        const int rec = p_rec[i] + lane;
+        p_wr[i] = rec / S2_IW;
+        p_wc[i] = rec - p_wr[i] * S2_IW;
+    }
+    const int64_t HWi = (int64_t)a.Hin * a.Win;
+    const unsigned char* const src0 = reinterpret_cast<const unsigned char*>(a.src[0]);
+    const unsigned char* const zero_blk = reinterpret_cast<const unsigned char*>(a.wpack + 4);   // 16 zero bytes (pack header)
+    uint32_t voff[S2D_NP];                                                    // byte offset inside a (group, kind) plane; ~0u: zero record
+    int iss_k = 0, iss_g = 0, iss_n = 0;
+    auto issue_geometry = [&]() __attribute__((always_inline)) {
+        const int t = t_first + iss_k * a.wgs_per_xcd;
+        iss_n = t / a.n_tiles;
+        const int tile = t - iss_n * a.n_tiles;
+        const int ty = tile / a.tiles_x;
+        const int iy0 = ty * S2_TH * 2 - 1, ix0 = (tile - ty * a.tiles_x) * S2_TW * 2 - 1;
+#pragma unroll
+        for (int i = 0; i < S2D_NP; ++i) {
+            const int gy = iy0 + p_wr[i], gx = ix0 + p_wc[i];
+            const bool ok = gy >= 0 && gy < a.Hin && gx >= 0 && gx < a.Win;
+            voff[i] = ok ? (uint32_t)(gy * a.Win + gx) * 16u : ~0u;
+        }
+    };
+    // the window of the issue side's (tile, group) -> stage `st`; steps the issue side (past the end: the last tile again)
+    auto issue_dma = [&](unsigned char* st) __attribute__((always_inline)) {
+        const unsigned char* base = src0 + (int64_t)iss_n * a.src_bstride[0] + (int64_t)(iss_g * 2 + kind) * HWi * 16;
+        unsigned char* dst = st + kind * S2D_PLANE;
+#pragma unroll
+        for (int i = 0; i < S2D_NP; ++i) {
+            const unsigned char* p = voff[i] != ~0u ? base + voff[i] : zero_blk;
+            __builtin_amdgcn_global_load_lds((s2_gptr_t)p, (s2_lptr_t)(dst + p_rec[i] * 16), 16, 0, 0);
+        }
+        if (++iss_g == n_groups) { iss_g = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }
+    };
+
+    // ---- consumer side: output rows 2 cw, 2 cw + 1 of the 8 x 32 tile; lane = (pixel lj, tap of the pair lg) ----
+    const int cw = wave & 3;
+    const uint32_t b_lane = (uint32_t)((cw * 4 * S2_IW + 2 * lj + lg) * 16);    // window row 4 wave (+ 2 p + dy), column 2 lj + lg (+ 2 (tap pair & 1))
+    s2_f16 acc[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f;
+    const float inv_scale = a.wpack[0];
+    const int64_t HWo = (int64_t)a.Hout * a.Wout;
+    int cur_k = 0, cur_g = 0;
+    bool range_bad = false;
+    // Epilogue of tile k of this workgroup: scale, bias, ReLU, split, stores; clears acc.  (Emitting it in chunks between the next
+    // iteration's MFMA micro-steps, on a copy of the accumulators, was built and measured SLOWER — enc2 73.6 vs 56.4 us with four loader
+    // waves: the stores hold the wave's issue port and the matrix pipe starves behind them.)
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int co = (r & 3) + 8 * (r >> 2) + 4 * lg;
+        bias_r[r] = a.bias ? a.bias[co < a.cout ? co : a.cout - 1] : 0.0f;
+    }
+    auto epilogue = [&](int k) __attribute__((always_inline)) {
+        const int t = t_first + k * a.wgs_per_xcd;
+        const int n = t / a.n_tiles, tile = t - n * a.n_tiles;
+        const int ty = tile / a.tiles_x;
+        const int oy0 = ty * S2_TH, ox0 = (tile - ty * a.tiles_x) * S2_TW;
+        float* outn = a.out ? a.out + (int64_t)n * a.cout_store * HWo : nullptr;
+        unsigned char* spkn = a.out_spk ? a.out_spk + (int64_t)n * ((a.cout_store + 7) >> 3) * 2 * HWo * 16 : nullptr;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int oy = oy0 + cw * 2 + p, ox = ox0 + lj;
+            const bool pix_ok = oy < a.Hout && ox < a.Wout;
+            const int64_t po = pix_ok ? (int64_t)oy * a.Wout + ox : 0;
+            float vv[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = (r & 3) + 8 * (r >> 2) + 4 * lg;
+                float v = acc[p][r] * inv_scale + bias_r[r];
+                if (a.relu) v = fmaxf(v, 0.0f);
+                vv[r] = v;
+                acc[p][r] = 0.0f;
+                if (outn && co < a.cout_store && pix_ok) outn[(int64_t)co * HWo + po] = v;
+            }
+            if (spkn) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+                for (int r0 = 0; r0 < 16; r0 += 4) {
+                    const int co0 = 8 * (r0 >> 2) + 4 * lg;
+                    h4 hi, lo;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                        _Float16 h_, l_;
+                        fldr_split_hl(x, h_, l_, range_bad);
+                        hi[r] = h_; lo[r] = l_;
+                    }
+                    if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {
+                        unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
+                        *reinterpret_cast<h4*>(q) = hi;
+                        *reinterpret_cast<h4*>(q + HWo * 16) = lo;
+                    }
+                }
+            }
+        }
+    };
+    // the 48 MFMAs of group `g` on stage `st`: micro-step m = (tap pair m >> 1, pixel block m & 1); operands read two micro-steps ahead
+    auto mfma_group = [&](const unsigned char* st, int g) __attribute__((always_inline)) {
+        const unsigned char* wg = wall + g * 16384 + lane * 16;
+        const unsigned char* xb = st + b_lane;
+        s2_h8 Ah[2], Al[2], Bh[3], Bl[3];
+        auto ld_a = [&](int tp) __attribute__((always_inline)) {
+            Ah[tp & 1] = *reinterpret_cast<const s2_h8*>(wg + tp * 2048);
+            Al[tp & 1] = *reinterpret_cast<const s2_h8*>(wg + tp * 2048 + 1024);
+        };
+        auto ld_b = [&](int m) __attribute__((always_inline)) {
+            const int tp = m >> 1, p = m & 1;
+            const int off = ((2 * p + (tp >> 1)) * S2_IW + 2 * (tp & 1)) * 16;
+            Bh[m % 3] = *reinterpret_cast<const s2_h8*>(xb + off);
+            Bl[m % 3] = *reinterpret_cast<const s2_h8*>(xb + off + S2D_PLANE);
+        };
+        ld_a(0); ld_b(0); ld_b(1);
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            if (m + 2 < 16) { if (!(m & 1)) ld_a((m >> 1) + 1); ld_b(m + 2); }
+            const s2_h8 ah = Ah[(m >> 1) & 1], al = Al[(m >> 1) & 1], bh = Bh[m % 3], bl = Bl[m % 3];
+            acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m & 1], 0, 0, 0);
+            acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m & 1], 0, 0, 0);
+            acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m & 1], 0, 0, 0);
+        }
+    };
+
+    // ---- pipeline ----
+    if (wave >= 4) {
+        issue_geometry();
+        issue_dma(xst);                                                       // iteration 0 -> stage 0
+        __builtin_amdgcn_s_waitcnt(0x0F70);                                   // vmcnt(0): weights and the first window
+        __syncthreads();
+        for (int j = 0; j < total; ++j) {
+#if !(defined(S2D_ABLATE) && S2D_ABLATE == 2)                             // diagnostic builds: 1 no MFMAs, 2 no DMA after the prologue, 3 no epilogue
+            issue_dma(xst + ((j + 1) & 1) * S2D_STAGE);                       // the next iteration's window (past the end: the last tile again)
+#endif
+            __builtin_amdgcn_s_waitcnt(0x0F70);                               // vmcnt(0): my part of it has landed
+            __syncthreads();
+        }
+        return;
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                       // vmcnt(0): my part of the weights
+    __syncthreads();
+    int done_k = -1;                                                          // tile whose accumulators wait for their epilogue
+    for (int j = 0; j < total; ++j) {
+        unsigned char* cur = xst + (j & 1) * S2D_STAGE;
+        // the epilogue of the previous tile at the TOP of the iteration: its stores have a whole iteration to drain before the barrier
+#if defined(S2D_ABLATE) && S2D_ABLATE == 3                                // diagnostic builds: 1 no MFMAs, 2 no DMA after the prologue, 3 no epilogue
+        if (done_k >= 0) { for (int p = 0; p < 2; ++p) { asm volatile("" :: "v"(acc[p])); for (int r = 0; r < 16; ++r) acc[p][r] = 0.0f; } done_k = -1; }
+#else
+        if (done_k >= 0) { epilogue(done_k); done_k = -1; }
+#endif
+#if !(defined(S2D_ABLATE) && S2D_ABLATE == 1)
+        mfma_group(cur, cur_g);
+#endif
+        if (cur_g == n_groups - 1) { done_k = cur_k; cur_g = 0; ++cur_k; } else ++cur_g;
+        __syncthreads();
+    }
+    if (done_k >= 0) epilogue(done_k);
     fldr_note_range(range_bad);
 }
 
@@ -931,12 +1165,35 @@ __global__ void s2_prepack_kernel(const float* __restrict__ w, float* __restrict
     reinterpret_cast<s2_h8*>(wp + S2_HDR)[i] = v;
 }
 
-extern "C" int64_t fldr_conv_s2_prepack_size(int cout, int cin) {
-    if (cout <= 0 || cin <= 0 || cout > 64 || cin > 112) return FLDR_E_ARG;
+// Section D of the pack (conv4x4s2_dma_spk_kernel: 17..32 output channels, cin a multiple of 8, <= 64): [group of 8 channels][tap pair
+// tp = dy * 2 + dx / 2][hi, lo][lane = tap-of-pair * 32 + output channel][8 channels] halves, cin * 512 floats behind the first section.
+static inline bool s2_has_dma_section(int cout, int cin) { return cout > 16 && cout <= 32 && cin % 8 == 0 && cin <= 64; }
+__global__ void s2_prepack_dma_kernel(const float* __restrict__ w, float* __restrict__ wp, float* __restrict__ dst, int cout, int cin, int64_t total_h8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // one 8-half element per thread
+    if (i >= total_h8) return;
+    const float scale = wp[1];
+    const int lane = (int)(i % 64), kind = (int)((i / 64) % 2), tp = (int)((i / 128) % 8), grp = (int)(i / 1024);
+    const int co = lane & 31, dy = tp >> 1, dx = 2 * (tp & 1) + (lane >> 5);
+    s2_h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = grp * 8 + j;
+        const float x = co < cout ? w[(((int64_t)co * cin + c) * 4 + dy) * 4 + dx] * scale : 0.0f;
+        const _Float16 h = (_Float16)x;
+        v[j] = kind == 0 ? h : (_Float16)(x - (float)h);
+    }
+    reinterpret_cast<s2_h8*>(dst)[i] = v;
+}
+
+static inline int64_t s2_first_section_floats(int cout, int cin) {
     int mt, nmt;
     s2_geometry(cout, mt, nmt);
     const int n_chunks = (cin + S2_CC - 1) / S2_CC, steps = S2_CC / ((64 / mt) / 2);
-    return S2_HDR + (int64_t)n_chunks * steps * nmt * 2 * 64 * 4;        // floats
+    return (int64_t)n_chunks * steps * nmt * 2 * 64 * 4;
+}
+extern "C" int64_t fldr_conv_s2_prepack_size(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cout > 64 || cin > 112) return FLDR_E_ARG;
+    return S2_HDR + s2_first_section_floats(cout, cin) + (s2_has_dma_section(cout, cin) ? (int64_t)cin * 512 : 0);        // floats
 }
 
 extern "C" int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream) {
@@ -945,10 +1202,15 @@ extern "C" int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout,
     if (total < 0) return (int)total;
     int mt, nmt;
     s2_geometry(cout, mt, nmt);
-    const int64_t total_h8 = (total - S2_HDR) / 4;
+    const int64_t first = s2_first_section_floats(cout, cin), total_h8 = first / 4;
     hipLaunchKernelGGL(s2_absmax_kernel, dim3(1), dim3(256), 0, fldr_s(stream), weight, (int64_t)cout * cin * 16, wpack);
     hipLaunchKernelGGL(s2_prepack_kernel, dim3(fldr_cdiv(total_h8, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin, mt, nmt,
                        total_h8);
+    if (s2_has_dma_section(cout, cin)) {
+        static_assert(S2_CC * 128 == 512, "first section: cin * 512 floats for 17..32 output channels");
+        const int64_t d_h8 = (int64_t)cin * 128;
+        hipLaunchKernelGGL(s2_prepack_dma_kernel, dim3(fldr_cdiv(d_h8, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, wpack + S2_HDR + first, cout, cin, d_h8);
+    }
     FLDR_LAUNCH_RET();
 }
 
@@ -1069,6 +1331,28 @@ static int s2_launch_pers_spk(S2Args& a, int N, hipStream_t s, int lds_bytes, in
     FLDR_LAUNCH_RET();
 }
 
+// The LDS-DMA kernel (17..32 output channels): all groups' weights + two window stages, one workgroup per CU.
+#ifndef S2_DMA_DEFAULT
+#define S2_DMA_DEFAULT 1
+#endif
+static int g_s2_dma = S2_DMA_DEFAULT;
+FLDR_HOOK int fldr_debug_s2_dma(int v) { if (v == 0 || v == 1) g_s2_dma = v; return g_s2_dma; }
+static int s2_launch_dma_spk(S2Args& a, int N, hipStream_t s, int lds_bytes, int pair) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv4x4s2_dma_spk_kernel), lds_bytes, attr_done)) return e;
+    a.x_shift = 0;
+    a.tiles_x = fldr_cdiv(a.Wout, S2_TW);
+    a.n_tiles = a.tiles_x * fldr_cdiv(a.Hout, S2_TH);
+    a.N = N;
+    const int64_t total = (int64_t)N * a.n_tiles;
+    if (total >= (1ll << 30)) return FLDR_E_SHAPE;
+    a.tiles_per_xcd = (int)((total + 7) / 8);
+    const int cap = 32 / pair;                                               // one workgroup per CU (a pair launch: shared by the two problems)
+    a.wgs_per_xcd = a.tiles_per_xcd < cap ? a.tiles_per_xcd : cap;
+    hipLaunchKernelGGL(conv4x4s2_dma_spk_kernel, dim3(8 * a.wgs_per_xcd, pair), dim3((4 + S2D_NLOAD) * 64), lds_bytes, s, a);
+    FLDR_LAUNCH_RET();
+}
+
 static int s2_spk_run(const fldr_conv_desc* d, const fldr_conv_desc* d2, fldr_stream_t stream) {
     FLDR_CHECK_ARG(d && d->wpack && (d->out || d->out_spk) && d->n_src == 1 && d->src[0] && !d->src_up2[0] && !d->residual);
     FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin <= 64 && (d->cin & 7) == 0 && d->src_c[0] == d->cin && d->cout > 0 && d->cout <= 64);
@@ -1096,7 +1380,12 @@ static int s2_spk_run(const fldr_conv_desc* d, const fldr_conv_desc* d2, fldr_st
     const int n_chunks = d->cin / S2_CC;
     hipStream_t s = fldr_s(stream);
     if (mt == 16) { const int lds = n_chunks * S2Cfg<16, 1>::W_BYTES + 2 * S2Cfg<16, 1>::X_DW * 4; if (lds <= 80 * 1024) return s2_launch_pers_spk<16, 1, 4>(a, d->N, s, lds, pair); }
-    else if (nmt == 1) { const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4; if (lds <= 156 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds, pair); }   // (> 80 KB: one workgroup per CU)
+    else if (nmt == 1) {
+        const int lds_dma = (d->cin / 8) * 16384 + 2 * S2D_STAGE;
+        if (g_s2_dma && s2_has_dma_section(d->cout, d->cin) && lds_dma <= 160 * 1024) return s2_launch_dma_spk(a, d->N, s, lds_dma, pair);
+        const int lds = n_chunks * S2Cfg<32, 1>::W_BYTES + 2 * S2Cfg<32, 1>::X_DW * 4;
+        if (lds <= 156 * 1024) return s2_launch_pers_spk<32, 1, 2>(a, d->N, s, lds, pair);   // (> 80 KB: one workgroup per CU)
+    }
     return FLDR_E_SHAPE;
 }
 

@@ -146,6 +146,7 @@ _SIGNATURES = {
     "fldr_conv2d_s2_spk": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_conv2d_s2_spk_pair": (ctypes.c_int, [ctypes.POINTER(ConvDesc), ctypes.POINTER(ConvDesc), ctypes.c_void_p]),
     "fldr_debug_s2_persistent": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_s2_dma": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_s2_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_dec3_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_dec3_xcd": (ctypes.c_int, [ctypes.c_int]),

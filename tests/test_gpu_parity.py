@@ -390,6 +390,42 @@ def test_stride2_conv_on_packed_source(hip, dev, shape):
     assert esp <= 1.5 * e32 + 1e-8, (esp, e32)
 
 
+@pytest.mark.parametrize("shape", [(16, 32, 50, 70, 2), (16, 32, 144, 240, 1), (32, 32, 68, 120, 1), (32, 32, 272, 96, 2), (40, 24, 30, 44, 1), (8, 20, 18, 34, 1),
+                                   (24, 32, 40, 72, 1), (32, 32, 576, 960, 1)])
+def test_stride2_lds_dma_kernel(hip, dev, shape, hooks):
+    """The LDS-DMA packed-source stride-2 kernel (records straight into LDS, taps outer / channels inner; 17..32 output channels: enc2,
+    enc3's halves) against the register-staged kernel it replaces and against fp64: equal to fp32 accumulation rounding (other summation
+    order), not less accurate; fp32 and packed outputs, single and pair launches, partial tiles, one group (cin 8) up to five (cin 40),
+    many rounds of workgroups, batch of 2."""
+    cin, cout, H, W, N = shape
+    g = _gen(91)
+    x = F.relu(torch.randn(N, cin, H, W, generator=g)).to(dev) * 3
+    wt = (torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5).to(dev)
+    wt2 = (torch.randn(cout, cin, 4, 4, generator=g) / (cin * 16) ** 0.5).to(dev)
+    b, b2 = torch.randn(cout, generator=g).to(dev), torch.randn(cout, generator=g).to(dev)
+    xp = hip.spk_pack(x)
+    L = hip.lib()
+    res = {}
+    try:
+        for dma in (0, 1):
+            assert L.fldr_debug_s2_dma(dma) == dma
+            o32, op = hip.conv2d_s2_spk(xp, wt, b, relu=True, want_f32=True, want_spk=True)
+            pa, pb = hip.conv2d_s2_spk_pair(xp, [(wt, b), (wt2, b2)], relu=False)
+            only = hip.conv2d_s2_spk(xp, wt, b, relu=True, want_f32=False, want_spk=True)
+            assert torch.equal(hip.spk_pack(o32).buf, op.buf) and torch.equal(only.buf, op.buf)
+            res[dma] = (o32, pa.float(), pb.float())
+    finally:
+        L.fldr_debug_s2_dma(1)
+    for a_, b_ in zip(res[0], res[1]):
+        _cmp(b_, a_, atol=2e-6 * float(a_.abs().max()) + 1e-7, what="LDS-DMA kernel vs register-staged kernel")
+    xv = xp.float().double().cpu()
+    ref = F.relu(F.conv2d(xv, wt.double().cpu(), b.double().cpu(), stride=2, padding=1))
+    e0, e1 = (res[0][0].double().cpu() - ref).abs().mean().item(), (res[1][0].double().cpu() - ref).abs().mean().item()
+    assert e1 <= 1.25 * e0 + 1e-9, (e1, e0)
+    ref2 = F.conv2d(xv, wt2.double().cpu(), b2.double().cpu(), stride=2, padding=1)
+    assert (res[1][2].double().cpu() - ref2).abs().max().item() <= 3e-6 * float(ref2.abs().max()) + 1e-7
+
+
 @pytest.mark.parametrize("case", [(96, 96, True, True), (96, 96, True, False), (48, 16, False, False), (64, 40, True, True)])
 def test_multi_level_conv_launch(hip, dev, case):
     """fldr_conv2d_spk_levels (rec_ctx_ds over the pyramid levels in one launch, fLDRnet.py:148-162): the bits of the per-level

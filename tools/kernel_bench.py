@@ -86,6 +86,19 @@ def s2():
     L.fldr_debug_s2_xshift(-1); L.fldr_debug_s2_vec4(1)
 
 
+def s2spk():
+    """enc2 / enc3 on a split-packed source (fldr_conv2d_s2_spk; enc3 as its two 32-channel halves in one launch), rotating inputs."""
+    for (cin, cout, h, w) in [(16, 32, 1152, 1920), (32, 64, 576, 960)]:
+        xs = [hip.spk_pack(torch.rand(1, cin, h, w, device=dev) * 2 - 1) for _ in range(3)]
+        wt = torch.randn(cout, cin, 4, 4, device=dev) / 20; b = torch.randn(cout, device=dev)
+        if cout == 64:
+            halves = [(wt[k:k + 32].contiguous(), b[k:k + 32].contiguous()) for k in (0, 32)]
+            t = timeit(lambda i: hip.conv2d_s2_spk_pair(xs[i % 3], halves, relu=True), 30)
+        else:
+            t = timeit(lambda i: hip.conv2d_s2_spk(xs[i % 3], wt, b, relu=True, want_f32=False, want_spk=True), 30)
+        print("%d->%d @%dx%d packed source: %.1f us" % (cin, cout, h, w, t), flush=True)
+
+
 def dec3():
     H, W = 2304, 3840
     sets = [(torch.rand(1, 16, H // 2, W // 2, device=dev), [torch.rand(1, 3, H, W, device=dev) * 2 - 1 for _ in range(6)]) for _ in range(2)]
@@ -190,7 +203,7 @@ def prep():
     L.fldr_debug_prep_variant(0)
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["conv", "s2", "dec3", "pca", "band", "gather"]
+    which = sys.argv[1:] or ["conv", "s2", "s2spk", "dec3", "pca", "band", "gather"]
     for name in which:
         print("----", name, "(%s)" % os.environ.get("FLDR_LIB", "product library").split("/")[-1], flush=True)
         globals()[name]()
