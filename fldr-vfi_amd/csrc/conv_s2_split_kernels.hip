@@ -1039,8 +1039,12 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
                     }
                     if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {
                         unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
+#if defined(S2D_ABLATE) && S2D_ABLATE == 4                                // diagnostic: the epilogue without its stores
+                        asm volatile("" :: "v"(q), "v"(hi), "v"(lo));
+#else
                         *reinterpret_cast<h4*>(q) = hi;
                         *reinterpret_cast<h4*>(q + HWo * 16) = lo;
+#endif
                     }
                 }
             }
