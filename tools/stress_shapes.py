@@ -27,6 +27,25 @@ for it in range(40):
 hip.lib().fldr_debug_s2_persistent(1); hip.lib().fldr_debug_s2_xshift(-1); hip.lib().fldr_debug_s2_vec4(1)
 print("stride-2 persistent vs per-tile: 40 shapes,", bad, "mismatches", flush=True)
 bad = 0
+for it in range(30):          # packed-source stride-2 encoders: LDS-DMA kernel (17..32 outputs) vs the register-staged kernel (fp32 rounding apart)
+    N = random.choice([1, 1, 2, 3]); cin = random.choice([8, 16, 24, 32, 40]); cout = random.choice([17, 20, 24, 31, 32])
+    H = random.choice([4, 6, 10, 18, 34, 66, 130]); W = random.choice([4, 6, 12, 64, 66, 68, 130, 134, 258])
+    x = torch.relu(torch.randn(N, cin, H, W, device=dev)) * 3
+    xp = hip.spk_pack(x)
+    wt = torch.randn(cout, cin, 4, 4, device=dev) / (cin * 16) ** 0.5; b = torch.randn(cout, device=dev)
+    if not hip.s2_spk_ok(wt): continue
+    outs = []
+    for dma in (0, 1):
+        hip.lib().fldr_debug_s2_dma(dma)
+        o, sp = hip.conv2d_s2_spk(xp, wt, b, relu=bool(it & 1), want_f32=True, want_spk=True)
+        outs.append((o.clone(), sp.float()))
+    hip.lib().fldr_debug_s2_dma(1)
+    tol = 2e-6 * float(outs[0][0].abs().max()) + 1e-7
+    ok = (outs[0][0] - outs[1][0]).abs().max().item() <= tol and (outs[1][1] - outs[1][0]).abs().max().item() <= tol
+    bad += not ok
+    if not ok: print("s2 dma MISMATCH", N, cin, cout, H, W, (outs[0][0] - outs[1][0]).abs().max().item(), tol)
+print("stride-2 packed source, LDS-DMA vs register-staged: 30 shapes,", bad, "mismatches", flush=True)
+bad = 0
 for it in range(30):
     N = random.choice([1, 2]); C = random.choice([1, 2, 3]); H = random.choice([1, 3, 11, 12, 13, 25, 70]); W = random.choice([1, 2, 55, 56, 57, 113, 300])
     mode = random.choice(["summation", "average", "linear", "softmax"])
