@@ -710,6 +710,222 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------
+// 32x32x16 variant (round 4; the previous review's item 2a): output channels in groups of 32, one v_mfma_f32_32x32x16_f16 tile per
+// consumer wave (its tile row of 32 pixels x the unit's 32 output channels).
+//   * K = 16 = ONE tap x the chunk's two 8-channel groups (lane half = group): 9 matrix instructions per chunk and split term,
+//     no zero-weight pad tap (the 16x16x32 kernel spends 10 tap slots on 9 taps);
+//   * a stage = 18 KB of weights ([tap][hi, lo] 1-KB blocks of this group and chunk) + the four input planes, unpadded (21,760 B):
+//     40,192 B, so the ring has FOUR slots (the 48-channel kernel: 3 x 52.5 KB) — MI355X_MICROARCH.md, ring-gemm: a ring one slot
+//     short of (fills in flight + 3) took 7-23 % longer;
+//   * operands read two taps ahead (triple-buffered: 48 registers), one accumulator tile (16 registers).
+// Summation order per output: chunk -> tap -> (hi hi, hi lo, lo hi) — not the 16x16x32 kernels' (tap pairs, term-major), so results
+// agree with them to fp32 accumulation rounding only; error vs fp64 tested against the exact-fp32 kernel's.
+// Scope of this first version: single-level launches, packed output only, every channel stored (cout_store == cout, cout % 32 == 0),
+// no residual.  Loader, unit walk, hand-shake and timeouts: as in conv3x3_ring_kernel.
+// ------------------------------------------------------------------------------------------------
+struct Ring32Cfg {
+    static constexpr int NBLK = 18;                                      // 1-KB weight blocks per chunk: (tap, kind)
+    static constexpr int W_BYTES = NBLK * 1024;
+    static constexpr int NWL = (NBLK + RING_NLOAD - 1) / RING_NLOAD;     // 5
+    static constexpr int IW = SPK_TW + 2;
+    static constexpr int PLANE = SPK_IH * IW * 16;                       // 5,440 B: no padding (the lane halves of an operand read different planes, no bank relation needed)
+    static constexpr int NXI = (SPK_IH * IW + 63) / 64;                  // 6
+    static constexpr int K_DMA = NWL + NXI;                              // 11
+    static constexpr int STAGE = W_BYTES + 4 * PLANE;                    // 40,192
+    static constexpr int SLOTS = 4;
+    static constexpr int CTR_OFF = SLOTS * STAGE;                        // FULL[8] at +0, FREE[8] at +32
+    static constexpr int BIAS_OFF = CTR_OFF + 64;
+    static constexpr int LDS_BYTES = BIAS_OFF + 128;
+    static_assert(K_DMA <= 15 && LDS_BYTES <= 160 * 1024, "ring32 shape");
+};
+
+__global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(SpkArgs a) {
+    using Cfg = Ring32Cfg;
+    constexpr int SLOTS = Cfg::SLOTS, NC = 8;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n_chunks = a.n_chunks;
+    const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
+    if (tid >= 64 && tid < 96) {
+        const int u0 = (blockIdx.x & 7) * a.units_per_xcd + (blockIdx.x >> 3);
+        const int co = (u0 % a.groups) * 32 + (tid - 64);
+        reinterpret_cast<float*>(smem + Cfg::BIAS_OFF)[tid - 64] = (a.bias && co < a.cout) ? a.bias[co] : 0.0f;
+    }
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int u_end = min((xcd + 1) * a.units_per_xcd, a.n_units);
+    const int u_first = xcd * a.units_per_xcd + slot_id;
+    if (u_first >= u_end) return;
+    const int my_units = (u_end - u_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_units * n_chunks;
+    const int grp0 = u_first % a.groups;
+
+    if (wave >= NC) {
+        // =========================================== loader ===========================================
+        const int lw = wave - NC;
+        const int ip = lw, ikind = ip >> 1, igrp = ip & 1;
+        const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
+        int w_blk[Cfg::NWL], x_piece[Cfg::NXI];
+#pragma unroll
+        for (int i = 0; i < Cfg::NWL; ++i) w_blk[i] = min(lw * Cfg::NWL + i, Cfg::NBLK - 1);
+#pragma unroll
+        for (int i = 0; i < Cfg::NXI; ++i) x_piece[i] = min(i * 64, Cfg::PLANE / 16 - 64);
+        unsigned long long tab_ptr;
+        long long tab_bs;
+        {
+            const auto* kt = (const __attribute__((address_space(4))) unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();
+            const int l = lane < SPK_MAX_GROUPS ? lane : 0;
+            unsigned long long e = kt[l];
+            tab_bs = (long long)kt[SPK_MAX_GROUPS + l];
+            const bool up2 = (e & 1ull) != 0ull;
+            const long long plane = up2 ? (long long)(a.H >> 1) * (a.W >> 1) * 16 : (long long)a.H * a.W * 16;
+            if (e != 0ull && ikind) e += (unsigned long long)plane;
+            tab_ptr = e;
+        }
+        int iss_u = u_first, iss_c = 0, iss_n = 0;
+        uint32_t g_full[Cfg::NXI], g_half[Cfg::NXI];
+        auto issue_geometry = [&]() {
+            const int t = spk_div(iss_u, a.m_groups, a.groups);
+            iss_n = spk_div(t, a.m_tiles, a.n_tiles);
+            const int tile = t - iss_n * a.n_tiles;
+            const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+#pragma unroll
+            for (int i = 0; i < Cfg::NXI; ++i) {
+                const int e = x_piece[i] + lane;
+                const int y = e / Cfg::IW, x = e % Cfg::IW;
+                const int gy = oy0 - 1 + y, gx = ox0 - 1 + x;
+                const bool ok = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                g_full[i] = ok ? (uint32_t)(gy * a.W + gx) * 16u : ~0u;
+                g_half[i] = ok ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : ~0u;
+            }
+        };
+        // section R32 of the pack: [group of 32 outputs][chunk][tap][hi, lo] 1-KB blocks behind the first section
+        const char* const iss_w = reinterpret_cast<const char*>(a.wpack) + a.w32_off + (int64_t)grp0 * n_chunks * Cfg::W_BYTES;
+        issue_geometry();
+        int st = 0;
+        uint32_t free_target = 0;
+        for (int k = 0; k < total; ++k) {
+            const char* wbase = iss_w + (int64_t)iss_c * Cfg::W_BYTES + lane * 16;
+            const int gi = iss_c * 2 + igrp;
+            const uint32_t e_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_ptr, gi), e_hi = __builtin_amdgcn_readlane((int)(uint32_t)(tab_ptr >> 32), gi);
+            const uint32_t b_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_bs, gi), b_hi = __builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)tab_bs >> 32), gi);
+            const unsigned long long e = ((unsigned long long)e_hi << 32) | e_lo;
+            const long long bs = (long long)(((unsigned long long)b_hi << 32) | b_lo);
+            const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
+            const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * bs;
+            const char* dptr[Cfg::NXI];
+#pragma unroll
+            for (int i = 0; i < Cfg::NXI; ++i) {
+                const uint32_t off = up2 ? g_half[i] : g_full[i];
+                dptr[i] = (off != ~0u && !nul) ? base + off : zero_blk;
+            }
+            if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane);
+            unsigned char* stage = smem + st * Cfg::STAGE;
+#pragma unroll
+            for (int i = 0; i < Cfg::NWL; ++i)
+                __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_blk[i] * 1024), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < Cfg::NXI; ++i)
+                __builtin_amdgcn_global_load_lds((kgptr_t)dptr[i], (klptr_t)(stage + Cfg::W_BYTES + ip * Cfg::PLANE + x_piece[i] * 16), 16, 0, 0);
+            if (k > 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_DMA);
+                ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
+            }
+            if (++st == SLOTS) { st = 0; free_target += NC; }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
+        return;
+    }
+
+    // ============================================= consumer =============================================
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    const int cw = wave;                                                  // tile row
+    const int lj = lane & 31, lh = lane >> 5;
+    const uint32_t b_lane = (uint32_t)(Cfg::W_BYTES + lh * Cfg::PLANE + (cw * Cfg::IW + lj) * 16);
+    f16v acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    int cur_u = u_first, cur_c = 0;
+    const float inv_scale = a.wpack[0];
+    const int64_t HW = (int64_t)a.H * a.W;
+    const uint32_t HW32 = (uint32_t)HW;
+    float bias_r[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bias_r[r] = reinterpret_cast<const float*>(smem + Cfg::BIAS_OFF)[(r & 3) + 8 * (r >> 2) + 4 * lh];
+    const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
+    bool range_bad = false;
+    auto finish_store = [&]() {
+        const int t = spk_div(cur_u, a.m_groups, a.groups);
+        const int n = spk_div(t, a.m_tiles, a.n_tiles);
+        const int tile = t - n * a.n_tiles;
+        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x), tx = tile - ty * a.tiles_x;
+        const int oy = ty * SPK_TH + cw, ox = tx * SPK_TW + lj;
+        const bool ok = oy < a.H && ox < a.W;
+        unsigned char* spkn = a.out_spk + (int64_t)n * a.out_spk_bstride;
+        const uint32_t pq = ok ? (uint32_t)(oy * a.W + ox) : 0u;
+#pragma unroll
+        for (int r0 = 0; r0 < 16; r0 += 4) {
+            const int co0 = grp0 * 32 + 8 * (r0 >> 2) + 4 * lh;
+            h4 ohi, olo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = fmaxf(acc[r0 + r] * inv_scale + bias_r[r0 + r], relu_floor);
+                acc[r0 + r] = 0.0f;
+                _Float16 h, l;
+                spk_split(v, h, l, range_bad);
+                ohi[r] = h; olo[r] = l;
+            }
+            if (ok) {
+                const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)lh * 8u;
+                *reinterpret_cast<h4*>(spkn + off) = ohi;
+                *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+            }
+        }
+    };
+    int st_cur = 0, g = 0;
+    uint32_t full_target = RING_NLOAD;
+    while (g < total) {
+        const bool last = cur_c == n_chunks - 1;
+        ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
+        {
+            const unsigned char* sb = smem + st_cur * Cfg::STAGE;
+            const unsigned char* wb = sb + lane * 16;
+            const unsigned char* xb = sb + b_lane;
+            h8 Ah[3], Al[3], Bh[3], Bl[3];
+            auto ld = [&](int t) __attribute__((always_inline)) {
+                const int off = ((t / 3) * Cfg::IW + t % 3) * 16;
+                Ah[t % 3] = *reinterpret_cast<const h8*>(wb + (2 * t) * 1024);
+                Al[t % 3] = *reinterpret_cast<const h8*>(wb + (2 * t + 1) * 1024);
+                Bh[t % 3] = *reinterpret_cast<const h8*>(xb + off);
+                Bl[t % 3] = *reinterpret_cast<const h8*>(xb + 2 * Cfg::PLANE + off);
+            };
+            ld(0); ld(1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                // (the fences keep the reads two taps ahead of their use: left alone, the scheduler sinks them to one MFMA before it —
+                // 76 registers instead of 100, and an exposed LDS round trip per tap)
+                if (t + 2 < 9) ld(t + 2);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[t % 3], Bh[t % 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[t % 3], Bl[t % 3], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[t % 3], Bh[t % 3], acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        ring_signal(ctr + 32 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
+        if (last) { finish_store(); cur_c = 0; cur_u += a.wgs_per_xcd; } else ++cur_c;
+        if (++st_cur == SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
+        ++g;
+    }
+    fldr_note_range(range_bad);
+}
+
 static int g_ring_consumers = 8;
 FLDR_HOOK int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
 
@@ -785,7 +1001,44 @@ static int ring_launch(SpkArgs& a, int N, int wpx, hipStream_t s) {
     return a.residual ? ring_launch2<NMT, TERMS, true>(a, N, wpx, s) : ring_launch2<NMT, TERMS, false>(a, N, wpx, s);
 }
 
+// The 32x32x16 kernel where it applies: 64 or 96 output channels all stored, packed output only, no residual, launches that are not
+// run as 16-channel sub-groups.
+#ifndef RING32_DEFAULT
+#define RING32_DEFAULT 1
+#endif
+static int g_ring32 = RING32_DEFAULT;
+FLDR_HOOK int fldr_debug_ring32(int v) { if (v >= 0 && v <= 2) g_ring32 = v; return g_ring32; }
+static int ring32_launch(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring32_kernel), Ring32Cfg::LDS_BYTES, attr_done)) return e;
+    a.groups = a.cout / 32;
+    if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, SPK_TW)) return e;
+    hipLaunchKernelGGL(conv3x3_ring32_kernel, dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Ring32Cfg::LDS_BYTES, s, a);
+    FLDR_LAUNCH_RET();
+}
+
+// Measured (tools/kernel_bench.py conv, 96 -> 96): a round of 32-channel units costs ~0.8 of a round of 48-channel units (11.1-11.4 vs
+// 12.6-14.2 us) for two thirds of the work — the kernel's 36 operand reads per 27 MFMAs keep the LDS array ~75 % busy — so it is NOT
+// the faster kernel per unit of work (288x480: 78.0 vs 71.1 us).  It wins where its finer units fill the rounds of persistent workgroups
+// better: the second pyramid level of a 4K pair, 144x240 = 405 units instead of 270 (or 540 narrow ones): 22.8 vs 25.2 us.
+#ifndef RING32_ROUND_COST
+#define RING32_ROUND_COST 0.8
+#endif
+static bool ring32_pays(const SpkArgs& a, int N, int wgs_per_xcd_max) {
+    if (g_ring32 == 2) return true;                                       // forced (tests, kernel_bench)
+    if (a.cout != 96) return false;                                      // (64 outputs: the 16x16x32 kernel's units are 32 channels already — 35.2 vs 36.5 us at 288x480)
+    const int64_t wgs = 8ll * wgs_per_xcd_max, tx32 = fldr_cdiv(a.W, 32), ty = fldr_cdiv(a.H, SPK_TH);
+    const int64_t u48 = (int64_t)N * tx32 * ty * a.groups, u16 = (int64_t)N * fldr_cdiv(a.W, 16) * ty * a.groups, u32 = (int64_t)N * tx32 * ty * (a.cout / 32);
+    if (u32 <= wgs) return false;                                        // launches that do not fill the chip either way
+    const double c48 = (double)((u48 + wgs - 1) / wgs), c16 = (double)((u16 + wgs - 1) / wgs) * RING_NARROW_COST;
+    const double c32 = (double)((u32 + wgs - 1) / wgs) * RING32_ROUND_COST;
+    return c32 < (c48 < c16 ? c48 : c16);
+}
+
 int fldr_spk_ring_dispatch(SpkArgs& a, int N, int nmt, int terms, int wgs_per_xcd_max, hipStream_t s) {
+    if (g_ring32 && terms == 3 && nmt >= 2 && a.w32_off && a.cout_store == a.cout && !a.residual && !a.out_f32 && a.out_spk && g_ring_consumers == 8 &&
+        g_ring_tile_width == 0 && ring32_pays(a, N, wgs_per_xcd_max))
+        return ring32_launch(a, N, wgs_per_xcd_max, s);
     if (terms == 1) {
         if (nmt == 1) return ring_launch<1, 1>(a, N, wgs_per_xcd_max, s);
         if (nmt == 2) return ring_launch<2, 1>(a, N, wgs_per_xcd_max, s);

@@ -509,14 +509,6 @@ extern "C" int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H,
 // weights: same body layout as conv_split_kernels.hip ([group][chunk][step][m][kind][lane][8 halves]) behind an
 // 8-float header whose second half is the zero block
 // ------------------------------------------------------------------------------------------------
-static inline void spk_geometry(int cout, int& nmt, int& groups) {
-    if (cout <= 16)      { nmt = 1; groups = 1; }
-    else if (cout <= 32) { nmt = 2; groups = 1; }
-    else if (cout <= 48) { nmt = 3; groups = 1; }
-    else if (cout <= 64) { nmt = 2; groups = 2; }
-    else                 { nmt = 3; groups = (cout + 47) / 48; }
-}
-
 __global__ void spk_absmax_kernel(const float* __restrict__ w, int64_t n, float* __restrict__ hdr) {
     __shared__ float red[256];
     float m = 0.0f;
@@ -561,12 +553,29 @@ __global__ void spk_prepack_kernel(const float* __restrict__ w, float* __restric
     reinterpret_cast<h8*>(wp + SPK_HDR)[i] = v;
 }
 
+// section R32: [group of 32 outputs][chunk][tap][hi, lo][lane = channel-group-of-the-chunk * 32 + output][8 channels]
+__global__ void spk_prepack32_kernel(const float* __restrict__ w, const float* __restrict__ hdr, float* __restrict__ dst, int cout, int cin,
+                                     int n_chunks, int64_t total_h8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_h8) return;
+    const float scale = hdr[1];
+    const int lane = (int)(i % 64), kind = (int)((i / 64) % 2), tap = (int)((i / 128) % 9);
+    const int ch = (int)((i / (128 * 9)) % n_chunks), gr = (int)(i / ((int64_t)128 * 9 * n_chunks));
+    const int co = gr * 32 + (lane & 31);
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = ch * 16 + (lane >> 5) * 8 + j;
+        const float x = (co < cout && c < cin) ? w[((int64_t)co * cin + c) * 9 + tap] * scale : 0.0f;
+        const _Float16 h = (_Float16)x;
+        v[j] = kind == 0 ? h : (_Float16)(x - (float)h);
+    }
+    reinterpret_cast<h8*>(dst)[i] = v;
+}
+
 extern "C" int64_t fldr_conv_spk_prepack_size(int cout, int cin) {
     if (cout <= 0 || cin <= 0 || cout > 96 || cin > SPK_MAX_GROUPS * 8) return FLDR_E_ARG;
-    int nmt, groups;
-    spk_geometry(cout, nmt, groups);
-    const int n_chunks = (cin + 15) / 16;
-    return SPK_HDR + (int64_t)groups * n_chunks * SPK_STEPS * nmt * 2 * 64 * 4;
+    return SPK_HDR + spk_first_section_floats(cout, cin) + spk_r32_section_floats(cout, cin);
 }
 
 extern "C" int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream) {
@@ -576,10 +585,15 @@ extern "C" int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout
     int nmt, groups;
     spk_geometry(cout, nmt, groups);
     const int n_chunks = (cin + 15) / 16;
-    const int64_t total_h8 = (total - SPK_HDR) / 4;
+    const int64_t first = spk_first_section_floats(cout, cin), total_h8 = first / 4;
     hipLaunchKernelGGL(spk_absmax_kernel, dim3(1), dim3(256), 0, fldr_s(stream), weight, (int64_t)cout * cin * 9, wpack);
     hipLaunchKernelGGL(spk_prepack_kernel, dim3(fldr_cdiv(total_h8, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, cout, cin,
                        nmt, n_chunks, total_h8);
+    if (spk_has_r32_section(cout)) {
+        const int64_t r_h8 = spk_r32_section_floats(cout, cin) / 4;
+        hipLaunchKernelGGL(spk_prepack32_kernel, dim3(fldr_cdiv(r_h8, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, wpack + SPK_HDR + first,
+                           cout, cin, n_chunks, r_h8);
+    }
     FLDR_LAUNCH_RET();
 }
 
@@ -644,6 +658,7 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
     int nmt, groups;
     spk_geometry(d->cout, nmt, groups);
     a.groups = groups; a.pack_nmt = nmt;
+    a.w32_off = spk_has_r32_section(d->cout) ? (SPK_HDR + spk_first_section_floats(d->cout, d->cin)) * 4 : 0;
     // Small launches (the coarse pyramid levels): fewer units than CUs, and every workgroup would stream the weights
     // of 48 output channels on its own (166 KB for 96 inputs, ~8 us at one CU's DMA rate).  Run the 16-channel kernel
     // on sub-groups of the same weight pack instead: 3x the workgroups, a third of the weight stream each; the
@@ -694,7 +709,7 @@ extern "C" int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_lev
     a.H = d0.H; a.W = d0.W; a.relu = d0.relu;
     int nmt, groups;
     spk_geometry(d0.cout, nmt, groups);
-    a.groups = groups; a.pack_nmt = nmt;
+    a.groups = groups; a.pack_nmt = nmt; a.w32_off = 0;
     a.n_levels = n_levels;
     int64_t units = 0;
     for (int l = 0; l < n_levels; ++l) {

@@ -49,7 +49,26 @@ struct SpkArgs {
         int64_t in_off, out_spk_off, out_f32_off, res_off;
     } lv[SPK_MAX_LEVELS];
     uint32_t m_groups, m_tiles, m_tiles_x;        // floor(2^32 / d) + 1: u / d == umulhi(u, m) for u * d < 2^32 (d > 1)
+    int64_t w32_off;                              // conv3x3_ring32_kernel: byte offset of section R32 of the weight pack from wpack
 };
+
+// Output-channel geometry of the 16x16x32 kernels: 16-channel blocks per group (NMT), groups per launch.
+static inline void spk_geometry(int cout, int& nmt, int& groups) {
+    if (cout <= 16)      { nmt = 1; groups = 1; }
+    else if (cout <= 32) { nmt = 2; groups = 1; }
+    else if (cout <= 48) { nmt = 3; groups = 1; }
+    else if (cout <= 64) { nmt = 2; groups = 2; }
+    else                 { nmt = 3; groups = (cout + 47) / 48; }
+}
+// Weight pack: header, first section ([group][chunk][step][m][kind] 1-KB blocks of the 16x16x32 kernels), and — for 64 or 96 output
+// channels — section R32 ([group of 32][chunk][tap][kind] 1-KB blocks of conv3x3_ring32_kernel).  Sizes in floats.
+static inline int64_t spk_first_section_floats(int cout, int cin) {
+    int nmt, groups;
+    spk_geometry(cout, nmt, groups);
+    return (int64_t)groups * ((cin + 15) / 16) * SPK_STEPS * nmt * 2 * 64 * 4;
+}
+static inline bool spk_has_r32_section(int cout) { return cout == 64 || cout == 96; }
+static inline int64_t spk_r32_section_floats(int cout, int cin) { return spk_has_r32_section(cout) ? (int64_t)(cout / 32) * ((cin + 15) / 16) * 18 * 256 : 0; }
 
 template <int NMT>
 struct SpkCfg {

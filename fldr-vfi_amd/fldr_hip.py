@@ -164,6 +164,7 @@ _SIGNATURES = {
     "fldr_debug_spk_small_units": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_consumers": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_ring32": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_resident": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_timeouts": (ctypes.c_int, []),
     "fldr_sizeof_desc": (ctypes.c_int, [ctypes.c_int]),

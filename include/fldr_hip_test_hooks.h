@@ -21,6 +21,7 @@ int fldr_debug_spk_small_units(int v);                              /* tuning ho
 int fldr_debug_spk_wgs_per_xcd(int v);                             /* tuning hook: persistent workgroups per XCD (default 32) */
 int fldr_debug_spk_variant(int v);                                 /* pipeline of fldr_conv2d_spk: 1 (default) loader / consumer ring, 0 barrier pipeline; -1: query.  Bit-identical results */
 int fldr_debug_ring_resident(int v);                               /* 1: resident-weight ring (5 slots, two fills in flight) for 16-output-channel launches of <= 4 input chunks; 0 (default): streamed weights; other: query */
+int fldr_debug_ring32(int v);                                      /* the 32x32x16 ring kernel for 64 / 96 output channels (packed output, no residual): 1 (default) where its cost model says it fills the workgroup rounds better, 2 wherever it applies, 0 never; other: query */
 int fldr_debug_ring_consumers(int v);                              /* tuning hook of the ring pipeline: 8 (default; two consumer waves per SIMD) or 4 consumer waves; other: query */
 int fldr_debug_corr_variant(int v);                                /* cost volume staging: 1 (default) LDS-DMA double buffer where W % 4 == 0, 0 synchronous; other: query.  Bit-identical results */
 int fldr_debug_corr_xcd(int v);                                    /* tile order of the LDS-DMA cost-volume kernel: 1 (default) contiguous tile ranges per XCD, 0 row-major; other: query.  Identical results */

@@ -390,6 +390,44 @@ def test_stride2_conv_on_packed_source(hip, dev, shape):
     assert esp <= 1.5 * e32 + 1e-8, (esp, e32)
 
 
+@pytest.mark.parametrize("shape", [(1, [96], [0], 96, 72, 120, True), (1, [48, 48, 4], [0, 0, 0], 96, 36, 60, True), (2, [96], [0], 96, 50, 70, False),
+                                   (1, [32, 32], [0, 0], 64, 144, 240, True), (1, [64, 32], [1, 0], 64, 48, 80, True), (1, [96], [0], 96, 288, 480, True),
+                                   (1, [16], [0], 64, 9, 15, False), (3, [40], [0], 96, 17, 33, True)])
+def test_ring32_conv_matches_the_16x16x32_kernels(hip, dev, shape, hooks):
+    """conv3x3_ring32_kernel (v_mfma_f32_32x32x16_f16 tiles, 4-slot ring, no pad tap; 64 / 96 output channels, packed output) against the
+    16x16x32 ring kernel: another summation order (tap by tap instead of tap pairs, term-major), so equal to fp32 accumulation rounding,
+    and not less accurate against fp64 than the exact-fp32-product kernel; multi-source, nearest-x2 source, partial tiles, batches,
+    several rounds of persistent workgroups, launches too small to fill the chip."""
+    N, cs, ups, cout, H, W, relu = shape
+    g = _gen(52)
+    srcs = [torch.randn(N, c, H // (2 if u else 1), W // (2 if u else 1), generator=g).to(dev) for c, u in zip(cs, ups)]
+    wt = (torch.randn(cout, sum(cs), 3, 3, generator=g) / (sum(cs) * 9) ** 0.5).to(dev)
+    b = torch.randn(cout, generator=g).to(dev)
+    up2 = [bool(u) for u in ups]
+    packed = [hip.spk_pack(x) for x in srcs]
+    L = hip.lib()
+    res = {}
+    try:
+        L.fldr_debug_spk_small_units(-1)                    # (keep the small launches on the kernels under test)
+        for r32 in (0, 2):                                  # never / wherever it applies (1 = by its cost model)
+            assert L.fldr_debug_ring32(r32) == r32
+            res[min(r32, 1)] = hip.conv2d_spk(packed, wt, b, relu=relu, up2=up2, want_f32=False, want_spk=True).float()
+    finally:
+        L.fldr_debug_ring32(1)
+        L.fldr_debug_spk_small_units(96)
+    assert L.fldr_debug_ring_timeouts() == 0
+    scale = float(res[0].abs().max())
+    _cmp(res[1], res[0], atol=3e-6 * scale + 1e-7, what="ring32 vs 16x16x32 ring")
+    xs = [p_.float().double().cpu() for p_ in packed]
+    xs = [F.interpolate(x, scale_factor=2, mode="nearest") if u else x for x, u in zip(xs, ups)]
+    ref = F.conv2d(torch.cat(xs, 1), wt.double().cpu(), b.double().cpu(), padding=1)
+    ref = F.relu(ref) if relu else ref
+    e32 = (hip.conv2d(srcs, wt, b, relu=relu, up2=up2, precision="fp32").double().cpu() - F.conv2d(torch.cat([F.interpolate(x.double().cpu(), scale_factor=2, mode="nearest") if u else x.double().cpu() for x, u in zip(srcs, ups)], 1), wt.double().cpu(), b.double().cpu(), padding=1).clamp(min=0 if relu else -1e30)).abs().mean().item()
+    e_r32 = (res[1].double().cpu() - ref).abs().mean().item()
+    # the packed output itself rounds to 22 bits: allow that on top of the exact-fp32 kernel's accumulation error
+    assert e_r32 <= 1.5 * e32 + 2.0 ** -22 * float(ref.abs().mean()) + 1e-9, (e_r32, e32)
+
+
 @pytest.mark.parametrize("shape", [(16, 32, 50, 70, 2), (16, 32, 144, 240, 1), (32, 32, 68, 120, 1), (32, 32, 272, 96, 2), (40, 24, 30, 44, 1), (8, 20, 18, 34, 1),
                                    (24, 32, 40, 72, 1), (32, 32, 576, 960, 1)])
 def test_stride2_lds_dma_kernel(hip, dev, shape, hooks):

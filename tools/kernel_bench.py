@@ -32,10 +32,15 @@ def conv():
                               (48, 48, 288, 480), (48, 16, 1152, 1920), (96, 32, 576, 960), (64, 64, 288, 480), (48, 4, 288, 480)]:
         x = torch.rand(1, cin, h, w, device=dev); xp = hip.spk_pack(x); w2 = torch.randn(cout, cin, 3, 3, device=dev) / 30
         t = []
+        L.fldr_debug_ring32(0)                               # the 16x16x32 kernels in the first three columns
         for var in (0, 1, 2):
             L.fldr_debug_spk_variant(min(var, 1)); L.fldr_debug_ring_consumers(8 if var == 1 else 4)
             t.append(timeit(lambda i: hip.conv2d_spk([xp], w2, None, relu=True, want_f32=False, want_spk=True), 40))
         extra = ""
+        L.fldr_debug_spk_variant(1); L.fldr_debug_ring_consumers(8)
+        if cout in (64, 96):                                 # the 32x32x16 ring kernel
+            L.fldr_debug_ring32(2)
+            extra += ", ring32 %.1f us" % timeit(lambda i: hip.conv2d_spk([xp], w2, None, relu=True, want_f32=False, want_spk=True), 40)
         if cout <= 16 and cin <= 64:                         # the resident-weight ring applies (test build, off by default): beside the default
             L.fldr_debug_ring_resident(1)
             for cons in (8, 4):
@@ -43,7 +48,7 @@ def conv():
                 extra += ", resident weights ring%d %.1f us" % (cons, timeit(lambda i: hip.conv2d_spk([xp], w2, None, relu=True, want_f32=False, want_spk=True), 40))
             L.fldr_debug_ring_resident(0)
         print("%3d->%2d @%4dx%4d: barrier %.1f us, ring8 %.1f us, ring4 %.1f us%s" % (cin, cout, h, w, t[0], t[1], t[2], extra), flush=True)
-    L.fldr_debug_spk_variant(1); L.fldr_debug_ring_consumers(8)
+    L.fldr_debug_spk_variant(1); L.fldr_debug_ring_consumers(8); L.fldr_debug_ring32(1)
     print("ring timeouts:", L.fldr_debug_ring_timeouts())
 
 
