@@ -909,6 +909,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #define S2D_NREC (S2_IH * S2_IW)                       // 1188 records per (group, kind) plane: [window row][window column]
 #define S2D_PLANE (S2D_NREC * 16)                      // 19,008 B
 #define S2D_STAGE (2 * S2D_PLANE)                      // hi plane, lo plane
+#ifdef S2D_NOFENCE
+#define S2D_FENCE()
+#else
+#define S2D_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifndef S2D_NLOAD
 #define S2D_NLOAD 8                                    // loader waves (half of them per plane)
 #endif
@@ -1066,13 +1071,16 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
             Bl[m % 3] = *reinterpret_cast<const s2_h8*>(xb + off + S2D_PLANE);
         };
         ld_a(0); ld_b(0); ld_b(1);
+        S2D_FENCE();
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
+            // (fences: left alone, the scheduler sinks the reads to one MFMA before their use and every micro-step waits an LDS round trip)
             if (m + 2 < 16) { if (!(m & 1)) ld_a((m >> 1) + 1); ld_b(m + 2); }
             const s2_h8 ah = Ah[(m >> 1) & 1], al = Al[(m >> 1) & 1], bh = Bh[m % 3], bl = Bl[m % 3];
             acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[m & 1], 0, 0, 0);
             acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[m & 1], 0, 0, 0);
             acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[m & 1], 0, 0, 0);
+            S2D_FENCE();
         }
     };
 
