@@ -57,6 +57,47 @@ __device__ __forceinline__ void fldr_split_hl(float x, _Float16& hi, _Float16& l
     hi = (_Float16)t;
     lo = (_Float16)__builtin_amdgcn_fmed3f(x - t, -FLDR_F16_MAX, FLDR_F16_MAX);
 }
+// Pieces of the wave-uniform guard for callers that decide once for MANY values (a whole unit's epilogue): sum |x| while the values
+// are produced, ask fldr_guard_trips once, then split with fldr_split_hl (tripped: exact per-value semantics, flag included) or
+// fldr_split_plain (no lane's sum left the range, so every value is in range and the plain split gives the same bits).
+__device__ __forceinline__ void fldr_split_plain(float x, _Float16& hi, _Float16& lo) {
+    const float t0 = __uint_as_float(__float_as_uint(x) & 0xFFFFE000u);
+    hi = (_Float16)t0; lo = (_Float16)(x - t0);
+}
+__device__ __forceinline__ bool fldr_guard_trips(float abs_sum) {        // wave-uniform; inf and NaN propagate through the sum
+#if defined(FLDR_PER_VALUE_GUARD) || defined(FLDR_NO_RANGE_GUARD)
+    return true;
+#else
+    return __builtin_expect(__builtin_amdgcn_ballot_w64(!(abs_sum <= FLDR_F16_MAX)) != 0ull, 0);
+#endif
+}
+// The same split for a GROUP of values with the guard decided per WAVE: one |x| sum per lane (an add per value) and one compare per
+// group instead of a compare and two clamps per value.  If no lane's sum exceeds the range (the sum bounds every |x|; inf and NaN
+// propagate through it) every value is in range and the plain split gives the guarded split's bits; otherwise — rare: activations of
+// this network are O(1..100) — the whole wave takes the guarded per-value path above, flag included.  Same results and the same flag
+// semantics as fldr_split_hl in every case; ~2 vector instructions per value less (the step runs at the board's power limit, where
+// instructions saved return as time: bench +2 % with the guards compiled out entirely, DESIGN_LOG round 4).
+template <int N>
+__device__ __forceinline__ void fldr_split_hl_group(const float (&x)[N], _Float16 (&hi)[N], _Float16 (&lo)[N], bool& bad) {
+#if defined(FLDR_PER_VALUE_GUARD) || defined(FLDR_NO_RANGE_GUARD)
+#pragma unroll
+    for (int i = 0; i < N; ++i) fldr_split_hl(x[i], hi[i], lo[i], bad);
+#else
+    float s = fabsf(x[0]);
+#pragma unroll
+    for (int i = 1; i < N; ++i) s += fabsf(x[i]);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(s <= FLDR_F16_MAX)) != 0ull, 0)) {   // wave-uniform, rare
+#pragma unroll
+        for (int i = 0; i < N; ++i) fldr_split_hl(x[i], hi[i], lo[i], bad);
+    } else {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const float t0 = __uint_as_float(__float_as_uint(x[i]) & 0xFFFFE000u);
+            hi[i] = (_Float16)t0; lo[i] = (_Float16)(x[i] - t0);
+        }
+    }
+#endif
+}
 __device__ __forceinline__ void fldr_note_range(bool bad) { if (bad) fldr_tu_range_flag = 1; }
 static inline int fldr_tu_range_read(int reset) {
     int v = 0;

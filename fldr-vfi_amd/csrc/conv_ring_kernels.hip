@@ -432,7 +432,8 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     // has no predication at all: ~20 VALU instructions and the stores per (pixel block, 16-channel block); the general
     // one predicates every store.  ReLU is max(v, floor) with floor = 0 or -FLT_MAX: no select.
     const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
-    bool range_bad = false;
+    // (no kernel-wide range flag: a per-lane bool carried through the iteration loop costs a 64-bit SGPR mask — this kernel spills SGPRs —
+    // and mask bookkeeping at every merge; the guarded paths are rare and note the event in the sticky flag on the spot)
     const bool grp_full = cbase + MTOT <= a.cout_store && !(a.cout_store & 7);      // wave-uniform, constant over the kernel
 #ifdef RING_STAMPS
     unsigned long long cs_f_dec = 0, cs_f_fast = 0, cs_f_b0 = 0, fq0 = 0;
@@ -452,49 +453,69 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         RSTAMP(f1)
         if (grp_full && inside) {
             const uint32_t p0 = (uint32_t)(oy0 * uW + ox0 + lj);
+            // pass 1: the finished values in place of the accumulators, and per lane the sum of their magnitudes — the range guard of the
+            // split is decided ONCE per unit and wave (common.h: fldr_guard_trips) instead of a compare and two clamps per value
+            float abs_sum = 0.0f;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                const uint32_t pq = p0 + (uint32_t)((q / CB) * uW + (q % CB) * 16);
-#ifdef RING_STAMPS
-                if (q == 1) { RSTAMP(fq) fq0 = fq; }
-#endif
+            for (int q = 0; q < NQ; ++q)
 #pragma unroll
                 for (int m = 0; m < NMT; ++m) {
-                    const int co0 = cbase + m * 16 + lg * 4;
-                    float ov[4];
-                    h4 ohi, olo;
                     const f4 bsv = bias_of(m);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         float v = fmaxf(acc[m][q][r] * inv_scale + bsv[r], relu_floor);
                         if constexpr (HAS_RES) v += res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r];
-                        ov[r] = v;
-                        acc[m][q][r] = 0.0f;
-                        _Float16 h, l;
-                        spk_split(v, h, l, range_bad);
-                        ohi[r] = h; olo[r] = l;
-                    }
-                    if (outn) {
-                        const uint32_t off = ((uint32_t)co0 * HW32 + pq) * 4u;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[r];
-                    }
-                    if (spkn) {
-#if defined(RING_ABLATE) && RING_ABLATE == 6                          // diagnostic: the finish without its packed stores
-                        asm volatile("" :: "v"(ohi), "v"(olo));
-#else
-                        const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)(lg & 1) * 8u;
-#if RING_NT_STORES
-                        __builtin_nontemporal_store(ohi, reinterpret_cast<h4*>(spkn + off));
-                        __builtin_nontemporal_store(olo, reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)));
-#else
-                        *reinterpret_cast<h4*>(spkn + off) = ohi;
-                        *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
-#endif
-#endif
+                        acc[m][q][r] = v;
+                        abs_sum += fabsf(v);
                     }
                 }
-            }
+            // pass 2: split and store
+            auto emit = [&](auto guardedc) __attribute__((always_inline)) {
+                constexpr bool GUARDED = decltype(guardedc)::value;
+                bool range_bad = false;
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const uint32_t pq = p0 + (uint32_t)((q / CB) * uW + (q % CB) * 16);
+#ifdef RING_STAMPS
+                    if (q == 1) { RSTAMP(fq) fq0 = fq; }
+#endif
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m) {
+                        const int co0 = cbase + m * 16 + lg * 4;
+                        float ov[4];
+                        h4 ohi, olo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            ov[r] = acc[m][q][r];
+                            acc[m][q][r] = 0.0f;
+                            _Float16 h, l;
+                            if constexpr (GUARDED) spk_split(ov[r], h, l, range_bad); else fldr_split_plain(ov[r], h, l);
+                            ohi[r] = h; olo[r] = l;
+                        }
+                        if (outn) {
+                            const uint32_t off = ((uint32_t)co0 * HW32 + pq) * 4u;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(outn + (off + (uint32_t)r * HW32 * 4u)) = ov[r];
+                        }
+                        if (spkn) {
+#if defined(RING_ABLATE) && RING_ABLATE == 6                          // diagnostic: the finish without its packed stores
+                            asm volatile("" :: "v"(ohi), "v"(olo));
+#else
+                            const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)(lg & 1) * 8u;
+#if RING_NT_STORES
+                            __builtin_nontemporal_store(ohi, reinterpret_cast<h4*>(spkn + off));
+                            __builtin_nontemporal_store(olo, reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)));
+#else
+                            *reinterpret_cast<h4*>(spkn + off) = ohi;
+                            *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+#endif
+#endif
+                        }
+                    }
+                }
+                if constexpr (GUARDED) { if (a.out_spk) fldr_note_range(range_bad); }
+            };
+            if (fldr_guard_trips(abs_sum)) emit(std::true_type{}); else emit(std::false_type{});
 #ifdef RING_STAMPS
             { RSTAMP(f2) cs_f_dec += f1 - f0; cs_f_fast += f2 - f1; cs_f_b0 += fq0 - f1; }
 #endif
@@ -515,16 +536,22 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 float ov[4];
                 h4 ohi, olo;
                 const f4 bsv = bias_of(m);
+                float xs[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float v = fmaxf(acc[m][q][r] * inv_scale + bsv[r], relu_floor);
                     if constexpr (HAS_RES) v += res_r[HAS_RES ? m : 0][HAS_RES ? q : 0][r];
                     ov[r] = v;
                     acc[m][q][r] = 0.0f;
-                    const float x = co0 + r < a.cout_store ? v : 0.0f;
-                    _Float16 h, l;
-                    spk_split(x, h, l, range_bad);
-                    ohi[r] = h; olo[r] = l;
+                    xs[r] = co0 + r < a.cout_store ? v : 0.0f;
+                }
+                {
+                    _Float16 h[4], l[4];
+                    bool bad = false;
+                    fldr_split_hl_group(xs, h, l, bad);
+                    if (a.out_spk) fldr_note_range(bad);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ohi[r] = h[r]; olo[r] = l[r]; }
                 }
                 if (outn) {
                     const uint32_t off = ((uint32_t)co0 * HW32 + po[q]) * 4u;
@@ -700,7 +727,6 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             iter_close();
         }
     }
-    if (a.out_spk) fldr_note_range(range_bad);
 #ifdef RING_STAMPS
     RSTAMP(c_end)
     if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == 0 && lane == 0) {
@@ -859,7 +885,6 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
 #pragma unroll
     for (int r = 0; r < 16; ++r) bias_r[r] = reinterpret_cast<const float*>(smem + Cfg::BIAS_OFF)[(r & 3) + 8 * (r >> 2) + 4 * lh];
     const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
-    bool range_bad = false;
     auto finish_store = [&]() {
         const int t = spk_div(cur_u, a.m_groups, a.groups);
         const int n = spk_div(t, a.m_tiles, a.n_tiles);
@@ -869,16 +894,23 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
         const bool ok = oy < a.H && ox < a.W;
         unsigned char* spkn = a.out_spk + (int64_t)n * a.out_spk_bstride;
         const uint32_t pq = ok ? (uint32_t)(oy * a.W + ox) : 0u;
+        float abs_sum = 0.0f;                                             // (the range guard of the split: once per unit and wave)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[r] = fmaxf(acc[r] * inv_scale + bias_r[r], relu_floor);
+            abs_sum += fabsf(acc[r]);
+        }
+        const bool guard = fldr_guard_trips(abs_sum);
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {
             const int co0 = grp0 * 32 + 8 * (r0 >> 2) + 4 * lh;
             h4 ohi, olo;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float v = fmaxf(acc[r0 + r] * inv_scale + bias_r[r0 + r], relu_floor);
+                const float v = acc[r0 + r];
                 acc[r0 + r] = 0.0f;
                 _Float16 h, l;
-                spk_split(v, h, l, range_bad);
+                if (guard) { bool bad = false; spk_split(v, h, l, bad); fldr_note_range(bad); } else fldr_split_plain(v, h, l);
                 ohi[r] = h; olo[r] = l;
             }
             if (ok) {
@@ -923,7 +955,6 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
         if (++st_cur == SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
         ++g;
     }
-    fldr_note_range(range_bad);
 }
 
 static int g_ring_consumers = 8;

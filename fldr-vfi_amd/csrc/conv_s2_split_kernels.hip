@@ -188,7 +188,6 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             dst[2 * i] = v0; dst[2 * i + 1] = v1;
         }
     };
-    bool range_bad = false;
     auto store_inputs = [&](unsigned char* stage, const float (&src)[2 * S2_NI]) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2* hi = reinterpret_cast<h2*>(stage + Cfg::W_BYTES) + wave * CHS;
@@ -198,8 +197,14 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             if (l_dw[i] < 0) continue;
             const float x0 = src[2 * i], x1 = src[2 * i + 1];
             h2 h, l;                                                               // the guarded split of common.h
-            { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[0] = a_; l[0] = b_; }
-            { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[1] = a_; l[1] = b_; }
+            {
+                const float xs[2] = {x0, x1};
+                _Float16 hs[2], ls[2];
+                bool bad = false;
+                fldr_split_hl_group(xs, hs, ls, bad);
+                fldr_note_range(bad);
+                h[0] = hs[0]; h[1] = hs[1]; l[0] = ls[0]; l[1] = ls[1];
+            }
             hi[l_dw[i]] = h;                                                       // half 0 = the even row of the pair
             lo[l_dw[i]] = l;
         }
@@ -285,16 +290,29 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             }
             if (spkn) {
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                // the range guard of the split, decided once per block of NR values and wave (common.h: fldr_guard_trips)
+                float abs_sum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < NR; ++r) abs_sum += fabsf(vv[r]);
+                const bool guard = fldr_guard_trips(abs_sum);
 #pragma unroll
                 for (int r0 = 0; r0 < NR; r0 += 4) {
                     const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
                     h4 hi, lo;
+                    {
+                        float xs[4];
+                        _Float16 hs[4], ls[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                        _Float16 h_, l_;
-                        fldr_split_hl(x, h_, l_, range_bad);
-                        hi[r] = h_; lo[r] = l_;
+                        for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                        if (guard) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { hi[r] = hs[r]; lo[r] = ls[r]; }
                     }
                     if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                         unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -305,7 +323,6 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             }
         }
     }
-    fldr_note_range(range_bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -445,37 +462,61 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         dst[SETN - 2] = __uint_as_float(live ? iss_m0 : 0u); dst[SETN - 1] = __uint_as_float(live ? iss_m1 : 0u);
         if (++iss_c == n_chunks) { iss_c = 0; if (iss_k + 1 < my_tiles) { ++iss_k; issue_geometry(); } }      // (past the end: the last tile again)
     };
-    bool range_bad = false;
+    // One staging call splits up to 24 values per thread.  The range guard of the split is decided once per call and wave: pass 1 masks the
+    // values and sums their magnitudes, fldr_guard_trips (common.h) picks the guarded per-value split or the plain one for the whole call.
     auto store_inputs = [&](unsigned char* stage, const float (&src)[SETN]) __attribute__((always_inline)) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const unsigned m0 = __float_as_uint(src[SETN - 2]), m1 = __float_as_uint(src[SETN - 1]);
         h2* hi = reinterpret_cast<h2*>(stage) + wave * CHS;
         h2* lo = hi + KIND;
+        constexpr int PER = V4 ? 8 : 2;
+        float xs[NIT][PER];
+        float abs_sum = 0.0f;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
-            if (l_dw[i] < 0) continue;
             if constexpr (V4) {
-                // columns x = 4 q - 1 .. 4 q + 2 of the window: odd plane index 2 q - 1 (x = -1: the padding in front of the line),
-                // even 2 q, odd 2 q, even 2 q + 1 (x = 66: the padding behind it)
-                h2 h[4], l[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float x0 = ((m0 >> i) & 1u) ? src[8 * i + j] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[8 * i + 4 + j] : 0.0f;
-                    { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[j][0] = a_; l[j][0] = b_; }
-                    { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[j][1] = a_; l[j][1] = b_; }
+                    xs[i][2 * j] = ((m0 >> i) & 1u) ? src[8 * i + j] : 0.0f;
+                    xs[i][2 * j + 1] = ((m1 >> i) & 1u) ? src[8 * i + 4 + j] : 0.0f;
                 }
-                const int ev = l_dw[i], od = l_dw[i] + IWHP - 1;
-                hi[ev] = h[1]; hi[ev + 1] = h[3]; hi[od] = h[0]; hi[od + 1] = h[2];
-                lo[ev] = l[1]; lo[ev + 1] = l[3]; lo[od] = l[0]; lo[od + 1] = l[2];
             } else {
-                const float x0 = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f, x1 = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
-                h2 h, l;
-                { _Float16 a_, b_; fldr_split_hl(x0, a_, b_, range_bad); h[0] = a_; l[0] = b_; }
-                { _Float16 a_, b_; fldr_split_hl(x1, a_, b_, range_bad); h[1] = a_; l[1] = b_; }
-                hi[l_dw[i]] = h;
-                lo[l_dw[i]] = l;
+                xs[i][0] = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f;
+                xs[i][1] = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
+            }
+            if (l_dw[i] >= 0) {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) abs_sum += fabsf(xs[i][k]);
             }
         }
+        auto emit = [&](auto guardedc) __attribute__((always_inline)) {
+            constexpr bool GUARDED = decltype(guardedc)::value;
+#pragma unroll
+            for (int i = 0; i < NIT; ++i) {
+                if (l_dw[i] < 0) continue;
+                _Float16 hs[PER], ls[PER];
+#pragma unroll
+                for (int k = 0; k < PER; ++k) {
+                    if constexpr (GUARDED) { bool bad = false; fldr_split_hl(xs[i][k], hs[k], ls[k], bad); fldr_note_range(bad); } else fldr_split_plain(xs[i][k], hs[k], ls[k]);
+                }
+                if constexpr (V4) {
+                    // columns x = 4 q - 1 .. 4 q + 2 of the window: odd plane index 2 q - 1 (x = -1: the padding in front of the line),
+                    // even 2 q, odd 2 q, even 2 q + 1 (x = 66: the padding behind it)
+                    h2 h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { h[j][0] = hs[2 * j]; h[j][1] = hs[2 * j + 1]; l[j][0] = ls[2 * j]; l[j][1] = ls[2 * j + 1]; }
+                    const int ev = l_dw[i], od = l_dw[i] + IWHP - 1;
+                    hi[ev] = h[1]; hi[ev + 1] = h[3]; hi[od] = h[0]; hi[od + 1] = h[2];
+                    lo[ev] = l[1]; lo[ev + 1] = l[3]; lo[od] = l[0]; lo[od + 1] = l[2];
+                } else {
+                    h2 h, l;
+                    h[0] = hs[0]; h[1] = hs[1]; l[0] = ls[0]; l[1] = ls[1];
+                    hi[l_dw[i]] = h;
+                    lo[l_dw[i]] = l;
+                }
+            }
+        };
+        if (fldr_guard_trips(abs_sum)) emit(std::true_type{}); else emit(std::false_type{});
     };
 
     // ---- operand geometry (as above) ----
@@ -577,16 +618,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 }
                 if (spkn) {
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    // the range guard of the split, decided once per block of NR values and wave (common.h: fldr_guard_trips)
+                    float abs_sum = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) abs_sum += fabsf(vv[r]);
+                    const bool guard = fldr_guard_trips(abs_sum);
 #pragma unroll
                     for (int r0 = 0; r0 < NR; r0 += 4) {
                         const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
                         h4 hi, lo;
+                        {
+                            float xs[4];
+                            _Float16 hs[4], ls[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                            _Float16 h_, l_;
-                            fldr_split_hl(x, h_, l_, range_bad);
-                            hi[r] = h_; lo[r] = l_;
+                            for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                            if (guard) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { hi[r] = hs[r]; lo[r] = ls[r]; }
                         }
                         if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {     // every quad of a stored group: padding channels are written as zeros, never left uninitialised
                             unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -626,7 +680,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         if (cur_c == n_chunks - 1) { epilogue(); cur_c = 0; ++cur_k; } else ++cur_c;
         __syncthreads();
     }
-    fldr_note_range(range_bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -771,7 +824,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             const int co = MT == 32 ? m * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg : m * 16 + lg * 4 + r;
             bias_r[m][r] = a.bias ? a.bias[co < a.cout ? co : a.cout - 1] : 0.0f;
         }
-    bool range_bad = false;
     auto mfma_phase = [&](const unsigned char* xs, int ch) __attribute__((always_inline)) {
         const int* xin = reinterpret_cast<const int*>(xs);
         const unsigned char* win = wall + ch * Cfg::W_BYTES + lane * 16;
@@ -834,16 +886,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                 }
                 if (spkn) {
                     typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                    // the range guard of the split, decided once per block of NR values and wave (common.h: fldr_guard_trips)
+                    float abs_sum = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) abs_sum += fabsf(vv[r]);
+                    const bool guard = fldr_guard_trips(abs_sum);
 #pragma unroll
                     for (int r0 = 0; r0 < NR; r0 += 4) {
                         const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
                         h4 hi, lo;
+                        {
+                            float xs[4];
+                            _Float16 hs[4], ls[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                            _Float16 h_, l_;
-                            fldr_split_hl(x, h_, l_, range_bad);
-                            hi[r] = h_; lo[r] = l_;
+                            for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                            if (guard) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { hi[r] = hs[r]; lo[r] = ls[r]; }
                         }
                         if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {
                             unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -883,7 +948,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #endif
         __syncthreads();
     }
-    fldr_note_range(range_bad);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -997,7 +1061,6 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
     const float inv_scale = a.wpack[0];
     const int64_t HWo = (int64_t)a.Hout * a.Wout;
     int cur_k = 0, cur_g = 0;
-    bool range_bad = false;
     // Epilogue of tile k of this workgroup: scale, bias, ReLU, split, stores; clears acc.  (Emitting it in chunks between the next
     // iteration's MFMA micro-steps, on a copy of the accumulators, was built and measured SLOWER — enc2 73.6 vs 56.4 us with four loader
     // waves: the stores hold the wave's issue port and the matrix pipe starves behind them.)
@@ -1031,16 +1094,29 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
             }
             if (spkn) {
                 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                // the range guard of the split, decided once per block of 16 values and wave (common.h: fldr_guard_trips)
+                float abs_sum = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) abs_sum += fabsf(vv[r]);
+                const bool guard = fldr_guard_trips(abs_sum);
 #pragma unroll
                 for (int r0 = 0; r0 < 16; r0 += 4) {
                     const int co0 = 8 * (r0 >> 2) + 4 * lg;
                     h4 hi, lo;
+                    {
+                        float xs[4];
+                        _Float16 hs[4], ls[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float x = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
-                        _Float16 h_, l_;
-                        fldr_split_hl(x, h_, l_, range_bad);
-                        hi[r] = h_; lo[r] = l_;
+                        for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
+                        if (guard) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
+                        }
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) { hi[r] = hs[r]; lo[r] = ls[r]; }
                     }
                     if ((co0 >> 3) < ((a.cout_store + 7) >> 3) && pix_ok) {
                         unsigned char* q = spkn + ((int64_t)(co0 >> 3) * 2 * HWo + po) * 16 + ((co0 >> 2) & 1) * 8;
@@ -1117,7 +1193,6 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
         __syncthreads();
     }
     if (done_k >= 0) epilogue(done_k);
-    fldr_note_range(range_bad);
 }
 
 int fldr_range_read_s2(int reset) { return fldr_tu_range_read(reset); }

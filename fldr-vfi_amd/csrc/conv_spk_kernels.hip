@@ -433,8 +433,9 @@ __global__ void spk_pack_kernel(const float* __restrict__ src, int64_t src_bstri
     for (int k = 0; k < 8; ++k) x[k] = g * 8 + k < C ? s[(int64_t)k * HW] : 0.0f;
     h8 hi, lo;
     bool bad = false;
+    { _Float16 hs[8], ls[8]; fldr_split_hl_group(x, hs, ls, bad);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { _Float16 h, l; spk_split(x[k], h, l, bad); hi[k] = h; lo[k] = l; }
+      for (int k = 0; k < 8; ++k) { hi[k] = hs[k]; lo[k] = ls[k]; } }
     fldr_note_range(bad);
     unsigned char* d = dst + (int64_t)n * dst_bstride + ((int64_t)g * 2 * HW + pix) * 16;
     *reinterpret_cast<h8*>(d) = hi;

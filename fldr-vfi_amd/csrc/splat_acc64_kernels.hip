@@ -472,11 +472,14 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
                         const int gi = (cbase >> 3) + g8;
                         if (gi >= G) break;
                         sa_h8 hi, lo;
+                        {
+                            float xs[8];
+                            _Float16 hs[8], ls[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            _Float16 h_, l_;
-                            fldr_split_hl(o[g8 * 8 + k], h_, l_, bad);
-                            hi[k] = h_; lo[k] = l_;
+                            for (int k = 0; k < 8; ++k) xs[k] = o[g8 * 8 + k];
+                            fldr_split_hl_group(xs, hs, ls, bad);
+#pragma unroll
+                            for (int k = 0; k < 8; ++k) { hi[k] = hs[k]; lo[k] = ls[k]; }
                         }
                         unsigned char* d = sp + ((int64_t)gi * 2 * HW + pix) * 16;
                         *reinterpret_cast<sa_h8*>(d) = hi;

@@ -466,6 +466,7 @@ __device__ __forceinline__ void resize_spk_pixel(const float* __restrict__ in, f
     const int64_t HW = (int64_t)H * W, pix = (int64_t)Y * W + X;
     h8 hi, lo;
     bool bad = false;
+    float vs[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         float v = 0.0f;
@@ -476,9 +477,13 @@ __device__ __forceinline__ void resize_spk_pixel(const float* __restrict__ in, f
             v = (wy0 * top + ly * bot) * mul;
             out[((int64_t)n * C + c) * HW + pix] = v;
         }
-        _Float16 h_, l_;
-        fldr_split_hl(v, h_, l_, bad);
-        hi[c] = h_; lo[c] = l_;
+        vs[c] = v;
+    }
+    {
+        _Float16 hs[8], ls[8];
+        fldr_split_hl_group(vs, hs, ls, bad);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { hi[c] = hs[c]; lo[c] = ls[c]; }
     }
     fldr_note_range(bad);
     unsigned char* d = spk + ((int64_t)n * 2 * HW + pix) * 16;
