@@ -472,17 +472,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         constexpr int PER = V4 ? 8 : 2;
         float xs[NIT][PER];
         float abs_sum = 0.0f;
+        // rows outside the image are zeroed by per-item mask bits; a wave whose live items are all inside (every tile away from the
+        // borders) skips the selects (wave-uniform test)
+        unsigned need = 0u;                                                   // this thread's live items
+#pragma unroll
+        for (int i = 0; i < NIT; ++i) need |= l_dw[i] >= 0 ? (1u << i) : 0u;
+        const bool masked = __builtin_amdgcn_ballot_w64((m0 & m1 & need) != need) != 0ull;
 #pragma unroll
         for (int i = 0; i < NIT; ++i) {
             if constexpr (V4) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    xs[i][2 * j] = ((m0 >> i) & 1u) ? src[8 * i + j] : 0.0f;
-                    xs[i][2 * j + 1] = ((m1 >> i) & 1u) ? src[8 * i + 4 + j] : 0.0f;
+                    xs[i][2 * j] = (!masked || ((m0 >> i) & 1u)) ? src[8 * i + j] : 0.0f;
+                    xs[i][2 * j + 1] = (!masked || ((m1 >> i) & 1u)) ? src[8 * i + 4 + j] : 0.0f;
                 }
             } else {
-                xs[i][0] = ((m0 >> i) & 1u) ? src[2 * i] : 0.0f;
-                xs[i][1] = ((m1 >> i) & 1u) ? src[2 * i + 1] : 0.0f;
+                xs[i][0] = (!masked || ((m0 >> i) & 1u)) ? src[2 * i] : 0.0f;
+                xs[i][1] = (!masked || ((m1 >> i) & 1u)) ? src[2 * i + 1] : 0.0f;
             }
             if (l_dw[i] >= 0) {
 #pragma unroll
