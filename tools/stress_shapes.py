@@ -107,6 +107,27 @@ for it in range(40):
 hip.lib().fldr_debug_spk_small_units(96); hip.lib().fldr_debug_spk_variant(1); hip.lib().fldr_debug_ring_consumers(8); hip.lib().fldr_debug_ring_tile_width(0)
 bad += hip.lib().fldr_debug_ring_timeouts() != 0
 print("split-packed conv (3 pipelines) vs split conv: 40 shapes x 2 unit policies,", bad, "mismatches", flush=True)
+bad = 0
+for it in range(30):          # 32x32x16 ring kernel (64 / 96 outputs, packed output) vs the 16x16x32 ring: fp32 rounding apart, no ring timeouts
+    N = random.choice([1, 1, 2, 3]); cout = random.choice([64, 96])
+    cs = random.choice([[96], [48, 48, 4], [32, 32], [64, 32], [16], [40], [8, 8, 3]]); ups = [random.random() < 0.3 for _ in cs]
+    H = 2 * random.choice([2, 3, 5, 9, 17, 33, 65]); W = 2 * random.choice([2, 3, 6, 32, 33, 34, 65, 67, 129])
+    srcs = [torch.randn(N, c, H // (2 if u else 1), W // (2 if u else 1), device=dev) for c, u in zip(cs, ups)]
+    if any(c % 8 for c in cs[:-1]): continue
+    packed = [hip.spk_pack(x) for x in srcs]
+    wt = torch.randn(cout, sum(cs), 3, 3, device=dev) / (sum(cs) * 9) ** 0.5; b = torch.randn(cout, device=dev)
+    outs = []
+    hip.lib().fldr_debug_spk_small_units(-1)
+    for r32 in (0, 2):
+        hip.lib().fldr_debug_ring32(r32)
+        outs.append(hip.conv2d_spk(packed, wt, b, relu=bool(it & 1), up2=ups, want_f32=False, want_spk=True).float())
+    hip.lib().fldr_debug_ring32(1); hip.lib().fldr_debug_spk_small_units(96)
+    tol = 3e-6 * float(outs[0].abs().max()) + 1e-7
+    ok = (outs[0] - outs[1]).abs().max().item() <= tol
+    bad += not ok
+    if not ok: print("ring32 MISMATCH", N, cs, ups, cout, H, W, (outs[0] - outs[1]).abs().max().item(), tol)
+bad += hip.lib().fldr_debug_ring_timeouts() != 0
+print("32x32x16 ring conv vs 16x16x32 ring: 30 shapes,", bad, "mismatches", flush=True)
 
 # ---- one-pass PCA (incl. the 4-components-per-thread variant on small grids) vs the two-pass kernel ----
 bad = 0
