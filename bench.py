@@ -124,10 +124,28 @@ def dominant_conv_roofline(model, h, w, device, steps):
                                        "peak": PEAK_FP32_MFMA_TFLOPS, "frac": round(flops / (ms32 * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4)}}
 
 
+def _moved_bytes_per_forward():
+    """HBM-side bytes a warm 4K forward actually moves (sum of FETCH_SIZE x 2 + WRITE_SIZE over its launches) from the newest
+    committed forward profile (tools/prof_forward_pmc.sh + pmc_forward_summary.py); older summaries carry no total: summed here
+    without their one-time prepack / harness kernels."""
+    import re
+    skip = re.compile(r"prepack|absmax|at::native|__amd_rocclr|FillFunctor|direct_copy|elementwise_kernel")
+    for name in ("r05_forward_pmc.json", "r04_forward_pmc.json"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            mb = d.get("moved_MB_per_forward")
+            if mb is None:
+                mb = sum(k["fetch_x2_MB"] + k["write_MB"] for k in d["kernels"] if not skip.search(k["kernel"]))
+            return mb * 1e6, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over single-stream 3840x2160 forwards; not measured in this run)" % name
+        except Exception:
+            pass
+    return None, None
+
+
 def _measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate --pmc passes); newest round first."""
-    for name in ("r04_conv96_spk_traffic.json", "r03_conv96_spk_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
+    for name in ("r05_conv96_spk_traffic.json", "r04_conv96_spk_traffic.json", "r03_conv96_spk_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
             return v, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_round.sh; not measured in this run)" % name
@@ -149,11 +167,12 @@ def host_info():
     return dict(host_core_budget(), cpu_model=model)
 
 
-def cpu_baseline(frames_cpu, t_cpu, gpu_out=None):
+def cpu_baseline(frames_cpu, t_cpu, gpu_out=None, runs=3):
     """The oracle (CPU restatement of the reference, kind 'port') timed on this box's host cores on the SAME 4K pair:
-    1 warm-up + 3 timed forwards with every core this process may use, then 1 + 2 with 8 threads (the survey
-    container's count); pyramid excluded like the GPU number.  The warm-up's output doubles as
-    the full-size parity check of the GPU frame (PSNR of the rounded 8-bit frames, max abs error)."""
+    1 warm-up + `runs` timed forwards with every core this process may use (3 at one GPU; 1 on rank 0 of a multi-GPU
+    launch, whose other ranks have left by then), then 1 + 2 with 8 threads (the survey container's count; BASELINE.md
+    section 4; one-GPU runs only); pyramid excluded like the GPU number.  The warm-up's output doubles as the full-size
+    parity check of the GPU frame (PSNR of the rounded 8-bit frames, max abs error)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import fldr_oracle as O
@@ -174,13 +193,13 @@ def cpu_baseline(frames_cpu, t_cpu, gpu_out=None):
                 ts.append(time.time() - t0)
         return ts[1:], ref
 
-    ts, ref = run(cores, 3)
+    ts, ref = run(cores, runs)
     mean = sum(ts) / len(ts)
-    res = {"value": round(1.0 / mean, 5), "unit": "4K frame-pairs/s", "cores": cores, "kind": "port",
-           "sample": "oracle/fldr_oracle.py (torch-CPU) on the same %dx%d pair (seed 0, t=0.5): 1 warm-up + 3 timed forwards, "
-                     "%.2f / %.2f / %.2f s" % ((W, H) + tuple(ts)),
+    res = {"value": round(1.0 / mean, 5), "unit": "4K frame-pairs/s", "cores": cores, "kind": "port", "runs": runs,
+           "sample": "oracle/fldr_oracle.py (torch-CPU) on the same %dx%d pair (rank 0's first pair, t=0.5): 1 warm-up + %d timed forward(s), %s s"
+                     % (W, H, runs, " / ".join("%.2f" % x for x in ts)),
            "host": info}
-    if cores != 8:
+    if cores != 8 and runs >= 3:
         ts8, _ = run(min(8, cores), 2)
         res["at_8_threads"] = {"value": round(len(ts8) / sum(ts8), 5), "runs_s": [round(x, 2) for x in ts8]}
     parity = None
@@ -287,14 +306,17 @@ def main():
                             graph_outs[(s_i, k)] = Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k])
                         graphs[(s_i, k)] = g
                 torch.cuda.synchronize()
-                # one replay against one eager forward: the same bits, or no graphs
-                with torch.cuda.stream(streams[0]), torch.no_grad():
-                    ref = Hn.interpolate(model, args, frames[0], t, pyramid=pyrs[0]).clone()
-                    graphs[(0, 0)].replay()
-                torch.cuda.synchronize()
-                if not torch.equal(ref, graph_outs[(0, 0)]):
-                    raise RuntimeError("replayed frame differs from the eager frame")
-                graph_state.update(on=True, why="%d graphs (streams x pairs), replay == eager bit for bit" % len(graphs))
+                # EVERY captured graph replayed once (untimed) against an eager forward of its pair on its stream: the same bits, or no
+                # graphs at all (a capture that baked in another stream's workspace or a stale pointer would otherwise be timed unnoticed)
+                for (s_i, k), g in graphs.items():
+                    with torch.cuda.stream(streams[s_i]), torch.no_grad():
+                        ref = Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k]).clone()
+                        g.replay()
+                    torch.cuda.synchronize()
+                    if not torch.equal(ref, graph_outs[(s_i, k)]):
+                        raise RuntimeError("replayed frame of graph (stream %d, pair %d) differs from the eager frame" % (s_i, k))
+                    del ref
+                graph_state.update(on=True, why="%d graphs (streams x pairs), every one replayed once and == its eager frame bit for bit" % len(graphs))
             except Exception as e:                                   # eager steps still work
                 graphs.clear(); graph_outs.clear()
                 graph_state.update(on=False, why="capture failed: %r" % (e,))
@@ -367,6 +389,23 @@ def main():
         barrier()
         graph_state["eager_ms_per_step"] = round((time.perf_counter() - t1) / n_e * 1e3, 3)
         graph_state["eager_host_enqueue_ms_per_step"] = round(t_host / n_e * 1e3, 3)
+    if gpu:                                            # every rank: a finite frame, no activation outside the fp16 split's range
+        import fldr_hip
+        assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
+        fldr_hip.check_range()
+    per_rank = gather_floats(a.steps / dt_local, device)
+    x_test = None
+    if gpu and a.xtest_dir:                            # BASELINE metric, second half: PSNR on X-Test when the data is there (every rank: collective)
+        x_test = Hn.evaluate_dir(a.xtest_dir, multiple=a.xtest_multiple, model=model, args=args, device=device, rank=rank, world=world)
+    pg_world = dist.get_world_size() if use_pg else 1
+    if use_pg:
+        # Every collective of the run is behind us: release the other ranks NOW.  What follows on rank 0 (informational legs, roofline
+        # of the dominant kernel, the CPU baseline: ~1 min) involves no other rank, so none of them waits in a barrier that a slow or
+        # stuck leg would turn into a collective timeout over there.
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank != 0:
+        return
     if gpu:
         # end-to-end on the device (informational, single stream): uint8 frames -> ingest kernels (normalise, reflect
         # pad, bicubic pyramid) -> forward -> rounded uint8 frame (fldr_frame_metrics)
@@ -379,9 +418,6 @@ def main():
             Hn.interpolate_u8(model, args, u8, t)
         sync()
         dt_e2e = (time.perf_counter() - t1) / max(1, a.steps // 4)
-        assert out.shape[-2:] == (a.height, a.width) and torch.isfinite(out).all()
-        import fldr_hip
-        fldr_hip.check_range()                         # no activation left the range of the fp16 hi/lo split (would raise)
         # BASELINE config 5 (informational; never `value`): the same loop with plain fp16 convolution inputs (one MFMA per
         # product instead of three; ~74 dB against the fp32-class frame, tests/test_gpu_parity.py::test_fp16_conv_path_config5)
         # Informational (never `value`): the same loop on pairs under a smoothly varying motion (zoom + rotation + shift,
@@ -482,11 +518,6 @@ def main():
                              "pairs_per_s_this_gpu": round(a.fp16_mode_steps / d5, 2)}
             finally:
                 fldr_hip.CONV_PRECISION = prev
-    per_rank = gather_floats(a.steps / dt_local, device)
-    x_test = None
-    if gpu and a.xtest_dir:                            # BASELINE metric, second half: PSNR on X-Test when the data is there (every rank: collective)
-        x_test = Hn.evaluate_dir(a.xtest_dir, multiple=a.xtest_multiple, model=model, args=args, device=device, rank=rank, world=world)
-
     if rank == 0:
         hp = ((a.height + 255) // 256 * 256, (a.width + 255) // 256 * 256)
         res = {
@@ -505,11 +536,16 @@ def main():
         if gpu:
             res["config"]["hip_graphs"] = dict(graph_state)
         if use_pg:
-            res["config"]["process_group"] = {"backend": pg_backend + (" (RCCL)" if pg_backend == "nccl" else ""), "world_size": dist.get_world_size(),
+            res["config"]["process_group"] = {"backend": pg_backend + (" (RCCL)" if pg_backend == "nccl" else ""), "world_size": pg_world,
                                               "forced_at_world_size_1": world == 1}
         if a.dry:
             res["dry"] = True
             res["data"] = "none (dry run: 1 ms sleep per step)"
+            if not a.no_cpu_baseline:                  # the leg itself runs in a dry launch too (rank 0, any world size), on a small pair
+                import fldr_harness as Hn
+                fr = Hn.frames_from_uint8(Hn.synthetic_pair(256, 256, seed=0))
+                res["cpu_baseline"], _ = cpu_baseline(fr, torch.tensor([[0.5]]), None, runs=1)
+                res["cpu_baseline"]["unit"] = "256x256 frame-pairs/s (dry run)"
         if gpu:
             res["config"].update({"pyramid_bytes_per_pair": pyr_bytes, "single_stream_latency_ms": round(latency_ms, 3), "single_stream_latency_eager_ms": round(latency_eager_ms, 3),
                                   "ms_uint8_in_to_uint8_out_single_stream": round(dt_e2e * 1e3, 3)})
@@ -536,17 +572,19 @@ def main():
                     "ms_per_step": round(ms_step, 3), "frac": round(max(floor_hbm, floor_mfma) / ms_step, 4),
                     "frac_single_stream": round(max(floor_hbm, floor_mfma) / latency_ms, 4),
                     "achieved_GBps": round(pm["hbm_bytes"] / (ms_step * 1e-3) / 1e9, 1)}
-            if world == 1 and not a.no_cpu_baseline:
+                if (a.height, a.width) == (H4K, W4K):
+                    mv, mv_src = _moved_bytes_per_forward()
+                    if mv:
+                        res["roofline"]["path"].update({"moved_bytes_per_forward": mv, "moved_over_algorithmic": round(mv / pm["hbm_bytes"], 3),
+                                                        "moved_bytes_source": mv_src})
+            if not a.no_cpu_baseline:                  # rank 0, any world size (3 timed forwards at one GPU, 1 beyond: `runs`)
                 with torch.no_grad():
                     g0 = Hn.interpolate(model, args, frames[0], t, pyramid=pyrs[0]).cpu()
-                res["cpu_baseline"], res["parity"] = cpu_baseline(frames[0].cpu(), t.cpu(), g0)
+                res["cpu_baseline"], res["parity"] = cpu_baseline(frames[0].cpu(), t.cpu(), g0, runs=3 if world == 1 else 1)
             if x_test is not None:
                 res["x_test"] = dict(x_test, dir=a.xtest_dir, multiple=a.xtest_multiple)
                 res.setdefault("parity", {})["x_test_psnr"] = x_test["psnr"]
         print(json.dumps(res), flush=True)
-    if use_pg:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -10,7 +10,8 @@
 // the test suite through fldr_hip.test_hooks()).  The product library exports the integration ABI of include/fldr_hip.h and
 // nothing else; in it the hook functions are file-local and unused, so the state they would change stays at its default.
 #ifdef FLDR_TEST_HOOKS
-#define FLDR_HOOK extern "C"
+#include "fldr_hip_test_hooks.h"             // the declarations carry the visibility of the test build's extra exports
+#define FLDR_HOOK extern "C" FLDR_API
 #else
 #define FLDR_HOOK __attribute__((unused)) static
 #endif
@@ -102,7 +103,7 @@ __device__ __forceinline__ void fldr_note_range(bool bad) { if (bad) fldr_tu_ran
 static inline int fldr_tu_range_read(int reset) {
     int v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_tu_range_flag), sizeof(int)) != hipSuccess) return -1;
-    if (v && reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(fldr_tu_range_flag), &z, sizeof(int)); }
+    if (v && reset) { const int z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(fldr_tu_range_flag), &z, sizeof(int)) != hipSuccess) return -1; }
     return v;
 }
 // translation units that split: each exports its flag through one of these (aggregated by fldr_range_status)
@@ -114,7 +115,7 @@ int fldr_range_read_split(int reset);
 int fldr_range_read_warp(int reset);
 int fldr_range_read_gather(int reset);
 int fldr_range_read_acc64(int reset);
-int fldr_ring_timeouts_read(int reset);             // conv_ring_kernels.hip: expired ring waits (fldr_range_status bit 1)
+int fldr_ring_timeouts_read(int reset);             // conv_ring_kernels.hip: expired ring waits (fldr_ring_status)
 
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
 // the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.

@@ -80,7 +80,7 @@ int fldr_range_read_ring(int reset) { return fldr_tu_range_read(reset); }
 int fldr_ring_timeouts_read(int reset) {
     int v = -1;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_ring_timeouts), sizeof(int)) != hipSuccess) return -1;
-    if (v > 0 && reset) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(fldr_ring_timeouts), &z, sizeof(int)); }
+    if (v > 0 && reset) { const int z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(fldr_ring_timeouts), &z, sizeof(int)) != hipSuccess) return -1; }
     return v;
 }
 

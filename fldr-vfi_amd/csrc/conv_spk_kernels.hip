@@ -456,20 +456,20 @@ __global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t
 
 int fldr_range_read_spk(int reset) { return fldr_tu_range_read(reset); }
 
-// Sticky status of the split-precision convolutions on the current device since the last reset; negative on a HIP error.
-//   bit 0 (FLDR_STATUS_RANGE): a value beyond +-65504 (or a NaN) was split — and saturated (common.h: fldr_split_hl);
-//   bit 1 (FLDR_STATUS_RING_TIMEOUT): a bounded wait of the loader / consumer ring expired (conv_ring_kernels.hip): the wave
-//          ran on with operands that had not landed — the output of that convolution is not to be trusted.
-// Synchronises.
+// Sticky range status of the split-precision convolutions on the current device since the last reset: 1 = a value beyond +-65504
+// (or a NaN) was split — and saturated (common.h: fldr_split_hl) —, 0 = clean, negative on a HIP error.  Synchronises.
 extern "C" int fldr_range_status(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     int v = 0;
     int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather, fldr_range_read_acc64};
-    for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x ? FLDR_STATUS_RANGE : 0; }
-    const int to = fldr_ring_timeouts_read(reset);
-    if (to < 0) return to;
-    if (to > 0) v |= FLDR_STATUS_RING_TIMEOUT;
+    for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x ? 1 : 0; }
     return v;
+}
+// Expired waits of the loader / consumer ring (conv_ring_kernels.hip) since the last reset; its own entry point so that a caller
+// testing fldr_range_status() != 0 never mistakes a library fault for out-of-range data.  Synchronises.
+extern "C" int fldr_ring_status(int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return fldr_ring_timeouts_read(reset);
 }
 
 // sizeof of the descriptor structs as this library was compiled (binding self-check: tests/test_host_cpu.py)

@@ -161,6 +161,7 @@ _SIGNATURES = {
     "fldr_conv2d_spk_levels": (ctypes.c_int, [ctypes.POINTER(SpkConvDesc), ctypes.c_int, ctypes.c_void_p]),
     "fldr_debug_spk_wgs_per_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_range_status": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_ring_status": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_small_units": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_spk_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_consumers": (ctypes.c_int, [ctypes.c_int]),
@@ -196,7 +197,13 @@ _TEST_BUILD_ONLY = ("fldr_softsplat_tile", "fldr_softsplat_tile_strided", "fldr_
 EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_") and n not in _TEST_BUILD_ONLY)
 HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_") or n in _TEST_BUILD_ONLY)
 TEST_LIB_PATH = os.path.join(_HERE, "libfldr_hip_test.so")
-ABI_VERSION = 102                # include/fldr_hip.h: FLDR_VERSION
+ABI_VERSION = 103                # include/fldr_hip.h: FLDR_VERSION
+# entry points the DEFAULT 4K forward / bench / harness call: a variant library (FLDR_LIB) that lacks one of them fails at load
+_DEFAULT_PATH = ("fldr_version", "fldr_error_string", "fldr_sizeof_desc", "fldr_range_status", "fldr_ring_status", "fldr_pca_prepack",
+                 "fldr_pca_project_pyramid", "fldr_conv2d_spk", "fldr_conv2d_spk_levels", "fldr_conv_spk_prepack", "fldr_conv2d_s2_split",
+                 "fldr_conv2d_s2_spk", "fldr_conv2d_s2_spk_pair", "fldr_conv_s2_prepack", "fldr_softsplat_acc64", "fldr_level0_prep",
+                 "fldr_splat_bounds_upsampled_pair", "fldr_resize_bilinear_spk", "fldr_resize_bilinear_spk_bounds", "fldr_dec3_prepack_spk",
+                 "fldr_dec3_synth_spk", "fldr_spk_pack")
 _lib = None
 _hooks_lib = None
 
@@ -206,24 +213,34 @@ def _load(path, want_hooks):
         raise ImportError("%s is missing — build it with `make -C fldr-vfi_amd/csrc` (or `python -c 'import __graft_entry__ as g; "
                           "g.build()'`). There is no CPU/eager fallback." % path)
     l = ctypes.CDLL(path)
+    variant = bool(os.environ.get("FLDR_LIB"))           # an experimental / older build selected for an A/B measurement
+    missing = []
     for name, (res, args) in _SIGNATURES.items():
         try:
             fn = getattr(l, name)
         except AttributeError:
-            # hooks exist in the test build only; an experimental / older build selected with FLDR_LIB may lack newer entry points
-            if (name in HOOKS and not want_hooks) or os.environ.get("FLDR_LIB"):
+            # hooks exist in the test build only; a variant build may lack newer entry points — but never one the default path calls
+            if name in HOOKS and (not want_hooks or variant):
                 continue
-            raise
+            if variant and name not in _DEFAULT_PATH:
+                missing.append(name)
+                continue
+            raise ImportError("%s does not export %s, which the default forward calls: rebuild it" % (path, name))
         fn.restype = res
         fn.argtypes = args
-    # binding self-check: this file's struct mirrors against the structs the library was compiled with (fldr_sizeof_desc), and the
-    # ABI version it was written for — a stale .so next to a newer binding (or the reverse) fails here instead of corrupting memory
-    if not os.environ.get("FLDR_LIB"):
-        if l.fldr_version() != ABI_VERSION:
-            raise ImportError("%s reports ABI version %d, this binding is written for %d: rebuild it" % (path, l.fldr_version(), ABI_VERSION))
-        for which, cls in enumerate((ConvDesc, SpkConvDesc, PrepDesc, PcaLevel, SplatAccDesc, SplatGatherDesc)):
-            if l.fldr_sizeof_desc(which) != ctypes.sizeof(cls):
-                raise ImportError("%s: sizeof(%s) is %d in the library, %d in this binding" % (path, cls.__name__, l.fldr_sizeof_desc(which), ctypes.sizeof(cls)))
+    # binding self-check, ALWAYS: this file's struct mirrors against the structs the library was compiled with (fldr_sizeof_desc exists
+    # in every build since ABI 102) — a stale .so next to a newer binding (or the reverse) fails here instead of corrupting memory.
+    # An index the library does not know yet (FLDR_E_ARG) is tolerated for variant builds only.
+    for which, cls in enumerate((ConvDesc, SpkConvDesc, PrepDesc, PcaLevel, SplatAccDesc, SplatGatherDesc)):
+        got = l.fldr_sizeof_desc(which)
+        if got != ctypes.sizeof(cls) and not (variant and got < 0):
+            raise ImportError("%s: sizeof(%s) is %d in the library, %d in this binding" % (path, cls.__name__, got, ctypes.sizeof(cls)))
+    if l.fldr_version() != ABI_VERSION:
+        msg = "%s reports ABI version %d, this binding is written for %d" % (path, l.fldr_version(), ABI_VERSION)
+        if not variant:
+            raise ImportError(msg + ": rebuild it")
+        import warnings
+        warnings.warn(msg + " (FLDR_LIB variant: struct sizes agree, continuing)" + (("; missing entry points: " + ", ".join(missing)) if missing else ""))
     return l
 
 
@@ -876,12 +893,16 @@ STATUS_RANGE, STATUS_RING_TIMEOUT = 1, 2
 
 
 def device_status(reset=True):
-    """fldr_range_status: bit 0 (STATUS_RANGE) an activation was saturated by the fp16 split, bit 1 (STATUS_RING_TIMEOUT) a bounded
-    wait of the convolution ring expired (that convolution's output is not to be trusted).  Synchronises the device."""
-    v = lib().fldr_range_status(int(bool(reset)))
-    if v < 0:
-        raise FldrError("fldr_range_status failed (%d)" % v)
-    return v
+    """Bit 0 (STATUS_RANGE): fldr_range_status — an activation was saturated by the fp16 split; bit 1 (STATUS_RING_TIMEOUT):
+    fldr_ring_status — a bounded wait of the convolution ring expired (that convolution's output is not to be trusted).  Two entry
+    points of the C ABI (a data problem and a library fault have different remedies); synchronises the device."""
+    r = lib().fldr_range_status(int(bool(reset)))
+    if r < 0:
+        raise FldrError("fldr_range_status failed (%d)" % r)
+    to = lib().fldr_ring_status(int(bool(reset)))
+    if to < 0:
+        raise FldrError("fldr_ring_status failed (%d)" % to)
+    return (STATUS_RANGE if r else 0) | (STATUS_RING_TIMEOUT if to else 0)
 
 
 def check_range():

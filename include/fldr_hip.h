@@ -22,16 +22,20 @@
 extern "C" {
 #endif
 
-#define FLDR_VERSION 102          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_range_status bits,
-                                     fldr_sizeof_desc(3..5) — a caller built against an older header must be rebuilt */
+#define FLDR_VERSION 103          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_sizeof_desc(3..5);
+                                     103: fldr_range_status is 0 / 1 again, the ring status has its own entry (fldr_ring_status),
+                                     fldr_enc1_fused — a caller built against an older header must be rebuilt */
 
 #define FLDR_E_ARG   (-1)         /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define FLDR_E_SHAPE (-2)         /* shape constraint violated (e.g. H,W not multiples of 8 for the PCA) */
 
+/* The product library is built with -fvisibility=hidden: the functions below are its whole dynamic symbol table. */
+#define FLDR_API __attribute__((visibility("default")))
+
 typedef void* fldr_stream_t;      /* hipStream_t; torch.cuda.current_stream().cuda_stream */
 
-int         fldr_version(void);
-const char* fldr_error_string(int code);
+FLDR_API int         fldr_version(void);
+FLDR_API const char* fldr_error_string(int code);
 
 /* ------------------------------------------------------------------------------------------
  * Softmax splatting — replaces softSplat.py.
@@ -41,7 +45,7 @@ const char* fldr_error_string(int code);
  * (softSplat.py:222-258): out[n,c,y',x'] += in[n,c,y,x] * bilinear weight of (x+fx, y+fy).
  * `out_zeroed` must be zero on entry (the reference allocates it with new_zeros, :234).
  * flow is [N,2,H,W], channel 0 = x displacement, 1 = y displacement, in pixels. */
-int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
+FLDR_API int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
                        int N, int C, int H, int W, fldr_stream_t stream);
 
 /* FunctionSoftsplat (softSplat.py:320-352) end to end.  mode: 0 summation, 1 average, 2 linear,
@@ -49,14 +53,14 @@ int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
  * scratch: N*(C+1)*H*W floats (the (C+1)-channel accumulator); contents are overwritten.
  * out: [N,C,H,W].  Includes the reference's pre-scale (x+1)/2 (softmax only, :334), the
  * zero-norm -> 1 rule (:346) and the post-scale (x-0.5)*2 (every mode, :349). */
-int fldr_softsplat_fused(const float* img, const float* flow, const float* metric_or_null,
+FLDR_API int fldr_softsplat_fused(const float* img, const float* flow, const float* metric_or_null,
                          float* out, float* scratch, int N, int C, int H, int W, int mode,
                          fldr_stream_t stream);
 
 /* The two feature splats of a pyramid level (fLDRnet.py:386-387; one sample each, no metric; mode 0, 1 or 3) with one memset
  * and one normalisation launch: scratch = 2 * (C + 1) * H * W floats, out_spk = packed batch of two (sample 0 = problem a).
  * Identical results to two fldr_softsplat_fused_spk calls. */
-int fldr_softsplat_pair_spk(const float* img_a, const float* flow_a, const float* img_b, const float* flow_b, void* out_spk,
+FLDR_API int fldr_softsplat_pair_spk(const float* img_a, const float* flow_a, const float* img_b, const float* flow_b, void* out_spk,
                             float* scratch, int C, int H, int W, int mode, fldr_stream_t stream);
 
 /* FunctionSoftsplat of FEATURE MAPS as a deterministic gather (no atomics, no accumulator, no memset, no separate
@@ -76,8 +80,8 @@ typedef struct fldr_splat_gather_desc {
     float*       ws;
     int32_t      ndir, N, C, H, W, mode;
 } fldr_splat_gather_desc;
-int64_t fldr_softsplat_gather_ws_floats(int ndir, int N, int H, int W);
-int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stream);
+FLDR_API int64_t fldr_softsplat_gather_ws_floats(int ndir, int N, int H, int W);
+FLDR_API int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stream);
 
 /* FunctionSoftsplat (softSplat.py:320-352) with destination-owned tiles and fp64 LDS atomics (csrc/splat_acc64_kernels.hip):
  * every workgroup owns an output tile as fp64 accumulators in LDS, the sources that can reach it (flow-bounds tables, as for
@@ -95,7 +99,7 @@ int fldr_softsplat_gather(const fldr_splat_gather_desc* desc, fldr_stream_t stre
  * up((1 - t) * flow_10) * mul, fLDRnet.py:404-405; pair 2 = the feature splats, problem 0: up(flow_10) * mul, problem 1:
  * up(flow_01) * mul, :384-387).  flow_l [N,4,h,w], samples lo_bstride floats apart (0 = 4*h*w); ws: 2 *
  * fldr_softsplat_tile_ws_floats(N,H,W) floats. */
-int fldr_splat_bounds_upsampled_pair(const float* flow_l, int64_t lo_bstride, const float* t, int pair, float mul, float* ws,
+FLDR_API int fldr_splat_bounds_upsampled_pair(const float* flow_l, int64_t lo_bstride, const float* t, int pair, float mul, float* ws,
                                      int N, int h, int w, int H, int W, fldr_stream_t stream);
 typedef struct fldr_splat_acc_desc {
     const float* img[2];
@@ -108,18 +112,18 @@ typedef struct fldr_splat_acc_desc {
     void*        out_spk[2];
     int32_t      nprob, N, C, H, W, mode, flags, reserved;
 } fldr_splat_acc_desc;
-int fldr_softsplat_acc64(const fldr_splat_acc_desc* desc, fldr_stream_t stream);
+FLDR_API int fldr_softsplat_acc64(const fldr_splat_acc_desc* desc, fldr_stream_t stream);
 
 /* fldr_softsplat_fused with the result in the split-packed layout of the convolution section (fldr_spk_bytes(C,H,W) bytes
  * per sample) instead of fp32 NCHW: the warped feature maps of fLDRnet.py:386-387 are read by conv_flow1 only. */
-int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric_or_null, void* out_spk,
+FLDR_API int fldr_softsplat_fused_spk(const float* img, const float* flow, const float* metric_or_null, void* out_spk,
                              float* scratch, int N, int C, int H, int W, int mode, fldr_stream_t stream);
 
 /* Floats of ONE flow-bounds table (intervals of the flow per 64x4 block and 256x64 super-block: what selects a destination tile's
  * candidate sources) for N samples of an H x W map: the workspace unit of fldr_splat_bounds_upsampled[_pair] / fldr_softsplat_acc64.
  * (The destination-owned splats of rounds 1-2 that shared these tables — fldr_softsplat_tile* — live in the test build only since
  * round 4: include/fldr_hip_test_hooks.h.) */
-int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W);
+FLDR_API int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W);
 
 /* The level-0 image splats (fLDRnet.py:449-450) take flows that are bilinear upsamplings of a low-resolution field
  * (flow_t = F.interpolate(scale * flow_lo, (H, W)) * mul, fLDRnet.py:404-405,419-422).  Their bounds table follows from the
@@ -129,7 +133,7 @@ int64_t fldr_softsplat_tile_ws_floats(int N, int H, int W);
  *                                flow_lo + n*lo_bstride, [2,h,w] contiguous; scale_mode 0: 1, 1: t[n], 2: 1 - t[n];
  * Any table whose block / super-block intervals contain the flow values of their pixels gives the exact result (the table only
  * selects candidate sources). */
-int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstride, const float* t_or_null, int scale_mode, float mul,
+FLDR_API int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstride, const float* t_or_null, int scale_mode, float mul,
                                 float* ws, int N, int h, int w, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -140,7 +144,7 @@ int fldr_splat_bounds_upsampled(const float* flow_lo, int64_t lo_bstride, const 
  * out[n,(dy+4)*9+(dx+4),y,x] = (1/C) sum_c a[n,c,y,x] * b[n,c,y+dy,x+dx], zero padded, dy,dx in [-4,4].
  * a, b: [N,C,H,W]; out: [N,81,H,W].  No rearranged NHWC copies are needed (the reference's
  * rbot0/rbot1, :297-298, exist only for its one-block-per-pixel kernel). */
-int fldr_correlation_fwd(const float* a, const float* b, float* out,
+FLDR_API int fldr_correlation_fwd(const float* a, const float* b, float* out,
                          int N, int C, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -149,12 +153,12 @@ int fldr_correlation_fwd(const float* a, const float* b, float* out,
 
 /* _FunctionSoftsplat.backward (softSplat.py:259-318; kernels :54-158): gradients of fldr_softsplat_fwd with respect to its
  * input ([N,C,H,W]) and flow ([N,2,H,W]); either output may be NULL.  One pass produces both. */
-int fldr_softsplat_bwd(const float* in, const float* flow, const float* grad_out, float* grad_in_or_null,
+FLDR_API int fldr_softsplat_bwd(const float* in, const float* flow, const float* grad_out, float* grad_in_or_null,
                        float* grad_flow_or_null, int N, int C, int H, int W, fldr_stream_t stream);
 
 /* _FunctionCorrelation.backward (correlation.py:350-410; kernels :114-242): gradients of fldr_correlation_fwd with respect
  * to first / second ([N,C,H,W]); grad_out [N,81,H,W]; either output may be NULL. */
-int fldr_correlation_bwd(const float* first, const float* second, const float* grad_out, float* grad_first_or_null,
+FLDR_API int fldr_correlation_bwd(const float* first, const float* second, const float* grad_out, float* grad_first_or_null,
                          float* grad_second_or_null, int N, int C, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -167,14 +171,14 @@ int fldr_correlation_bwd(const float* first, const float* second, const float* g
  * out_f32: [P*K,H/8,W/8] (the caller's .float() of fLDRnet.py:146); out_f64_or_null: same shape in
  * fp64 (the function's own return value) when wanted.  minmax_ws: 2 doubles of workspace; on
  * completion it holds {min, max}.  H and W must be multiples of 8 (pca_comp.py:486-487). */
-int fldr_pca_project(const float* planes, const double* ev, const double* mean, const double* meanvec,
+FLDR_API int fldr_pca_project(const float* planes, const double* ev, const double* mean, const double* meanvec,
                      float* out_f32, double* out_f64_or_null, double* minmax_ws,
                      int P, int K, int H, int W, fldr_stream_t stream);
 
 /* The same projection with ONE pass over the planes: the raw fp64 projections are parked in out_f64 (required) and
  * rescaled in place by a streaming kernel that also emits the fp32 cast and, when out_spk is given, its split-packed
  * twin (fldr_spk_bytes(P*K, H/8, W/8) bytes; see the convolution section).  Identical results. */
-int fldr_pca_project_stream(const float* planes, const double* ev, const double* mean, const double* meanvec,
+FLDR_API int fldr_pca_project_stream(const float* planes, const double* ev, const double* mean, const double* meanvec,
                             float* out_f32_or_null, double* out_f64, void* out_spk_or_null, double* minmax_ws,
                             int P, int K, int H, int W, fldr_stream_t stream);
 
@@ -195,9 +199,9 @@ typedef struct fldr_pca_level {
                                   un-normalised projections there and the second rescales them instead of reading the planes again and
                                   recomputing (worth it on the big levels: 128 bytes per block instead of 256 + 64 K fp64 FMAs); same bits */
 } fldr_pca_level;
-int64_t fldr_pca_table_size(int K);
-int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K, fldr_stream_t stream);
-int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K, double* minmax_ws,
+FLDR_API int64_t fldr_pca_table_size(int K);
+FLDR_API int fldr_pca_prepack(const double* ev, const double* mean, const double* meanvec, double* table, int K, fldr_stream_t stream);
+FLDR_API int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const double* table, int K, double* minmax_ws,
                              fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
@@ -207,30 +211,30 @@ int fldr_pca_project_pyramid(const fldr_pca_level* levels, int n_levels, const d
 /* DCTVFInet.bwarp (fLDRnet.py:546-581): grid = pixel + flo, normalised with 2v/max(S-1,1)-1,
  * F.grid_sample(bilinear, zeros, align_corners=False), times the {0,1} validity mask when
  * withmask != 0 (mask = sampled ones, <0.999 -> 0, else 1).  No grid/ones tensors are built. */
-int fldr_bwarp(const float* x, const float* flo, float* out,
+FLDR_API int fldr_bwarp(const float* x, const float* flo, float* out,
                int N, int C, int H, int W, int withmask, fldr_stream_t stream);
 
 /* flowback of fLDRnet.py:474-475: bwarp(sx*x, sf*flo) with per-sample scales chosen by x_mode / flo_mode
  * (0: 1, 1: t[n], 2: 1-t[n]); t is a device array of N floats.  The scaled tensors are never materialised. */
-int fldr_bwarp_tscaled(const float* x, const float* flo, float* out, const float* t, int x_mode, int flo_mode,
+FLDR_API int fldr_bwarp_tscaled(const float* x, const float* flo, float* out, const float* t, int x_mode, int flo_mode,
                        int N, int C, int H, int W, int withmask, fldr_stream_t stream);
 
 /* F.interpolate(mode='bilinear', align_corners=False) from [NC,h,w] to [NC,H,W], result multiplied
  * by `mul` (fLDRnet.py:384-385 with mul = W/w; :419-422 with mul = upscale). */
 /* fldr_resize_bilinear for [N,C,h,w] with C <= 8 that also writes the split-packed twin of the result (one group). */
-int fldr_resize_bilinear_spk(const float* in, float* out, void* out_spk, int N, int C, int h, int w, int H, int W, float mul,
+FLDR_API int fldr_resize_bilinear_spk(const float* in, float* out, void* out_spk, int N, int C, int h, int w, int H, int W, float mul,
                              fldr_stream_t stream);
-int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int H, int W, float mul,
+FLDR_API int fldr_resize_bilinear(const float* in, float* out, int NC, int h, int w, int H, int W, float mul,
                          fldr_stream_t stream);
 /* fldr_resize_bilinear_spk of a [N,4,h,w] level flow AND fldr_splat_bounds_upsampled_pair(pair 2) of the same flow in one launch
  * (fLDRnet.py:384-387: the upsampled flow and the tables of the two feature splats that follow); both results bit-identical to the
  * two calls.  ws: 2 * fldr_softsplat_tile_ws_floats(N, H, W) floats.  Needs W < 4 w (FLDR_E_SHAPE otherwise: use the two calls). */
-int fldr_resize_bilinear_spk_bounds(const float* in, float* out, void* out_spk, float* ws, int N, int h, int w, int H, int W, float mul,
+FLDR_API int fldr_resize_bilinear_spk_bounds(const float* in, float* out, void* out_spk, float* ws, int N, int h, int w, int H, int W, float mul,
                                     fldr_stream_t stream);
 
 /* Splat metric of fLDRnet.py:442-446: z[n,0,y,x] = mean_c( alpha * |self[n,c,y,x] - bwarp(other, flow)[n,c,y,x]| ).
  * self/other: [N,C,H,W]; flow [N,2,H,W]; z [N,1,H,W]. */
-int fldr_zmetric(const float* self_img, const float* other_img, const float* flow, float alpha, float* z,
+FLDR_API int fldr_zmetric(const float* self_img, const float* other_img, const float* flow, float alpha, float* z,
                  int N, int C, int H, int W, fldr_stream_t stream);
 
 /* Everything of fLDRnet.py:400-479 between the level-0 flow and the UNet input that is not a splat, in one pass over the
@@ -257,7 +261,7 @@ typedef struct fldr_prep_desc {
                                         the consumer of those planes (enc1) can run right behind their producer */
     int32_t reserved;
 } fldr_prep_desc;
-int fldr_level0_prep(const fldr_prep_desc* desc, fldr_stream_t stream);
+FLDR_API int fldr_level0_prep(const fldr_prep_desc* desc, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Convolutions — replace the nn.Conv2d stacks of fLDRnet.py (:44-49, :318-345, :611-617).
@@ -295,34 +299,34 @@ typedef struct fldr_conv_desc {
 } fldr_conv_desc;
 
 /* Number of floats fldr_conv_prepack writes for a [cout,cin,k,k] weight. */
-int64_t fldr_conv_prepack_size(int cout, int cin, int ksize);
+FLDR_API int64_t fldr_conv_prepack_size(int cout, int cin, int ksize);
 /* Repack nn.Conv2d weight [cout,cin,k,k] (fp32, device) into the kernel's layout. */
-int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream);
-int fldr_conv2d(const fldr_conv_desc* desc, fldr_stream_t stream);
+FLDR_API int fldr_conv_prepack(const float* weight, float* wpack, int cout, int cin, int ksize, fldr_stream_t stream);
+FLDR_API int fldr_conv2d(const fldr_conv_desc* desc, fldr_stream_t stream);
 
 /* The same convolution (3x3 / stride 1 only) on the fp16 matrix cores with fp32-equivalent accuracy: every operand is
  * split into fp16 hi + lo halves and each product is formed by three fp16 MFMAs with fp32 accumulation ("3 x fp16
  * split"; measured error vs fp64 <= that of the exact fp32 MFMA chain, see csrc/conv_split_kernels.hip).  Takes the
  * same descriptor; desc->wpack must come from fldr_conv_split_prepack (it also holds the power-of-two weight scale). */
-int64_t fldr_conv_split_prepack_size(int cout, int cin);
-int fldr_conv_split_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
-int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
+FLDR_API int64_t fldr_conv_split_prepack_size(int cout, int cin);
+FLDR_API int fldr_conv_split_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+FLDR_API int fldr_conv2d_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 
 /* The stride-2 4x4 convolutions (UNet encoders, fLDRnet.py:611-613) with the same 3 x fp16 split: fldr_conv_desc with ksize 4,
  * stride 2, no x2 sources, no residual, cout <= 64; wpack from fldr_conv_s2_prepack; `out` and / or `out_spk`. */
-int64_t fldr_conv_s2_prepack_size(int cout, int cin);
-int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+FLDR_API int64_t fldr_conv_s2_prepack_size(int cout, int cin);
+FLDR_API int fldr_conv_s2_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
 /* The same stride-2 4x4 convolution reading ONE split-packed source (an encoder reading the previous encoder's packed output:
  * the producer then needs no fp32 copy): desc->src[0] = the packed tensor, src_c[0] = cin (a multiple of 8, <= 64),
  * src_bstride[0] in BYTES; outputs as fldr_conv2d_s2_split.  The MFMA operands are the stored hi / lo halves themselves (what
  * fldr_conv2d_s2_split derives from the unpacked value hi + lo, except in the rare case that lo was rounded up to a whole ulp
  * of hi: same value, other split), so the results agree with that function to fp32 accumulation rounding.  Shapes whose
  * weights do not fit the persistent kernel's LDS return FLDR_E_SHAPE (use fldr_spk_unpack + fldr_conv2d_s2_split). */
-int fldr_conv2d_s2_spk(const fldr_conv_desc* desc, fldr_stream_t stream);
+FLDR_API int fldr_conv2d_s2_spk(const fldr_conv_desc* desc, fldr_stream_t stream);
 /* Two such convolutions of the SAME packed source (same geometry, channel counts, relu; other weights / bias / outputs) in ONE launch:
  * the two 32-channel halves of enc3 (fLDRnet.py:617).  The bits of two fldr_conv2d_s2_spk calls. */
-int fldr_conv2d_s2_spk_pair(const fldr_conv_desc* desc0, const fldr_conv_desc* desc1, fldr_stream_t stream);
-int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
+FLDR_API int fldr_conv2d_s2_spk_pair(const fldr_conv_desc* desc0, const fldr_conv_desc* desc1, fldr_stream_t stream);
+FLDR_API int fldr_conv2d_s2_split(const fldr_conv_desc* desc, fldr_stream_t stream);
 
 /* Split-packed ("SPK") activations: the layout convolution outputs take when their consumer is another convolution.
  * A logical [N,C,H,W] fp32 tensor is stored as [N][G=ceil(C/8)][hi,lo][H*W][8 x fp16] (x = hi + lo, 22 significant
@@ -349,28 +353,29 @@ typedef struct fldr_spk_conv_desc {
     int32_t precision;         /* bit 0: 0 = 3 x fp16 split (fp32-equivalent), 1 = hi halves only (plain fp16 inputs); bit 1: `residual` is split-packed */
 } fldr_spk_conv_desc;
 
-int64_t fldr_spk_bytes(int C, int H, int W);                       /* bytes of one packed sample */
-int fldr_spk_pack(const float* src, int64_t src_bstride_floats, void* dst, int N, int C, int H, int W, fldr_stream_t stream);
-int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fldr_stream_t stream);   /* hi + lo, tests */
-int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
-int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
-int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
+FLDR_API int64_t fldr_spk_bytes(int C, int H, int W);                       /* bytes of one packed sample */
+FLDR_API int fldr_spk_pack(const float* src, int64_t src_bstride_floats, void* dst, int N, int C, int H, int W, fldr_stream_t stream);
+FLDR_API int fldr_spk_unpack(const void* src, float* dst, int N, int C, int H, int W, fldr_stream_t stream);   /* hi + lo, tests */
+FLDR_API int64_t fldr_conv_spk_prepack_size(int cout, int cin);             /* floats */
+FLDR_API int fldr_conv_spk_prepack(const float* weight, float* wpack, int cout, int cin, fldr_stream_t stream);
+FLDR_API int fldr_conv2d_spk(const fldr_spk_conv_desc* desc, fldr_stream_t stream);
 /* The same convolution (shared wpack / bias / relu / channel counts / precision) over n_levels (<= 8) inputs of different sizes in ONE
  * launch of the ring pipeline — rec_ctx_ds over the pyramid levels (fLDRnet.py:148-162 runs it level by level).  Every entry:
  * N = 1, one packed source; residual / out_f32 / out_spk for all entries or none.  Results are the bits of n_levels separate
  * fldr_conv2d_spk calls. */
-int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_levels, fldr_stream_t stream);
-int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc, 3: fldr_pca_level,
+FLDR_API int fldr_conv2d_spk_levels(const fldr_spk_conv_desc* descs, int n_levels, fldr_stream_t stream);
+FLDR_API int fldr_sizeof_desc(int which);                                   /* 0: sizeof(fldr_conv_desc), 1: fldr_spk_conv_desc, 2: fldr_prep_desc, 3: fldr_pca_level,
                                                                       4: fldr_splat_acc_desc, 5: fldr_splat_gather_desc — binding self-check: a binding compares its own struct sizes */
 /* Range status of the fp16 hi/lo splits behind the split-precision convolutions (fp32-equivalent for |x| <= 65504; up to
  * 131008 the excess is kept to fp16 precision; beyond that, and for NaN inputs, values SATURATE to a finite number —
- * never inf / NaN out of finite inputs): bit 0 (FLDR_STATUS_RANGE) is set if that happened on the current device since the
- * last reset.  Bit 1 (FLDR_STATUS_RING_TIMEOUT): one of the bounded waits inside the loader / consumer ring of the 3x3
- * convolutions expired (never observed; it would mean a wave ran on with operands that had not landed, so the affected
- * convolution's output must not be trusted).  0 = clean, negative on a HIP error.  Synchronises the device. */
-#define FLDR_STATUS_RANGE        1
-#define FLDR_STATUS_RING_TIMEOUT 2
-int fldr_range_status(int reset);
+ * never inf / NaN out of finite inputs): returns 1 if that happened on the current device since the last reset, 0 if not,
+ * negative on a HIP error.  The remedy for such data is exact fp32 (precision = 0 descriptors).  Synchronises the device. */
+FLDR_API int fldr_range_status(int reset);
+/* Status of the bounded waits inside the loader / consumer ring of the 3x3 convolutions: the number of waits that expired on
+ * the current device since the last reset (never observed; > 0 would mean a wave ran on with operands that had not landed, so the
+ * outputs since the last reset must not be trusted — a library fault, not a data problem), 0 = clean, negative on a HIP error
+ * (including a failed reset).  Synchronises the device. */
+FLDR_API int fldr_ring_status(int reset);
 
 /* ------------------------------------------------------------------------------------------
  * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.
@@ -381,7 +386,7 @@ int fldr_range_status(int reset);
  * (T_param is a 1-D double tensor, so the reference's tail is fp64: SURVEY F3).
  * refine [N,6,H,W]; the six candidates [N,3,H,W] with batch strides cand_bstride[k] (floats);
  * t: per-sample fp32 value t[n].  Exactly one of out_f64 / out_f32 may be NULL. */
-int fldr_synth_tail(const float* refine, const float* const cand[6], const int64_t cand_bstride[6],
+FLDR_API int fldr_synth_tail(const float* refine, const float* const cand[6], const int64_t cand_bstride[6],
                     const float* t, double T_param, double* out_f64, float* out_f32,
                     int N, int H, int W, fldr_stream_t stream);
 
@@ -389,13 +394,13 @@ int fldr_synth_tail(const float* refine, const float* const cand[6], const int64
  * (fLDRnet.py:511-524): refine_out is never stored.  d2: dec2 output [N,16,H/2,W/2]; weff: dec3 weights repacked by
  * fldr_dec3_prepack ([6,16,3,3] -> 1536 floats of per-phase 2x2 weights); bias [6]; cand/t/T/out as fldr_synth_tail.
  * refine_out_or_null: optional [N,6,H,W] debug/verification output of the logits. H, W even; candidate rows 8-B aligned. */
-int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream);
-int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+FLDR_API int fldr_dec3_prepack(const float* weight, float* weff, fldr_stream_t stream);
+FLDR_API int fldr_dec3_synth(const float* d2, const float* weff, const float* bias, const float* const cand[6],
                     const int64_t cand_bstride[6], const float* t, double T_param, double* out_f64, float* out_f32,
                     float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream);
 /* The same with channel-strided candidates: channel ch of candidate k, sample n at cand[k] + n*cand_bstride[k] +
  * ch*cand_cstride[k] (floats; even). */
-int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bias, const float* const cand[6],
+FLDR_API int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bias, const float* const cand[6],
                             const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
                             double* out_f64, float* out_f32, float* refine_out_or_null, int N, int H, int W,
                             fldr_stream_t stream);
@@ -403,9 +408,9 @@ int fldr_dec3_synth_strided(const float* d2, const float* weff, const float* bia
  * on the fp16 matrix cores with the 3 x fp16 split of the 3x3 convolutions (fp32-equivalent logits; not the bits of the fp32-FMA
  * kernel of fldr_dec3_synth), the fp64 tail is the same code.  wm: fldr_dec3_prepack_spk (fldr_dec3_prepack_spk_size() floats,
  * 16-byte aligned).  The model's default since round 3 (fLDRnet.py:642-643 + :511-524). */
-int64_t fldr_dec3_prepack_spk_size(void);
-int fldr_dec3_prepack_spk(const float* weight, float* wm, fldr_stream_t stream);
-int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const float* bias, const float* const cand[6],
+FLDR_API int64_t fldr_dec3_prepack_spk_size(void);
+FLDR_API int fldr_dec3_prepack_spk(const float* weight, float* wm, fldr_stream_t stream);
+FLDR_API int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const float* bias, const float* const cand[6],
                         const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
                         double* out_f64, float* out_f32, float* refine_out_or_null, int N, int H, int W, fldr_stream_t stream);
 
@@ -415,22 +420,22 @@ int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const float* bias, 
 
 /* frames_u8 [B,2,3,H,W] (I0, I1) -> level0 [B,3,2,Hp,Wp] fp32: x/255*2-1 (run_on_your_images.py:84) with right/bottom
  * reflect padding (main.py:840-849).  Hp, Wp: padded size (multiples of 2^S_tst*8), pad < size. */
-int fldr_ingest_u8(const uint8_t* frames_u8, float* level0, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream);
+FLDR_API int fldr_ingest_u8(const uint8_t* frames_u8, float* level0, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream);
 
 /* One pyramid level: F.interpolate(level0 planes, scale_factor=1/factor, mode='bicubic', align_corners=False)
  * (main.py:855-856), factor a power of two >= 2.  level0 [planes,Hp,Wp] -> level_i [planes,Hp/factor,Wp/factor]. */
-int fldr_pyramid_bicubic(const float* level0, float* level_i, int planes, int Hp, int Wp, int factor, fldr_stream_t stream);
+FLDR_API int fldr_pyramid_bicubic(const float* level0, float* level_i, int planes, int Hp, int Wp, int factor, fldr_stream_t stream);
 
 /* Both of the above for every level in ONE launch (one read of the uint8 frames, every level written from a staged 64 x 64 tile):
  * levels[i] = [B,3,2,Hp >> i,Wp >> i] for i < n_levels <= 7; Hp, Wp multiples of 2^(n_levels-1) and of 4.  The bits of fldr_ingest_u8 +
  * fldr_pyramid_bicubic (main.py:840-856). */
-int fldr_ingest_pyramid_u8(const uint8_t* frames_u8, float* const* levels, int n_levels, int B, int H, int W, int Hp, int Wp,
+FLDR_API int fldr_ingest_pyramid_u8(const uint8_t* frames_u8, float* const* levels, int n_levels, int B, int H, int W, int Hp, int Wp,
                            fldr_stream_t stream);
 
 /* main.py:885-911 on the device: crop pred [B,3,Hp,Wp] (fp64 if pred_is_f64 else fp32) to H x W, (x+1)/2 clipped to
  * [0,1] * 255, rounded half-to-even; optionally written as uint8 [B,3,H,W]; when target_u8 [B,3,H,W] is given,
  * sse[b] (zeroed by the caller) accumulates the squared error, so PSNR = 10 log10(255^2 * 3HW / sse[b]). */
-int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8_t* target_u8_or_null, uint8_t* out_u8_or_null,
+FLDR_API int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8_t* target_u8_or_null, uint8_t* out_u8_or_null,
                        double* sse_zeroed_or_null, int B, int H, int W, int Hp, int Wp, fldr_stream_t stream);
 
 /* utils.ssim_bgr (utils.py:662-669; main.py:911) on the device: SSIM of the Y channel of two uint8 images [B,3,H,W]
@@ -439,8 +444,8 @@ int fldr_frame_metrics(const void* pred, int pred_is_f64, const uint8_t* target_
  * max - min of Y_pred, map cropped by 3 pixels), all in fp64.  ws: fldr_ssim_y_ws_doubles(B,H,W) doubles; on completion
  * sample b's statistics sit at ws[b * (2 H W + 4) + 2 H W ...] = {min Y_pred, max Y_pred, sum of the SSIM map, 0}:
  * SSIM = sum / ((H - 6) (W - 6)).  H, W >= 7. */
-int64_t fldr_ssim_y_ws_doubles(int B, int H, int W);
-int fldr_ssim_y_u8(const uint8_t* pred_u8, const uint8_t* target_u8, double* ws, int B, int H, int W, fldr_stream_t stream);
+FLDR_API int64_t fldr_ssim_y_ws_doubles(int B, int H, int W);
+FLDR_API int fldr_ssim_y_u8(const uint8_t* pred_u8, const uint8_t* target_u8, double* ws, int B, int H, int W, fldr_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -20,13 +20,27 @@ WEIGHTS = os.path.join(PKG, "weights", "fLDRnet_X4K1000FPS_exp1_best_PSNR.npz")
 # has initialised the GPU must not fork + exec another program on this pool, so the helper is started here, in pytest_configure,
 # before any test or fixture has touched the GPU; it never imports torch, only runs the commands it is sent and returns their output.
 _LAUNCHER_CODE = r"""
-import json, subprocess, sys
+import json, os, signal, subprocess, sys
 for line in sys.stdin:
     req = json.loads(line)
     try:
-        r = subprocess.run(req["cmd"], capture_output=True, text=True, timeout=req.get("timeout", 600), env=req.get("env"))
-        out = {"rc": r.returncode, "stdout": r.stdout, "stderr": r.stderr}
-    except Exception as e:                                  # timeout etc.
+        # own session = own process group: on timeout the WHOLE group goes (torchrun and the rank grandchildren that would otherwise
+        # keep the output pipes open and stall communicate())
+        p = subprocess.Popen(req["cmd"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=req.get("env"), start_new_session=True)
+        try:
+            so, se = p.communicate(timeout=req.get("timeout", 600))
+            out = {"rc": p.returncode, "stdout": so, "stderr": se}
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(p.pid, signal.SIGKILL)
+            except Exception:
+                p.kill()
+            try:
+                so, se = p.communicate(timeout=20)
+            except Exception:
+                so, se = "", ""
+            out = {"rc": -999, "stdout": so, "stderr": (se or "") + "\nTIMEOUT: process group killed"}
+    except Exception as e:
         out = {"rc": -999, "stdout": "", "stderr": repr(e)}
     sys.stdout.write(json.dumps(out) + "\n")
     sys.stdout.flush()
@@ -38,7 +52,9 @@ def pytest_configure(config):
     global _launcher
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     expr = config.getoption("markexpr", "") or ""
-    if "gpu" in expr and "not gpu" not in expr and _launcher is None:
+    # Started in every session that may run GPU tests (-m gpu, a -k selection, no expression at all) — i.e. unless the marker
+    # expression excludes them —, here, before any test module or fixture can have touched the GPU.
+    if "not gpu" not in expr and _launcher is None:
         import subprocess
         _launcher = subprocess.Popen([sys.executable, "-c", _LAUNCHER_CODE], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 
@@ -58,12 +74,18 @@ def pytest_unconfigure(config):
 def clean_launcher():
     """run(cmd, env, timeout) -> dict(rc, stdout, stderr), executed by the GPU-clean helper process started in pytest_configure."""
     import json
+    import select
     if _launcher is None or _launcher.poll() is not None:
-        pytest.skip("the GPU-clean launcher only exists in `-m gpu` sessions")
+        pytest.skip("the GPU-clean launcher does not exist in sessions that exclude the gpu marker")
 
     def run(cmd, env=None, timeout=600):
         _launcher.stdin.write(json.dumps({"cmd": cmd, "env": env, "timeout": timeout}) + "\n")
         _launcher.stdin.flush()
+        # the reply is read with a deadline (the helper's own timeout + the time it grants the killed group + slack)
+        ready, _, _ = select.select([_launcher.stdout], [], [], timeout + 60)
+        if not ready:
+            _launcher.kill()
+            return {"rc": -998, "stdout": "", "stderr": "the launcher helper did not answer within %d s (killed)" % (timeout + 60)}
         return json.loads(_launcher.stdout.readline())
     return run
 

@@ -84,6 +84,9 @@ def test_bench_self_launches_n_ranks_gloo_dry():
     assert len(j["config"]["per_rank_pairs_per_s"]) == 2
     assert j["value"] == pytest.approx(2 * 4 / (j["ms_per_step"] * 4e-3), rel=1e-3)
     assert j["value"] < sum(j["config"]["per_rank_pairs_per_s"]) * 1.001        # whole-job rate uses the MAX over ranks
+    # the CPU-baseline leg runs on rank 0 at ANY world size (after the other ranks were released), so a multi-GPU line is complete
+    cb = j["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["runs"] == 1 and cb["value"] > 0 and cb["cores"] >= 1
 
 
 def test_bench_launcher_failure_modes():
