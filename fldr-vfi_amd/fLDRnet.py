@@ -141,9 +141,9 @@ class DCTXVFInet(nn.Module):
             B = x_l[0].shape[0]
             nch = a.dctvfi_nf * 6
             # all six projections in two launches (pass A: per-level min / max, pass B: emit): fLDRnet.py:133-146
-            # rec_ctx_ds of ALL levels in two launches; with FLDR_PCA_F32=0 the features exist split-packed only and the second convolution
-            # adds them back from the packed tensor (hi + lo: the fp32 feature up to 2^-22 relative, |x| <= 1), so that the rescale launch
-            # writes no fp32 copy (71 MB of 141 per 4K forward).  Default: the fp32 residual (see fldr_hip.PCA_F32 for why).
+            # rec_ctx_ds of ALL levels in two launches; the features exist split-packed only and the second convolution adds them back
+            # from the packed tensor (hi + lo: the fp32 feature up to 2^-22 relative, |x| <= 1), so that the rescale launch writes no
+            # fp32 copy (71 MB of 141 per 4K forward).  FLDR_PCA_F32=1: the fp32 residual (see fldr_hip.PCA_F32).
             levels_batched = bool(a.ref_feat_extrac and spk and B == 1 and fldr_hip.LEVEL_BATCH and fldr_hip.spk_variant() == 1)
             packed_only = levels_batched and not fldr_hip.PCA_F32
             r = to_pca_diff_f32_pyramid([x_l[i].reshape(B * 6, x_l[i].shape[3], x_l[i].shape[4]) for i in range(n_levels)],

@@ -144,6 +144,29 @@ def function_softsplat(img, flow, metric, mode="softmax"):
     return (out - 0.5) * 2
 
 
+SPLAT_COND_EPS = 1e-4       # a target cell whose normaliser stays below this is "nearly empty" ...
+SPLAT_COND_DELTA = 1e-3     # ... under flow perturbations of this many pixels
+
+
+def splat_ill_conditioned_cells(flow, eps=SPLAT_COND_EPS, delta=SPLAT_COND_DELTA):
+    """Test diagnostic (not part of the reference): target cells of a softmax splat WITHOUT metric whose value is ill-conditioned
+    in the flow.  The splat divides by the cell's normaliser n = sum of the bilinear weights that reach it and writes a hole where
+    n == 0 (softSplat.py:343-349): a cell with a tiny n — a single source whose footprint grazes it — flips between "hole" and
+    "that source's full value" when the flow moves by one ulp, which is what the reference's own fp32 atomics and any fp32
+    re-association of the convolutions in front of it do from run to run.  Returns the number of cells whose normaliser,
+    over the flow and its four axis perturbations by `delta` px, is > 0 at least once and < eps at least once."""
+    ones = torch.ones_like(flow[:, :1])
+    n_min = n_max = None
+    for dx, dy in ((0.0, 0.0), (delta, 0.0), (-delta, 0.0), (0.0, delta), (0.0, -delta)):
+        f = flow.clone()
+        f[:, 0] += dx
+        f[:, 1] += dy
+        n = splat_forward(ones, f)
+        n_min = n if n_min is None else torch.minimum(n_min, n)
+        n_max = n if n_max is None else torch.maximum(n_max, n)
+    return int(((n_min < eps) & (n_max > 0)).sum())
+
+
 # --------------------------------------------------------------------------
 # cost volume  (OpticalFlow/correlation.py)
 # --------------------------------------------------------------------------
@@ -250,9 +273,10 @@ def refine_unet(w, x):
     return _conv(w, p + "dec3", out)
 
 
-def flow_level(w, feat, flow_prev, splat=None):
+def flow_level(w, feat, flow_prev, splat=None, cond=None):
     """Flow estimation part of DCTVFInet.forward (fLDRnet.py:368-391).
-    `splat(img, flow)` defaults to the softmax splat without metric."""
+    `splat(img, flow)` defaults to the softmax splat without metric.  cond: a list that receives the number of ill-conditioned
+    target cells of this level's two feature splats (splat_ill_conditioned_cells; test diagnostic)."""
     if splat is None:
         splat = lambda a, b: function_softsplat(a, b, None, "softmax")
     B, C, H, W = feat.shape
@@ -261,6 +285,8 @@ def flow_level(w, feat, flow_prev, splat=None):
         return conv_flow_bottom(w, torch.cat((feat0, feat1), 1))
     up = F.interpolate(flow_prev, size=(H, W), mode="bilinear", align_corners=False)  # :384
     up = up * (up.shape[3] / flow_prev.shape[3])                                       # :385
+    if cond is not None:
+        cond.append(splat_ill_conditioned_cells(up[:, :2]) + splat_ill_conditioned_cells(up[:, 2:]))
     w1 = splat(feat1, up[:, :2])                                                      # :386
     w0 = splat(feat0, up[:, 2:])                                                      # :387
     a = _conv(w, "vfinet.conv_flow1", torch.cat([feat0, w1], 1))
@@ -312,7 +338,7 @@ def synthesis_level0(w, flow_l, x_l, t, splat_fn=None, keep=None):
 
 
 def forward(w, pyramid, t_value, n_levels=None, identity_splat=False, keep=None,
-            out_size=(2160, 4096)):
+            out_size=(2160, 4096), conditioning=False):
     """DCTXVFInet.forward, test branch (fLDRnet.py:106-223).
 
     pyramid: list of [B,3,2,H/2^i,W/2^i] fp32 (B must be 1 for parity, SURVEY 8e);
@@ -332,12 +358,15 @@ def forward(w, pyramid, t_value, n_levels=None, identity_splat=False, keep=None,
     splat = (lambda a, b: a) if identity_splat else None
     flow = None
     flows = {}
+    cond = [] if conditioning else None                       # keep["ill_conditioned_splat_cells"]: per level (coarse to fine, from the second)
     for level in range(n_levels - 1, 0, -1):                                              # :210
-        flow = flow_level(w, feats[level], flow, splat)
+        flow = flow_level(w, feats[level], flow, splat, cond)
         flows[level] = flow
-    flow = flow_level(w, feats[0], flow, splat)                                           # :218
+    flow = flow_level(w, feats[0], flow, splat, cond)                                     # :218
     flows[0] = flow
     keep.update(dict(pca=pcas, feat=feats, flows=flows))
+    if conditioning:
+        keep["ill_conditioned_splat_cells"] = cond
     sp = (lambda img, fl, z, mode: img) if identity_splat else None
     out = synthesis_level0(w, flow, pyramid[0], t, sp, keep)
     return out[:, :, :out_size[0], :out_size[1]]                                          # :222

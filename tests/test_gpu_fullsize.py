@@ -124,8 +124,17 @@ def test_deterministic_mode_is_bitwise_reproducible(hip, dev, model, xtest):
 def test_4k_strong_nonrigid_motion_matches_oracle(hip, dev, model, oracle, weights):
     """Whole forward at 3840x2160 on a pair under a strong smoothly varying motion field (2.5 % zoom + 0.8 degree rotation +
     shift: displacements up to ~85 px that change from pixel to pixel, large occluded / disoccluded borders) — the flows the
-    scatter kernels find hardest, through the model rather than through operator tests — against the oracle.  The backward
-    warp's hard mask threshold (fLDRnet.py:573-574) may flip on isolated pixels: at most one value in a million beyond 1e-4."""
+    scatter kernels find hardest, through the model rather than through operator tests — against the oracle.
+
+    The bound follows the CONDITIONING of the problem, which the oracle reports (oracle.splat_ill_conditioned_cells: target cells of a
+    feature splat whose normaliser is > 0 and < 1e-4 within +-1e-3 px of the flow — one grazing source decides between a hole and a
+    full value; the reference's own fp32 atomics flip such a cell from run to run):
+      * no such cell: the backward warp's hard mask threshold (fLDRnet.py:573-574) may still flip on isolated pixels — at most
+        one value in a million beyond 1e-4;
+      * some: a flipped cell changes the flow of the levels below it in a patch of the frame (measured with the packed-only PCA
+        residual, whose features differ from the oracle's by 2.4e-7: one cell, a 24 x 46 px patch, 4.9e-5 of the values, 91.7 dB)
+        — at most 2e-4 of the values beyond 1e-4, and never more than 5e-5 per ill-conditioned cell.
+    Mean error and PSNR bounds hold in both cases."""
     import fldr_harness as Hn
     m, a = model
     Hs, Ws = 2160, 3840
@@ -134,11 +143,14 @@ def test_4k_strong_nonrigid_motion_matches_oracle(hip, dev, model, oracle, weigh
     out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
     hip.check_range()
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
+    keep = {}
     with torch.no_grad():
-        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)[:, :, :Hs, :Ws]
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t, keep=keep, conditioning=True)[:, :, :Hs, :Ws]
+    n_ill = sum(keep["ill_conditioned_splat_cells"])
     err = (out.double().cpu() - ref.double()).abs()
     frac = (err > 1e-4).double().mean().item()
     p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
-    print("3840x2160 strong non-rigid motion: max|err| %.2e mean %.2e, %.2e of the values beyond 1e-4, PSNR(8-bit) %.1f dB"
-          % (err.max().item(), err.mean().item(), frac, p))
-    assert frac <= 1e-6 and err.mean().item() <= 1e-6 and p >= 90.0
+    print("3840x2160 strong non-rigid motion: max|err| %.2e mean %.2e, %.2e of the values beyond 1e-4, PSNR(8-bit) %.1f dB; "
+          "ill-conditioned feature-splat cells per level (oracle, eps %.0e, +-%.0e px): %s"
+          % (err.max().item(), err.mean().item(), frac, p, oracle.SPLAT_COND_EPS, oracle.SPLAT_COND_DELTA, keep["ill_conditioned_splat_cells"]))
+    assert frac <= (1e-6 if n_ill == 0 else min(2e-4, 5e-5 * n_ill)) and err.mean().item() <= 1e-6 and p >= 90.0
