@@ -151,7 +151,6 @@ _SIGNATURES = {
     "fldr_debug_dec3_xshift": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_dec3_xcd": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_splat_quad": (ctypes.c_int, [ctypes.c_int]),
-    "fldr_debug_prep_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_spk_bytes": (ctypes.c_int64, [ctypes.c_int] * 3),
     "fldr_spk_pack": (ctypes.c_int, [_c_float_p, ctypes.c_int64, ctypes.c_void_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_spk_unpack": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),

@@ -37,7 +37,6 @@ FLDR_API int fldr_debug_s2_vec4(int v);                                     /* 1
 FLDR_API int fldr_debug_s2_dma(int v);                                      /* packed-source stride-2 encoders of 17..32 output channels: 1 (default) the LDS-DMA kernel, 0 the register-staged kernel; other: query */
 FLDR_API int fldr_debug_dec3_xshift(int v);                                 /* tile-grid shift of dec3_synth (low-resolution columns; -1: default) */
 FLDR_API int fldr_debug_splat_group_fold(int v);                            /* fldr_softsplat_acc64, > 3 channels: 1 all channel groups of a tile in one workgroup where the map is large enough, 0 (default) one group per workgroup; other: query.  Same results */
-FLDR_API int fldr_debug_prep_variant(int v);                               /* fldr_level0_prep: 0 (default = the product's kernel) global gathers, 1 backward-warp gathers from LDS-staged windows (64 x 16 tiles; W % 4 == 0, 16-byte aligned frames; measured not faster on coherent flows: test build only); other: query.  Bit-identical results */
 FLDR_API int fldr_debug_conv_occupancy(int* out4);
 
 /* The destination-owned splats of rounds 1-2 (csrc/splat_tile_kernels.hip: claim-and-add bands without atomics; the LDS-f32-atomic

@@ -116,12 +116,12 @@ def test_level0_prep_bit_identical_to_unfused(hip, dev, shape):
 
 @pytest.mark.parametrize("shape", [(1, 20, 70, 8, 0.5, 1.0, "shift"), (2, 9, 33, 8, 0.125, 6.0, "noise"), (1, 6, 40, 16, 0.75, 3.0, "noise"), (1, 37, 45, 8, 0.3, 400.0, "noise"),
                                    (1, 24, 32, 8, 0.5, 0.2, "zoom"), (1, 11, 14, 3, 0.3, 2.0, "noise"), (1, 20, 21, 4, 0.6, 30.0, "edge")])
-def test_level0_prep_lds_windows_bit_identical(hip, hooks, dev, shape):
-    """Round 4: fldr_level0_prep with the backward-warp gathers served from LDS-staged windows (64 x 16 tiles; the exact corner box of
-    each tap pair found by a workgroup reduction, staged by 16-byte LDS-DMA) against the thread-per-pixel kernel with global gathers:
-    every plane bit-identical — rigid shifts (every window fits), smooth zoom, noise and 400 px wild flows (windows that do not fit fall
-    back per tile), a motion edge, frames read in place as channel-strided views, the two-phase call, partial tiles, W % 4 != 0 and
-    frames at a 4-byte offset (whole call falls back)."""
+def test_level0_prep_flow_fields_bit_identical_to_unfused(hip, dev, shape):
+    """fldr_level0_prep against the unfused kernels (resize_bilinear, zmetric, bwarp_tscaled, bwarp) on the flow fields that stress its
+    taps: rigid shifts, smooth zoom, noise and 400 px wild flows (taps far outside the frame: clamped corners, masked weights), a motion
+    edge; x3 / x4 / x8 / x16 upsampling (the integer source-index arithmetic of the power-of-two scales and the general path); frames read
+    in place as channel-strided views, from a copy, at a 4-byte offset; the two-phase call; without masks / metrics.  Every plane
+    bit-identical."""
     N, h, w, up, tv, amp, kind = shape
     H, W = h * up, w * up
     g = _gen(77)
@@ -141,31 +141,33 @@ def test_level0_prep_lds_windows_bit_identical(hip, hooks, dev, shape):
     t4 = torch.full((N, 1, 1, 1), tv).to(dev)
     keys = ("z0", "z1", "flow_t0", "flow_t1", "flowback_0", "flowback_1", "im0_tot", "im1_tot")
     I0, I1 = x[:, :, 0], x[:, :, 1]                                       # strided views: read in place
-    try:
-        hooks.fldr_debug_prep_variant(0)
-        ref = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
-        hooks.fldr_debug_prep_variant(1)
-        r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
-        rc = hip.level0_prep(flow_lo, I0.contiguous(), I1.contiguous(), t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
-        st = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=True, want_z=True, phase=1)
-        st = hip.level0_prep(None, None, None, None, H, W, 0, 0, state=st)
-        nz = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=False, want_z=False)
-        hooks.fldr_debug_prep_variant(0)
-        nz0 = hip.level0_prep(flow_lo, I0, I1, t4, H, W, -1.894, -1.8942, withmask=False, want_z=False)
-        for k in keys:
-            assert torch.equal(r[k], ref[k]) and torch.equal(rc[k], ref[k]) and torch.equal(st[k], ref[k]), k
-            if not k.startswith("z"):
-                assert torch.equal(nz[k], nz0[k]), k
-        # frames at a 4-byte offset: no 16-byte chunks — the call falls back to the global-gather kernel and still agrees
-        hooks.fldr_debug_prep_variant(1)
-        buf = torch.empty(x.numel() + 1, device=dev)
-        buf[1:] = x.reshape(-1)
-        xo = buf[1:].view_as(x)
-        ro = hip.level0_prep(flow_lo, xo[:, :, 0], xo[:, :, 1], t4, H, W, -1.894, -1.8942, withmask=True, want_z=True)
-        for k in keys:
-            assert torch.equal(ro[k], ref[k]), ("misaligned", k)
-    finally:
-        hooks.fldr_debug_prep_variant(0)
+    za0, za1 = -1.894, -1.8942
+    r = hip.level0_prep(flow_lo, I0, I1, t4, H, W, za0, za1, withmask=True, want_z=True)
+    # the unfused chain
+    I0c, I1c = I0.contiguous(), I1.contiguous()
+    both = hip.resize_bilinear(flow_lo, H, W, mul=float(up))
+    f10, f01 = both[:, :2], both[:, 2:]
+    tl = hip.resize_bilinear(torch.cat([t4 * flow_lo[:, 2:], (1 - t4) * flow_lo[:, :2]], 1), H, W, mul=float(up))
+    fb0 = hip.bwarp_tscaled(f10, f01, t4, "t", "1-t", withmask=True)
+    fb1 = hip.bwarp_tscaled(f01, f10, t4, "1-t", "t", withmask=True)
+    ref = {"z0": hip.zmetric(I0c, I1c, f01, za0), "z1": hip.zmetric(I1c, I0c, f10, za1), "flow_t0": tl[:, 0:2], "flow_t1": tl[:, 2:4],
+           "flowback_0": fb0, "flowback_1": fb1, "im0_tot": hip.bwarp(I0c, fb0, True), "im1_tot": hip.bwarp(I1c, fb1, True)}
+    rc = hip.level0_prep(flow_lo, I0c, I1c, t4, H, W, za0, za1, withmask=True, want_z=True)
+    st = hip.level0_prep(flow_lo, I0, I1, t4, H, W, za0, za1, withmask=True, want_z=True, phase=1)
+    st = hip.level0_prep(None, None, None, None, H, W, 0, 0, state=st)
+    for k in keys:
+        assert torch.equal(r[k], ref[k]), k
+        assert torch.equal(rc[k], ref[k]) and torch.equal(st[k], ref[k]), k
+    nz = hip.level0_prep(flow_lo, I0, I1, t4, H, W, za0, za1, withmask=False, want_z=False)
+    fb0n = hip.bwarp_tscaled(f10, f01, t4, "t", "1-t", withmask=False)
+    assert torch.equal(nz["flowback_0"], fb0n) and torch.equal(nz["im0_tot"], hip.bwarp(I0c, fb0n, False)) and torch.equal(nz["flow_t1"], ref["flow_t1"])
+    # frames at a 4-byte offset
+    buf = torch.empty(x.numel() + 1, device=dev)
+    buf[1:] = x.reshape(-1)
+    xo = buf[1:].view_as(x)
+    ro = hip.level0_prep(flow_lo, xo[:, :, 0], xo[:, :, 1], t4, H, W, za0, za1, withmask=True, want_z=True)
+    for k in keys:
+        assert torch.equal(ro[k], ref[k]), ("misaligned", k)
 
 
 @pytest.mark.parametrize("shape", [(1, 27, 60, 8, 0.5, 6.0), (2, 13, 21, 8, 0.25, 40.0), (1, 9, 15, 4, 1.0, 2.0), (1, 34, 40, 8, 0.0, 10.0)])

@@ -189,23 +189,14 @@ def prep():
     lo = torch.tensor([-0.75, -0.5, 0.75, 0.5], device=dev).view(1, 4, 1, 1) + torch.randn(1, 4, H // up, W // up, device=dev) * noise
     frames = [torch.rand(1, 3, 2, H, W, device=dev) * 2 - 1 for _ in range(3)]
     t4 = torch.tensor([0.5], device=dev).view(1, 1, 1, 1)
-    ref = None
     for rep in range(2):
-        for var in (0, 1):
-            L.fldr_debug_prep_variant(var)
-            us = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True), 16)
-            r = hip.level0_prep(lo, frames[0][:, :, 0], frames[0][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True)
-            same = ref is None or all(torch.equal(r[k], ref[k]) for k in ("z0", "z1", "flow_t0", "flow_t1", "flowback_0", "flowback_1", "im0_tot", "im1_tot"))
-            ref = ref or r
-            print("level0_prep 2304x3840 (flow noise %g), %s: %.1f us (same bits: %s)" % (noise, "LDS-staged windows " if var else "global gathers      ", us, same), flush=True)
-    for var in (0, 1):
-        L.fldr_debug_prep_variant(var)
-        sts = [hip.level0_prep(lo, frames[k][:, :, 0], frames[k][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True, phase=1) for k in range(3)]
-        p1 = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True, phase=1), 16)
-        p2 = timeit(lambda i: hip.level0_prep(None, None, None, None, H, W, 0, 0, state=sts[i % 3]), 16)
-        nz = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=False), 16)
-        print("  %s: phase 1 (z + flow_t) %.1f us, phase 2 (flowback + im_tot) %.1f us, everything without z %.1f us" % ("LDS windows" if var else "global     ", p1, p2, nz), flush=True)
-    L.fldr_debug_prep_variant(0)
+        us = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True), 16)
+        print("level0_prep 2304x3840 (flow noise %g): %.1f us" % (noise, us), flush=True)
+    sts = [hip.level0_prep(lo, frames[k][:, :, 0], frames[k][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True, phase=1) for k in range(3)]
+    p1 = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=True, phase=1), 16)
+    p2 = timeit(lambda i: hip.level0_prep(None, None, None, None, H, W, 0, 0, state=sts[i % 3]), 16)
+    nz = timeit(lambda i: hip.level0_prep(lo, frames[i % 3][:, :, 0], frames[i % 3][:, :, 1], t4, H, W, 20.0, 20.0, withmask=True, want_z=False), 16)
+    print("  phase 1 (z + flow_t) %.1f us, phase 2 (flowback + im_tot) %.1f us, everything without z %.1f us" % (p1, p2, nz), flush=True)
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["conv", "s2", "s2spk", "dec3", "pca", "band", "gather"]
