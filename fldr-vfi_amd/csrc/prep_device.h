@@ -126,7 +126,14 @@ __device__ __forceinline__ float prep_tap_mask(const PrepTap& p) {
 // literal +0, which never changes a sum that starts at +0)
 __device__ __forceinline__ float prep_tap_sample(const PrepTap& p, const float* __restrict__ plane) {
 #pragma clang fp contract(off)
+#if defined(PREP_ABLATE) && PREP_ABLATE == 2            // diagnostic build: one gather per sample instead of four
+    float pnw = prep_ldf(plane, p.onw), pne = pnw, psw = pnw, pse = pnw;
+#elif defined(PREP_ABLATE) && PREP_ABLATE == 3          // diagnostic build: the four corners as two 8-byte loads (nw|ne, sw|se; wrong at clamped borders)
+    const prep_f2 tn = *reinterpret_cast<const prep_f2*>(reinterpret_cast<const char*>(plane) + p.onw), ts = *reinterpret_cast<const prep_f2*>(reinterpret_cast<const char*>(plane) + p.osw);
+    float pnw = tn.x, pne = tn.y, psw = ts.x, pse = ts.y;
+#else
     float pnw = prep_ldf(plane, p.onw), pne = prep_ldf(plane, p.one), psw = prep_ldf(plane, p.osw), pse = prep_ldf(plane, p.ose);
+#endif
     fldr_pin(pnw); fldr_pin(pne); fldr_pin(psw); fldr_pin(pse);
     float v = 0.0f;
     v += pnw * p.wnw;

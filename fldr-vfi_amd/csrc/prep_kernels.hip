@@ -36,6 +36,10 @@ struct PrepArgs {
 #define PREP_NT 1
 #endif
 __device__ __forceinline__ void prep_stf(float* __restrict__ base, uint32_t boff, float v) {
+#if defined(PREP_ABLATE) && PREP_ABLATE == 1            // diagnostic build: no plane stores (the values stay live through an opaque use)
+    asm volatile("" :: "v"(v), "v"(boff), "s"(base));
+    return;
+#endif
 #if PREP_NT
     __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff));
 #else

@@ -251,37 +251,31 @@ class DCTVFInet(nn.Module):
             flow_l = self._chain([feat_p if spk else feat_x], self.conv_flow_bottom, (0, 2, 4, 6, 8), final_store=4)   # :379-380
         else:
             up_p = bw = None
-            if spk and fldr_hip.SPLAT_FEATURES == "acc64" and H * W > 2304:     # ... and the bounds tables of the two feature splats below come out of the same launch
+            if spk and fldr_hip.SPLAT_FEATURES != "gather" and H * W > 2304:     # ... and the bounds tables of the two feature splats below come out of the same launch
                 up, up_p, bw = fldr_hip.resize_bilinear_spk_bounds(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])   # :384-385
             elif spk:     # the upsampled flow is consumed as fp32 (splats, residual) and packed (conv_flow2.0): one kernel writes both
                 up, up_p = fldr_hip.resize_bilinear_spk(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])   # :384-385
             else:
                 up = fldr_hip.resize_bilinear(flow_l_prev, H, W, mul=W / flow_l_prev.shape[3])         # :384-385
             f1 = self.conv_flow1
+            wpair = None
             if spk and C // 2 <= 48 and fldr_hip.SPLAT_FEATURES == "gather":
-                # both warped feature maps in one deterministic gather launch; they only feed conv_flow1: split-packed
+                # opt-in: both warped feature maps in one deterministic gather launch; they only feed conv_flow1: split-packed
                 w1, w0 = fldr_hip.softsplat_gather([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax")   # :386-387
-            elif spk and B == 1 and half % 8 == 0 and fldr_hip.SPLAT_FEATURES == "acc64":
+            elif spk:
                 # both directions in one launch of the fp64-LDS-atomic tile splat: no accumulator, memset or normalisation pass
                 # (maps of <= 2304 pixels need no table: every tile walks the whole map)
-                wpair = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False,
-                                                 want_spk=True, spk_batch=True, bounds_ws=bw)          # :386-387
-                w1, w0 = wpair.sample(0), wpair.sample(1)
-            elif spk and B == 1 and half % 8 == 0:
-                wpair = fldr_hip.softsplat_pair_spk(feat1, up[:, :2], feat0, up[:, 2:], "softmax")     # :386-387, one memset / finish
-                w1, w0 = wpair.sample(0), wpair.sample(1)
-            elif spk and fldr_hip.SPLAT_FEATURES == "acc64":
-                wpair = None
-                w1, w0 = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False, want_spk=True,
-                                                   bounds_ws=bw)
-            elif spk:
-                wpair = None
-                w1 = fldr_hip.softsplat_fused(feat1, up[:, :2], None, "softmax", want_spk=True)        # :386
-                w0 = fldr_hip.softsplat_fused(feat0, up[:, 2:], None, "softmax", want_spk=True)        # :387
+                pair_batch = B == 1 and half % 8 == 0
+                r = fldr_hip.softsplat_acc64([feat1, feat0], [up[:, :2], up[:, 2:]], None, "softmax", want_f32=False,
+                                             want_spk=True, spk_batch=pair_batch, bounds_ws=bw)        # :386-387
+                if pair_batch:
+                    wpair, w1, w0 = r, r.sample(0), r.sample(1)
+                else:
+                    w1, w0 = r
             else:
                 w1 = self.softsplat(feat1, up[:, :2])                                                  # :386
                 w0 = self.softsplat(feat0, up[:, 2:])                                                  # :387
-            if spk and B == 1 and half % 8 == 0 and fldr_hip.SPLAT_FEATURES != "gather":
+            if wpair is not None:
                 # conv_flow1(cat(feat0, w1)) and conv_flow1(cat(feat1, w0)) share their weights: ONE launch over a batch of two
                 # (feat seen as its two channel halves, the warped maps written side by side above) — twice the units per launch
                 pair = fldr_hip.conv2d_spk([feat_p.channel_halves(), wpair], f1.weight, f1.bias, want_f32=False, want_spk=True)
@@ -320,30 +314,22 @@ class DCTVFInet(nn.Module):
         I1 = x_l[:, :, 1]
         if inv is not None:
             z0, z1 = inv
-        split = fldr_hip.PREP_SPLIT
-        r = fldr_hip.level0_prep(flow_l, I0, I1, t4, H, W, za0, za1, withmask=mask,
-                                 want_z=bool(a.impmasksoftsplat) and inv is None, phase=1 if split else 3)
+        lowres_tables = fldr_hip.SPLAT_BOUNDS == "lowres" and fldr_hip.SPLAT_KERNEL in ("auto", "acc64")
+        r = fldr_hip.level0_prep(flow_l, I0, I1, t4, H, W, za0, za1, withmask=mask, want_z=bool(a.impmasksoftsplat) and inv is None)
         if inv is None:
             z0, z1 = r["z0"], r["z1"]                                                                   # :442-446
             if cache is not None:
                 cache["level0"] = (z0, z1)
         flow_t0, flow_t1 = r["flow_t0"], r["flow_t1"]                                                   # :404-405,419-422
-        if fldr_hip.SPLAT_BOUNDS == "lowres" and fldr_hip.SPLAT_KERNEL in ("auto", "acc64", "tile"):
-            # candidate-source bounds of the two splats from the low-resolution flow their flow_t is the upsampling of
-            if fldr_hip.SPLAT_KERNEL != "tile":                   # both image splats in one launch (fp64 LDS atomics), one bounds launch
-                bw = fldr_hip.splat_bounds_upsampled_pair(flow_l, t4, "images", up, H, W)
-                warped0, warped1 = fldr_hip.softsplat_acc64([I0, I1], [flow_t0, flow_t1], [z0, z1] if z0 is not None else None,
-                                                            self.softsplat.strType, bounds_ws=bw)          # :449-450
-            else:
-                b0 = fldr_hip.splat_bounds_upsampled(flow_01_lo, t4, 1, up, H, W)
-                b1 = fldr_hip.splat_bounds_upsampled(flow_10_lo, t4, 2, up, H, W)
-                warped0 = fldr_hip.softsplat_fused(I0, flow_t0, z0, self.softsplat.strType, bounds_ws=b0)   # :449
-                warped1 = fldr_hip.softsplat_fused(I1, flow_t1, z1, self.softsplat.strType, bounds_ws=b1)   # :450
+        if lowres_tables:
+            # candidate-source bounds of the two splats from the low-resolution flow their flow_t is the upsampling of; both image
+            # splats in one launch (fp64 LDS atomics)
+            bw = fldr_hip.splat_bounds_upsampled_pair(flow_l, t4, "images", up, H, W)
+            warped0, warped1 = fldr_hip.softsplat_acc64([I0, I1], [flow_t0, flow_t1], [z0, z1] if z0 is not None else None,
+                                                        self.softsplat.strType, bounds_ws=bw)          # :449-450
         else:
             warped0 = self.softsplat(I0, flow_t0, z=z0)                                                # :449
             warped1 = self.softsplat(I1, flow_t1, z=z1)                                                # :450
-        if split:                     # the second half of the prep kernel, right in front of its consumer (enc1)
-            fldr_hip.level0_prep(None, None, None, None, H, W, za0, za1, state=r)
         flowback_0, flowback_1 = r["flowback_0"], r["flowback_1"]                                       # :474-475
         im0_tot, im1_tot = r["im0_tot"], r["im1_tot"]                                                   # :478-479
         srcs = [I0, I1, warped0, warped1, flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot]  # :480 (no cat)

@@ -392,11 +392,7 @@ SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 # normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
 # splat_gather_kernels.hip (bitwise run-to-run reproducible output frames; measured 531 us per forward: every match costs a
 # 48-load body whose latency the few waves of a feature map cannot hide).
-SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (default since round 3: fp64 LDS-atomic tiles) | strip | gather
-# Level-0 prep kernel in one launch (0, default) or in two around the image splats (1: enc1 then reads flowback_* / im*_tot
-# right behind their producer; measured 408 vs 419 pairs/s: the second launch's repeated flow evaluation costs more than the
-# Infinity-Cache hits give)
-PREP_SPLIT = os.environ.get("FLDR_PREP_SPLIT", "0") == "1"
+SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (default since round 3: fp64 LDS-atomic tiles) | gather (deterministic, opt-in)
 # rec_ctx_ds of all pyramid levels in two launches (fldr_conv2d_spk_levels) instead of two per level (FLDR_LEVEL_BATCH=0)
 LEVEL_BATCH = os.environ.get("FLDR_LEVEL_BATCH", "1") != "0"
 # 0 (default since round 5): the PCA features exist split-packed only — rec_ctx_ds.2 adds hi + lo of the packed feature (the fp32
