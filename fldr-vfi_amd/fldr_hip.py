@@ -387,14 +387,17 @@ _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 #            _FunctionSoftsplat (fldr_softsplat_fwd accumulates into the caller's tensor) and fldr_softsplat_fused;
 #   "tile":  the destination-owned bands of rounds 1-2 (no atomics, claim rounds; splat_tile_kernels.hip) — a retired generation,
 #            compiled into the TEST build only since round 4 (cross-check of acc64): selecting it outside fldr_hip.test_hooks() raises.
+# Environment switches of the product path (everything else below is a module attribute that tests / tools flip to reach a cross-check
+# kernel, not a deployment knob): FLDR_SPLAT (operator-level splat kernel), FLDR_SPLAT_FEATURES=gather (deterministic feature splats),
+# FLDR_PCA_F32=1 (fp32 PCA residual), FLDR_CONV_PRECISION (split | fp32 | fp16), FLDR_LIB (an experimental build of the library).
 SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 # Warped feature maps of the flow estimator (fLDRnet.py:386-387): "strip" (default) = the global-atomic scatter kernel +
 # normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
 # splat_gather_kernels.hip (bitwise run-to-run reproducible output frames; measured 531 us per forward: every match costs a
 # 48-load body whose latency the few waves of a feature map cannot hide).
 SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (default since round 3: fp64 LDS-atomic tiles) | gather (deterministic, opt-in)
-# rec_ctx_ds of all pyramid levels in two launches (fldr_conv2d_spk_levels) instead of two per level (FLDR_LEVEL_BATCH=0)
-LEVEL_BATCH = os.environ.get("FLDR_LEVEL_BATCH", "1") != "0"
+# rec_ctx_ds of all pyramid levels in two launches (fldr_conv2d_spk_levels) instead of two per level
+LEVEL_BATCH = True
 # 0 (default since round 5): the PCA features exist split-packed only — rec_ctx_ds.2 adds hi + lo of the packed feature (the fp32
 # feature up to 2^-22 relative: 2.4e-7 for |x| <= 1; every golden / oracle bound holds, tests/test_gpu_parity.py) and the rescale
 # launch writes half the bytes (71 of 141 MB per 4K forward).  1: the features are also written as fp32 and the residual is that
@@ -408,7 +411,7 @@ PCA_F32 = os.environ.get("FLDR_PCA_F32", "0") == "1"
 # Bounds table of the level-0 image splats: "lowres" (default) = from the low-resolution flow the upsampled flow_t is made of
 # (fldr_splat_bounds_upsampled: conservative intervals, 3 us instead of a 23 us pass over the full-resolution planes);
 # "exact" = the pre-pass over the full-resolution flow.  Same results up to fp32 summation order.
-SPLAT_BOUNDS = os.environ.get("FLDR_SPLAT_BOUNDS", "lowres")
+SPLAT_BOUNDS = "lowres"
 
 
 def splat_bounds_upsampled(flow_lo, t, scale_mode, mul, H, W):
@@ -690,10 +693,10 @@ def pca_table(ev, mean, meanvec):
     return tab
 
 
-ENC3_SPLIT = os.environ.get("FLDR_ENC3_SPLIT", "1") != "0"    # enc3 as two 32-channel persistent problems on enc2's packed output
-ENC3_PAIR = os.environ.get("FLDR_ENC3_PAIR", "1") != "0"      # ... in ONE launch (fldr_conv2d_s2_spk_pair); 0: two launches
-DEC3_MFMA = os.environ.get("FLDR_DEC3_MFMA", "1") != "0"      # the fused dec3 + blend kernel reads dec2's packed output (matrix-core phase convolutions)
-PCA_RAW_MIN_BYTES = int(os.environ.get("FLDR_PCA_RAW_MIN_BYTES", "0"))      # levels of at least this many projection bytes are parked between the two passes (4K pyramid: 196.9 us none, 186.7 from 4 MB, 168.4 all)
+ENC3_SPLIT = True    # enc3 as two 32-channel persistent problems on enc2's packed output
+ENC3_PAIR = True      # ... in ONE launch (fldr_conv2d_s2_spk_pair); 0: two launches
+DEC3_MFMA = True      # the fused dec3 + blend kernel reads dec2's packed output (matrix-core phase convolutions)
+PCA_RAW_MIN_BYTES = 0      # levels of at least this many projection bytes are parked between the two passes (4K pyramid: 196.9 us none, 186.7 from 4 MB, 168.4 all)
 
 
 def pca_project_pyramid(planes_list, ev, mean, meanvec, want_f32=True, want_spk=False, raw_min_bytes=None):
@@ -778,12 +781,12 @@ def resize_bilinear_spk(x, H, W, mul=1.0):
 
 # The upsampled level flow and the bounds tables of the feature splats that consume it in ONE launch (fldr_resize_bilinear_spk_bounds);
 # 0: the two launches.  Bit-identical either way.
-RESIZE_BOUNDS = os.environ.get("FLDR_RESIZE_BOUNDS", "1") != "0"
+RESIZE_BOUNDS = True
 
 
 def resize_bilinear_spk_bounds(x, H, W, mul=1.0):
     """resize_bilinear_spk(x, H, W, mul) + splat_bounds_upsampled_pair(x, None, "features", mul, H, W) of a [N,4,h,w] level flow
-    in one launch: -> (fp32 [N,4,H,W], Spk, bounds workspace).  Falls back to the two launches when W >= 4 w or FLDR_RESIZE_BOUNDS=0."""
+    in one launch: -> (fp32 [N,4,H,W], Spk, bounds workspace).  Falls back to the two launches when W >= 4 w."""
     N, C, h, w = x.shape
     assert C == 4
     x = x.contiguous()
@@ -1221,7 +1224,7 @@ def conv2d_s2_spk_pair(src, halves, relu=False):
 def s2_spk_ok(weight):
     """Does fldr_conv2d_s2_spk take this layer (cin a multiple of 8, <= 64; all chunks' weights + two stages within 80 KB of LDS)?"""
     cout, cin, k, _ = weight.shape
-    if k != 4 or cin % 8 or cin > 64 or cout > 32 or CONV_PRECISION == "fp32" or os.environ.get("FLDR_S2_SPK", "1") == "0":
+    if k != 4 or cin % 8 or cin > 64 or cout > 32 or CONV_PRECISION == "fp32":
         return False
     w_bytes = (2 if cout <= 16 else 4) * 2 * 1024                  # S2Cfg<MT, 1>::W_BYTES: steps x (hi, lo) KB
     return (cin // 4) * w_bytes + 2 * 4 * 1440 * 4 <= (80 if cout <= 16 else 156) * 1024      # (17..32 outputs: one workgroup per CU above 80 KB)
@@ -1339,7 +1342,7 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
     return (out, refine) if want_refine else out
 
 
-INGEST_FUSED = os.environ.get("FLDR_INGEST_FUSED", "1") != "0"     # ingest + all pyramid levels in one launch (0: one launch per level)
+INGEST_FUSED = True     # ingest + all pyramid levels in one launch (0: one launch per level)
 
 
 def ingest_pyramid(frames_u8, n_levels=6):

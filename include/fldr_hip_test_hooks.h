@@ -37,7 +37,7 @@ FLDR_API int fldr_debug_s2_vec4(int v);                                     /* 1
 FLDR_API int fldr_debug_s2_dma(int v);                                      /* packed-source stride-2 encoders of 17..32 output channels: 1 (default) the LDS-DMA kernel, 0 the register-staged kernel; other: query */
 FLDR_API int fldr_debug_dec3_xshift(int v);                                 /* tile-grid shift of dec3_synth (low-resolution columns; -1: default) */
 FLDR_API int fldr_debug_splat_group_fold(int v);                            /* fldr_softsplat_acc64, > 3 channels: 1 all channel groups of a tile in one workgroup where the map is large enough, 0 (default) one group per workgroup; other: query.  Same results */
-FLDR_API int fldr_debug_conv_occupancy(int* out4);
+FLDR_API int fldr_debug_conv_occupancy(int* out4);                          /* occupancy query of the fp32-MFMA convolution kernels */
 
 /* The destination-owned splats of rounds 1-2 (csrc/splat_tile_kernels.hip: claim-and-add bands without atomics; the LDS-f32-atomic
  * tiles behind fldr_debug_splat_tile_variant(0)), retired from the product in round 4 — every splat of the forward and
@@ -51,7 +51,7 @@ FLDR_API int fldr_softsplat_tile_strided(const float* img, int64_t img_bstride, 
                                 fldr_stream_t stream);
 FLDR_API int fldr_softsplat_tile_prebounded(const float* img, int64_t img_bstride, int64_t img_cstride, const float* flow,
                                    const float* metric_or_null, float* out, float* ws, int N, int C, int H, int W, int mode,
-                                   fldr_stream_t stream);                          /* occupancy query of the fp32-MFMA convolution kernels */
+                                   fldr_stream_t stream);
 
 #ifdef __cplusplus
 }

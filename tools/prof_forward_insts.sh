@@ -1,6 +1,6 @@
 #!/bin/bash
 # Instruction mix of single-stream 4K forwards per kernel (the step runs at the board's power limit: instructions are energy):
-#   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM  (own run)  and  --pmc SQ_INSTS_MFMA SQ_WAVES  (own run)
+#   rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS  (own run)  and  --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR  (own run)
 # usage (inside gpurun): bash tools/prof_forward_insts.sh <tag>   -> gpurun_out/<tag>/insts.txt
 set -e
 tag=${1:-insts}
@@ -10,7 +10,7 @@ out=$root/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $out/a -- python3 $root/tools/one_forward.py > $out/a.log 2>&1
-timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/b -- python3 $root/tools/one_forward.py > $out/b.log 2>&1 || true
+timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d $out/b -- python3 $root/tools/one_forward.py > $out/b.log 2>&1
 python3 - <<PY > $out/insts.txt
 import csv, glob, re
 from collections import OrderedDict, defaultdict
