@@ -40,6 +40,9 @@ __device__ __forceinline__ void prep_stf(float* __restrict__ base, uint32_t boff
     asm volatile("" :: "v"(v), "v"(boff), "s"(base));
     return;
 #endif
+#if defined(PREP_ABLATE) && PREP_ABLATE == 4            // diagnostic build: every store instruction issued, all into the first 64 KB of the plane (no HBM write stream)
+    boff &= 0xFFFCu;
+#endif
 #if PREP_NT
     __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + boff));
 #else
@@ -69,12 +72,19 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 template <int PH, bool P2>
 __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
+    __shared__ __attribute__((aligned(16))) unsigned char prep_lds[4 * PREP_WAVE_LDS];
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int px = blockIdx.x * 64 + tx;
+    const prep_lds_t wq = (prep_lds_t)prep_lds + ty * PREP_WAVE_LDS;     // this wave's windows (prep_device.h): quad, tap 0, tap 1
+    const prep_lds_t wu0 = wq + 2 * PREP_QW * 16;
+    const prep_lds_t wu1 = wu0 + PREP_UW * PREP_UH * 8;
+    const int px_raw = blockIdx.x * 64 + tx;
     const int py = blockIdx.y * 4 + ty;
     const int n = blockIdx.z;
     if (py >= a.H) return;                                               // wave-uniform
-    const bool live = px < a.W;
+    // (the lanes of a partial wave beyond the image compute on its last column — the wave stages its low-resolution windows together —
+    // and store nothing)
+    const bool live = px_raw < a.W;
+    const int px = live ? px_raw : a.W - 1;
     const int64_t HW = (int64_t)a.H * a.W, hw = (int64_t)a.h * a.w;
     constexpr bool ph1 = (PH & 1) != 0, ph2 = (PH & 2) != 0;
     const int64_t o1 = (int64_t)n * HW, o2 = (int64_t)n * 2 * HW, o3 = (int64_t)n * 3 * HW;
@@ -83,10 +93,10 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
         a.flow_t0 + o2, a.flow_t0 + o2 + HW, a.flow_t1 + o2, a.flow_t1 + o2 + HW,
         a.flowback_0 + o2, a.flowback_0 + o2 + HW, a.flowback_1 + o2, a.flowback_1 + o2 + HW,
         a.im0_tot + o3, a.im0_tot + o3 + HW, a.im0_tot + o3 + 2 * HW, a.im1_tot + o3, a.im1_tot + o3 + HW, a.im1_tot + o3 + 2 * HW};
-    if (live) {
+    {
         const uint32_t pixb = ((uint32_t)py * (uint32_t)a.W + (uint32_t)px) * 4u;      // byte offset of this pixel inside a plane
         auto put = [&](int plane, float v) __attribute__((always_inline)) {
-            prep_stf(dst[plane], pixb, v);                               // 4-byte lanes, straight from the pixel's thread
+            if (live) prep_stf(dst[plane], pixb, v);                     // 4-byte lanes, straight from the pixel's thread
         };
         const float2* lo10 = a.flow_lo2 + (int64_t)n * hw;       // flow_10 (x,y)
         const float2* lo01 = a.flow_lo2 + (int64_t)(a.N + n) * hw;   // flow_01 (x,y)
@@ -102,9 +112,11 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
             for (int c = 0; c < 3; ++c) { c0[c] = prep_ldf(i0 + (int64_t)c * a.i0_cstride, pixb); c1[c] = prep_ldf(i1 + (int64_t)c * a.i1_cstride, pixb); }
         }
 
-        // upsampled flows at this pixel (fLDRnet.py:419-422); the row's source rows / weight are scalar
+        // upsampled flows at this pixel (fLDRnet.py:419-422); the row's source rows / weight are scalar; the neighbours come from the
+        // wave's quad window (global loads where the window does not cover the wave: x2 upsampling, non-power-of-two scales)
         const PrepLin lx = prep_lin_in<P2>(px, a.sx, a.w, a.kx, a.rkx), ly = prep_lin_in<P2>(py, a.sy, a.h, a.ky, a.rky);
-        const PrepQuad q = prep_quad(lo10, lo01, a.w, lx, ly);
+        PrepQuad q;
+        if (!prep_quad_window(lo10, lo01, a.w, lx, ly, wq, tx, q)) q = prep_quad(lo10, lo01, a.w, lx, ly);
         const prep_f2 f10 = prep_up2<false>(q.a00, q.a01, q.a10, q.a11, lx.l, ly.l, a.mul, 1.0f);
         const prep_f2 f01 = prep_up2<false>(q.b00, q.b01, q.b10, q.b11, lx.l, ly.l, a.mul, 1.0f);
 
@@ -121,10 +133,13 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
             const PrepTap t1 = prep_tap(fpx, fpy, f10.x, f10.y, a);
             const float m0 = prep_tap_mask(t0), m1 = prep_tap_mask(t1);
             float acc0 = 0.0f, acc1 = 0.0f;
+            PrepCorners g0[3], g1[3];                                       // all 24 gathers in flight together
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { g0[c] = prep_tap_gather(t0, i1 + (int64_t)c * a.i1_cstride); g1[c] = prep_tap_gather(t1, i0 + (int64_t)c * a.i0_cstride); }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float w0 = prep_tap_sample(t0, i1 + (int64_t)c * a.i1_cstride) * m0;
-                const float w1 = prep_tap_sample(t1, i0 + (int64_t)c * a.i0_cstride) * m1;
+                const float w0 = prep_tap_blend(t0, g0[c]) * m0;
+                const float w1 = prep_tap_blend(t1, g1[c]) * m1;
                 acc0 += a.za0 * fabsf(c0[c] - w0);
                 acc1 += a.za1 * fabsf(c1[c] - w1);
             }
@@ -134,7 +149,11 @@ __global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
 
         if (ph2) {
             // backward flows (fLDRnet.py:474-475) and backward-warped frames (:478-479)
-            const PrepP2 r = prep_phase2_pixel<P2>(a, fpx, fpy, f10, f01, lo10, lo01, i0, i1, tv, omt);
+            // (the taps' low-resolution neighbourhoods through the wave's windows; a wave whose flows are too incoherent for them redoes
+            // its pixels on the global path)
+            bool fail = false;
+            PrepP2 r = prep_phase2_pixel<P2, true>(a, fpx, fpy, f10, f01, lo10, lo01, i0, i1, tv, omt, wu0, wu1, tx, fail);
+            if (fail) r = prep_phase2_pixel<P2, false>(a, fpx, fpy, f10, f01, lo10, lo01, i0, i1, tv, omt, wu0, wu1, tx, fail);
             put(6, r.fb0.x); put(7, r.fb0.y); put(8, r.fb1.x); put(9, r.fb1.y);
 #pragma unroll
             for (int c = 0; c < 3; ++c) { put(10 + c, r.im0[c]); put(13 + c, r.im1[c]); }
