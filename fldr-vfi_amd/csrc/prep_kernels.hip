@@ -69,8 +69,11 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 // P2: both scales are exact powers of two (the model's x8 upsampling): integer source-index arithmetic (prep_lin_in).
 // A wave covers 64 pixels of ONE row: everything that depends on the row only (its source rows and weight, its byte offset) is
 // wave-uniform and lives in scalar registers.
+#ifndef PREP_WPE
+#define PREP_WPE 7                 // <= 72 registers: seven waves per SIMD (8 spills; 6 measured 2 % slower)
+#endif
 template <int PH, bool P2>
-__global__ __launch_bounds__(256) void level0_prep_kernel(PrepArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREP_WPE))) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) unsigned char prep_lds[4 * PREP_WAVE_LDS];
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
