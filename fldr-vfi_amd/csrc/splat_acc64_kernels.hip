@@ -430,13 +430,21 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
                 }
             }
             float o[CB][4];
+            // (quotients over one normaliser: reciprocal + corrected product, splat_common.h; true division for normalisers out of its range)
+            StRecip rn[4];
+            bool fast = true;
+            if (MODE >= 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { rn[j] = st_recip(norm[j]); fast = fast && st_recip_safe(norm[j]); }
+                fast = __builtin_amdgcn_ballot_w64(!fast) == 0ull;           // wave-uniform
+            }
 #pragma unroll
             for (int c = 0; c < CB; ++c)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = (float)acc[c * CELLS + cell + j * (TW / 4)];
                     acc[c * CELLS + cell + j * (TW / 4)] = 0.0;
-                    if (MODE >= 1) v = v / norm[j];
+                    if (MODE >= 1) v = fast ? st_div(v, rn[j]) : v / norm[j];
                     o[c][j] = (v - 0.5f) * 2.0f;
                 }
             if (x >= W || y >= H || !on) continue;                       // (W % 4 == 0: the whole run is inside or outside)
@@ -451,11 +459,13 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
             float norm = 1.0f;
             if (MODE >= 1) { norm = (float)acc[CB * CELLS + i]; acc[CB * CELLS + i] = 0.0; if (norm == 0.0f) norm = 1.0f; }
             float o[CB];
+            const StRecip rn = st_recip(norm);
+            const bool fast = MODE >= 1 && __builtin_amdgcn_ballot_w64(!st_recip_safe(norm)) == 0ull;        // wave-uniform
 #pragma unroll
             for (int c = 0; c < CB; ++c) {
                 float v = (float)acc[c * CELLS + i];
                 acc[c * CELLS + i] = 0.0;
-                if (MODE >= 1) v = v / norm;
+                if (MODE >= 1) v = fast ? st_div(v, rn) : v / norm;
                 o[c] = cbase + c < C ? (v - 0.5f) * 2.0f : 0.0f;
             }
             if (x >= W || y >= H) continue;

@@ -36,6 +36,25 @@ __device__ __forceinline__ StGeom st_geom(int x, int y, float fx, float fy, int 
     return g;
 }
 
+// acc / norm of the splat normalisation (softSplat.py:343-349) for SEVERAL accumulators over one normaliser: the reciprocal once
+// (v_rcp_f32 + one Newton step), then per value q = v r, one exact residual v - q n and one correction (Markstein): the correctly
+// rounded quotient except on rare double-rounding ties (<= 1 ulp there) — 3 full-rate instructions per value instead of the ~10 of the
+// IEEE division expansion (16 quotients per cell in the feature configuration: a third of that kernel's finish).  Normalisers outside
+// [2^-100, 2^100] (never a sum of bilinear weights x exp(metric) of this model) take the true division: wave-uniform branch in the callers.
+struct StRecip { float n, r; };
+__device__ __forceinline__ StRecip st_recip(float n) {
+    StRecip q;
+    q.n = n;
+    const float r0 = __builtin_amdgcn_rcpf(n);
+    q.r = __builtin_fmaf(__builtin_fmaf(-n, r0, 1.0f), r0, r0);
+    return q;
+}
+__device__ __forceinline__ bool st_recip_safe(float n) { const float a = fabsf(n); return a >= 7.888609e-31f && a <= 1.2676506e30f; }
+__device__ __forceinline__ float st_div(float v, const StRecip& d) {
+    const float q = v * d.r;
+    return __builtin_fmaf(__builtin_fmaf(-q, d.n, v), d.r, q);
+}
+
 // Can a source region [rx0, rx1] x [ry0, ry1] (inclusive pixel coordinates) with flow bounds b touch the tile?
 // Target corner columns of a source: floor(x + fx) and floor(x + fx) + 1.  Conservative by one cell.
 __device__ __forceinline__ bool st_match(const float4 b, float rx0, float rx1, float ry0, float ry1, float tx0, float tx1,
