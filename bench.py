@@ -297,26 +297,18 @@ def main():
         graphs, graph_outs, graph_state = {}, {}, {"on": False, "why": "disabled (--no-graphs)" if a.no_graphs else "not captured yet"}
 
         def capture_graphs():
+            # fldr_harness.GraphedInterpolator (the opt-in replay API of the harness): one instance per (stream, pair), the instances of
+            # a stream share a memory pool; each checks its first replay against an eager forward of its pair on its stream (the same
+            # bits, or no graphs at all: a capture that baked in another stream's workspace would otherwise be timed unnoticed)
             try:
                 pools = [torch.cuda.graph_pool_handle() for _ in streams]
                 for s_i, st in enumerate(streams):
                     for k in range(npairs):
-                        g = torch.cuda.CUDAGraph()
-                        with torch.no_grad(), torch.cuda.graph(g, pool=pools[s_i], stream=st):
-                            graph_outs[(s_i, k)] = Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k])
-                        graphs[(s_i, k)] = g
+                        gi = Hn.GraphedInterpolator(model, args, frames[k], t, pyramid=pyrs[k], stream=st, pool=pools[s_i], check=True)
+                        graphs[(s_i, k)] = gi
+                        graph_outs[(s_i, k)] = gi.out
                 torch.cuda.synchronize()
-                # EVERY captured graph replayed once (untimed) against an eager forward of its pair on its stream: the same bits, or no
-                # graphs at all (a capture that baked in another stream's workspace or a stale pointer would otherwise be timed unnoticed)
-                for (s_i, k), g in graphs.items():
-                    with torch.cuda.stream(streams[s_i]), torch.no_grad():
-                        ref = Hn.interpolate(model, args, frames[k], t, pyramid=pyrs[k]).clone()
-                        g.replay()
-                    torch.cuda.synchronize()
-                    if not torch.equal(ref, graph_outs[(s_i, k)]):
-                        raise RuntimeError("replayed frame of graph (stream %d, pair %d) differs from the eager frame" % (s_i, k))
-                    del ref
-                graph_state.update(on=True, why="%d graphs (streams x pairs), every one replayed once and == its eager frame bit for bit" % len(graphs))
+                graph_state.update(on=True, why="%d graphs (streams x pairs; fldr_harness.GraphedInterpolator), every one replayed once and == its eager frame bit for bit" % len(graphs))
             except Exception as e:                                   # eager steps still work
                 graphs.clear(); graph_outs.clear()
                 graph_state.update(on=False, why="capture failed: %r" % (e,))
@@ -325,9 +317,7 @@ def main():
         def step(i):
             if graph_state["on"]:
                 s_i, k = i % len(streams), i % npairs
-                with torch.cuda.stream(streams[s_i]):
-                    graphs[(s_i, k)].replay()
-                return graph_outs[(s_i, k)]
+                return graphs[(s_i, k)].replay()
             return eager_step(i)
     else:
         def step(i):

@@ -242,6 +242,36 @@ def test_channel_strided_frames_read_in_place(hip, dev):
     assert torch.equal(hip.softsplat_fused(views[1], r["flow_t1"], r["z1"], "softmax"), w1)
 
 
+def test_graphed_interpolator_replays_the_eager_forward(hip, dev, model):
+    """fldr_harness.GraphedInterpolator (the opt-in hipGraph replay of the harness; bench.py's steps are its replays): captured on one
+    pair, fed two other pairs of the same shape — every replay == the eager forward of that pair, bit for bit; a prebuilt pyramid as the
+    captured input works the same way; with the pair cache on it refuses."""
+    import fldr_harness as Hn
+    m, a = model
+    pairs = [Hn.frames_from_uint8(Hn.synthetic_pair(200, 328, seed=s)).to(dev) for s in (3, 4, 5)]
+    t = torch.tensor([[0.5]], device=dev)
+    g = Hn.GraphedInterpolator(m, a, pairs[0], t)
+    for f, tv in ((pairs[1], 0.5), (pairs[2], 0.25), (pairs[0], 0.875)):
+        tt = torch.tensor([[tv]], device=dev)
+        out = g(f, tt).clone()                       # (the caller's stream waits for the replay)
+        ref = Hn.interpolate(m, a, f, tt)
+        torch.cuda.synchronize()
+        assert out.shape == (1, 3, 200, 328) and torch.equal(out, ref), tv
+    pyr = Hn.build_pyramid(Hn.pad_frames(pairs[1], a), a)
+    gp = Hn.GraphedInterpolator(m, a, pairs[1], t, pyramid=pyr)
+    out = gp.replay(join=True).clone()
+    assert torch.equal(out, Hn.interpolate(m, a, pairs[1], t))
+    with pytest.raises(RuntimeError):
+        gp(pairs[2], t)
+    m.pair_cache = True
+    try:
+        with pytest.raises(RuntimeError):
+            Hn.GraphedInterpolator(m, a, pairs[0], t)
+    finally:
+        m.pair_cache = False
+    hip.check_range()
+
+
 def test_pca_stream_equals_two_pass(hip, dev, model):
     """One-pass projection (raw fp64 parked, streaming rescale) == two-pass kernel bit for bit; its split-packed twin ==
     fldr_spk_pack of the fp32 output."""
