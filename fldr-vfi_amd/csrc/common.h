@@ -115,6 +115,7 @@ int fldr_range_read_split(int reset);
 int fldr_range_read_warp(int reset);
 int fldr_range_read_gather(int reset);
 int fldr_range_read_acc64(int reset);
+int fldr_range_read_dec23(int reset);
 int fldr_ring_timeouts_read(int reset);             // conv_ring_kernels.hip: expired ring waits (fldr_ring_status)
 
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into

@@ -461,7 +461,7 @@ int fldr_range_read_spk(int reset) { return fldr_tu_range_read(reset); }
 extern "C" int fldr_range_status(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
     int v = 0;
-    int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather, fldr_range_read_acc64};
+    int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather, fldr_range_read_acc64, fldr_range_read_dec23};
     for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x ? 1 : 0; }
     return v;
 }

@@ -335,7 +335,12 @@ class DCTVFInet(nn.Module):
         srcs = [I0, I1, warped0, warped1, flow_t0, flow_t1, flowback_0, flowback_1, im0_tot, im1_tot]  # :480 (no cat)
         cands = [warped0, warped1, im0_tot, im1_tot, I0, I1]
         unet = self.refine_unet
-        if tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and H % 2 == 0 and W % 2 == 0:
+        if (fldr_hip.DEC23_FUSED and fldr_hip.use_spk() and fldr_hip.CONV_PRECISION == "split" and H % 4 == 0 and W % 4 == 0
+                and tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and tuple(unet.dec2.weight.shape) == (16, 48, 3, 3)):
+            # dec2 + dec3 + softmax/T + blend in one persistent kernel: neither dec2's output nor refine_out is ever stored
+            dec1p, enc1p = unet.forward_until_dec1(srcs)
+            out = fldr_hip.dec23_synth(dec1p, enc1p, unet.dec2.weight, unet.dec2.bias, unet.dec3.weight, unet.dec3.bias, cands, t4, T)
+        elif tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and H % 2 == 0 and W % 2 == 0:
             # dec3 + softmax/T + blend in one kernel; refine_out (6 full-resolution planes) is never stored
             out = fldr_hip.dec3_synth(unet.forward_until_dec2(srcs, packed_out=fldr_hip.DEC3_MFMA and fldr_hip.use_spk()),
                                       unet.dec3.weight, unet.dec3.bias, cands, t4, T)
@@ -394,7 +399,12 @@ class PCARefineUNet(nn.Module):
             self._enc3_split = hit = (key, parts)
         return hit[1]
 
-    def forward_until_dec2(self, concat, packed_out=False):
+    def forward_until_dec1(self, concat):
+        """Everything up to and including dec1 + ReLU (fLDRnet.py:621-636) on split-packed activations -> (dec1 packed [B,32,H/4,W/4],
+        enc1 packed [B,16,H/2,W/2]): the two inputs of dec2."""
+        return self.forward_until_dec2(concat, packed_out=True, stop_before_dec2=True)
+
+    def forward_until_dec2(self, concat, packed_out=False, stop_before_dec2=False):
         """Everything up to and including dec2 + ReLU (fLDRnet.py:621-640), at half resolution."""
         srcs = list(concat) if isinstance(concat, (list, tuple)) else [concat]
         cv = fldr_hip.conv2d
@@ -426,6 +436,8 @@ class PCARefineUNet(nn.Module):
                 out = [cv([enc2], self.enc3.weight, self.enc3.bias, stride=2, relu=True, want_f32=False, want_spk=True)]
             out = cs(out, self.dec0.weight, self.dec0.bias, relu=True, want_f32=False, want_spk=True)
             out = cs([out, enc2p], self.dec1.weight, self.dec1.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
+            if stop_before_dec2:
+                return out, enc1p
             # dec2's output stays split-packed when the fused dec3 + blend kernel consumes it (matrix-core phase convolutions)
             return cs([out, enc1p], self.dec2.weight, self.dec2.bias, relu=True, up2=[True, False],
                       want_f32=not packed_out, want_spk=packed_out)

@@ -181,6 +181,11 @@ _SIGNATURES = {
     "fldr_dec3_synth_spk": (ctypes.c_int, [ctypes.c_void_p, _c_float_p, _c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                            ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p,
                                            _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+    "fldr_dec23_prepack_size": (ctypes.c_int64, []),
+    "fldr_dec23_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
+    "fldr_dec23_synth": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p]
+                         + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
     "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_ingest_pyramid_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
@@ -202,7 +207,7 @@ _DEFAULT_PATH = ("fldr_version", "fldr_error_string", "fldr_sizeof_desc", "fldr_
                  "fldr_pca_project_pyramid", "fldr_conv2d_spk", "fldr_conv2d_spk_levels", "fldr_conv_spk_prepack", "fldr_conv2d_s2_split",
                  "fldr_conv2d_s2_spk", "fldr_conv2d_s2_spk_pair", "fldr_conv_s2_prepack", "fldr_softsplat_acc64", "fldr_level0_prep",
                  "fldr_splat_bounds_upsampled_pair", "fldr_resize_bilinear_spk", "fldr_resize_bilinear_spk_bounds", "fldr_dec3_prepack_spk",
-                 "fldr_dec3_synth_spk", "fldr_spk_pack")
+                 "fldr_dec3_synth_spk", "fldr_spk_pack", "fldr_dec23_prepack_size", "fldr_dec23_prepack", "fldr_dec23_synth")
 _lib = None
 _hooks_lib = None
 
@@ -1340,6 +1345,52 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
                                              _dev(t, "t"), float(T_param), o64, o32, _dev(refine, "refine") if want_refine else None,
                                              N, H, W, _stream()), "fldr_dec3_synth_strided")
     return (out, refine) if want_refine else out
+
+
+# dec2 -> dec3 -> blend in one persistent producer / consumer kernel (fldr_dec23_synth): dec2's packed output never reaches HBM
+DEC23_FUSED = os.environ.get("FLDR_DEC23", "1") != "0"
+
+
+def dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, T_param, out_dtype=torch.float64):
+    """PCARefineUNet.dec2 (on cat(nearest-x2(dec1), enc1), ReLU) + dec3 (on the nearest-x2 upsampled result) + softmax / T + blend
+    (fLDRnet.py:638-643, 511-524) in one kernel.  dec1p: Spk [N,32,H/4,W/4]; enc1p: Spk [N,16,H/2,W/2]; w2 [16,48,3,3], w3 [6,16,3,3]."""
+    N, c1, h4, w4 = dec1p.shape
+    N2, c2, h, w = enc1p.shape
+    assert isinstance(dec1p, Spk) and isinstance(enc1p, Spk) and N == N2 and c1 == 32 and c2 == 16 and h == 2 * h4 and w == 2 * w4
+    assert tuple(w2.shape) == (16, 48, 3, 3) and tuple(w3.shape) == (6, 16, 3, 3) and len(cands) == 6
+    assert dec1p.bstride == 8 * h4 * w4 * 16 and enc1p.bstride == 4 * h * w * 16, "dec23_synth: the packed sources must be whole tensors"
+    H, W = 2 * h, 2 * w
+    hit = getattr(w2, "_fldr_dec23", None)
+    if hit is None or hit[0] != (w2._version, w2.data_ptr()):
+        wp = torch.empty(int(lib().fldr_dec23_prepack_size()), device=w2.device, dtype=torch.float32)
+        _check(lib().fldr_dec23_prepack(_dev(w2.detach().contiguous(), "weight"), _dev(wp, "wpack"), _stream()), "fldr_dec23_prepack")
+        _prepack_done()
+        w2._fldr_dec23 = hit = ((w2._version, w2.data_ptr()), wp)
+    w2p = hit[1]
+    hit3 = getattr(w3, "_fldr_dec3m", None)
+    if hit3 is None or hit3[0] != (w3._version, w3.data_ptr()):
+        wm = torch.empty(int(lib().fldr_dec3_prepack_spk_size()), device=w3.device, dtype=torch.float32)
+        _check(lib().fldr_dec3_prepack_spk(_dev(w3.detach().contiguous(), "weight"), _dev(wm, "wm"), _stream()), "fldr_dec3_prepack_spk")
+        _prepack_done()
+        w3._fldr_dec3m = hit3 = ((w3._version, w3.data_ptr()), wm)
+    w3m = hit3[1]
+    ptrs = (ctypes.c_void_p * 6)()
+    strides = (ctypes.c_int64 * 6)()
+    cstrides = (ctypes.c_int64 * 6)()
+    keep = []
+    for k, c in enumerate(cands):
+        assert c.shape == (N, 3, H, W)
+        c, strides[k], cstrides[k] = _planes(c, "candidate")
+        keep.append(c)
+        ptrs[k] = c.data_ptr()
+    t = t.reshape(N).contiguous().float()
+    out = torch.empty(N, 3, H, W, device=w2.device, dtype=out_dtype)
+    o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
+    o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
+    _check(lib().fldr_dec23_synth(ctypes.c_void_p(dec1p.ptr), ctypes.c_void_p(enc1p.ptr), _dev(w2p, "w2pack"), _dev(b2.detach(), "bias2"), _dev(w3m, "w3m"),
+                                  _dev(b3.detach(), "bias3"), ptrs, strides, cstrides, _dev(t, "t"), float(T_param), o64, o32, N, H, W, _stream()),
+           "fldr_dec23_synth")
+    return out
 
 
 INGEST_FUSED = True     # ingest + all pyramid levels in one launch (0: one launch per level)

@@ -1337,6 +1337,45 @@ def test_fused_dec3_synth_on_the_matrix_cores(hip, dev, shape):
     assert o32.dtype == torch.float32 and torch.equal(o32, out.float())
 
 
+@pytest.mark.parametrize("shape", [(1, 16, 64), (2, 24, 40), (1, 20, 72), (1, 8, 36), (1, 72, 136)])
+def test_dec2_dec3_fused_producer_consumer_kernel(hip, dev, shape):
+    """fldr_dec23_synth (round 5): dec2 = ReLU(conv3x3(cat(nearest-x2(dec1), enc1))) produced tile by tile in LDS by four waves while eight
+    others run dec3's phase convolutions + fp64 softmax / blend on the previous tile — against fp64 torch (the bound of the matrix-core
+    dec3 test, 3e-6) and against the two-kernel path (conv2d_spk + dec3_synth on the packed tensor): full and partial tiles, tiles at
+    every border, one-tile and many-tile workgroups, two samples, candidates that are strided views (as I0 / I1 are planes of the frame
+    pair tensor), the fp32 output."""
+    g = _gen(45)
+    N, h, w = shape                                                          # half resolution (dec2 / enc1); dec1 at h/2 x w/2
+    dec1 = torch.rand(N, 32, h // 2, w // 2, generator=g) * 1.5             # post-ReLU activations
+    enc1 = torch.rand(N, 16, h, w, generator=g) * 1.5
+    w2 = torch.randn(16, 48, 3, 3, generator=g) / 12
+    b2 = torch.randn(16, generator=g) * 0.2
+    w3 = torch.randn(6, 16, 3, 3, generator=g) / 6
+    b3 = torch.randn(6, generator=g) * 0.3
+    cands = [(torch.rand(N, 3, 2 * h, 2 * w, generator=g) * 2 - 1).to(dev) for _ in range(4)]
+    pair = (torch.rand(N, 3, 2, 2 * h, 2 * w, generator=g) * 2 - 1).to(dev)
+    cands += [pair[:, :, 0], pair[:, :, 1]]                                  # channel stride 2 H W, batch stride 6 H W
+    t = torch.tensor([[0.25], [0.5]])[:N]
+    cat = torch.cat([F.interpolate(dec1.double(), scale_factor=2, mode="nearest"), enc1.double()], 1)
+    d2 = F.relu(F.conv2d(cat, w2.double(), b2.double(), padding=1))
+    logits = F.conv2d(F.interpolate(d2, scale_factor=2, mode="nearest"), w3.double(), b3.double(), padding=1)
+    occ = F.softmax(logits / 1.5616, dim=1)
+    t4 = t.view(N, 1, 1, 1).double()
+    wk = [(1 - t4), t4] * 3
+    ref = sum(wk[k] * occ[:, k:k + 1] * cands[k].cpu().double() for k in range(6)) / sum(wk[k] * occ[:, k:k + 1] for k in range(6))
+    dec1p, enc1p = hip.spk_pack(dec1.to(dev)), hip.spk_pack(enc1.to(dev))
+    out = hip.dec23_synth(dec1p, enc1p, w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), cands, t.to(dev), 1.5616)
+    assert out.dtype == torch.float64 and out.shape == (N, 3, 2 * h, 2 * w)
+    _cmp(out, ref, atol=3e-6, what="fused dec2 + dec3 + blend vs fp64 torch")
+    d2p = hip.conv2d_spk([dec1p, enc1p], w2.to(dev), b2.to(dev), relu=True, up2=[True, False], want_f32=False, want_spk=True)
+    two = hip.dec3_synth(d2p, w3.to(dev), b3.to(dev), cands, t.to(dev), 1.5616)
+    _cmp(out, two, atol=3e-6, what="fused vs conv2d_spk + dec3_synth")
+    assert torch.equal(out, hip.dec23_synth(dec1p, enc1p, w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), cands, t.to(dev), 1.5616))
+    o32 = hip.dec23_synth(dec1p, enc1p, w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), cands, t.to(dev), 1.5616, out_dtype=torch.float32)
+    assert o32.dtype == torch.float32 and torch.equal(o32, out.float())
+    hip.check_range()
+
+
 def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):
     """8x protocol: 7 outputs per pair with PCA/flows/z computed once == 7 independent forwards == oracle."""
     import fldr_harness as Hn
