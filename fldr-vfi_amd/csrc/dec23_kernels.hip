@@ -50,7 +50,7 @@
 #define D23_LDS (D23_OFF_L + 8 * D23_LWAVE)   // 162,816 B
 #define D23_THREADS 768
 #ifndef D23_CPIECES
-#define D23_CPIECES 4                         // window pieces per consumer wave (of 44; the producer waves share the rest)
+#define D23_CPIECES 6                         // window pieces per consumer wave (of 44; the producer waves share the rest)
 #endif
 #ifndef D23_NB
 #define D23_NB 3                              // pixel blocks per fetch / MFMA unit of the producer (6 blocks per wave and K-step)
@@ -108,6 +108,17 @@ __device__ __forceinline__ void d23_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+// 1 / x for a finite positive x of ordinary magnitude (a sum of softmax weights): the hardware estimate + two Newton steps (full fp64
+// precision; no scaling / fix-up of the IEEE division sequence, whose special cases cannot occur here — a zero or non-finite x gives a
+// non-finite result in both)
+__device__ __forceinline__ double d23_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+
 template <int I, int N, typename F>
 __device__ __forceinline__ void d23_static_for(F& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); d23_static_for<I + 1, N>(f); }
@@ -139,6 +150,14 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
         i0 = tyi * D23_TH; j0 = (trem - tyi * a.tiles_x) * D23_TW;
     };
     const int ln = lane & 15, lg = lane >> 4;
+    // Arguments that are used at one place of the tile loop are read from the kernel-argument segment THERE (scalar loads, hits in the
+    // constant cache): kept in registers across the loop they were ~40 SGPRs too many, spilled to vector lanes and read back with ~75
+    // v_readlane per tile.  The empty asm makes the pointer opaque, so the loads cannot be hoisted out of the loop again.
+    auto args = [&]() __attribute__((always_inline)) {
+        auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return (const __attribute__((address_space(4))) D23Args*)kp;
+    };
     unsigned long long st6 = 0, sf = 0, st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, st5 = 0, sa = 0, sb = 0, sc = 0, sd = 0, se = 0;
     (void)st0; (void)st1; (void)st2; (void)st3; (void)st4; (void)st5; (void)sa; (void)sb; (void)sc; (void)sd; (void)se; (void)st6; (void)sf;
 
@@ -166,7 +185,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             const int piece = i < 6 ? i * 64 : D23_EH * D23_EW - 64;
             const int gy = i0 - 2 + (rc >> 8), gx = j0 - 2 + (rc & 255);
             const bool ok = gy >= 0 && gy < h && gx >= 0 && gx < w;
-            const unsigned char* pl = a.enc1 + ((int64_t)n * 4 + plane) * (int64_t)h * w * 16;
+            const unsigned char* pl = args()->enc1 + ((int64_t)n * 4 + plane) * (int64_t)h * w * 16;
             r.g = ok ? pl + (uint32_t)(gy * w + gx) * 16u : zero;
             r.lds = D23_OFF_WIN + set * D23_WIN + plane * D23_EPLANE + piece * 16;
         } else {
@@ -174,29 +193,32 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             const int piece = (e & 1) ? D23_QH * D23_QW - 64 : 0;
             const int gy = (i0 >> 1) - 1 + (rc >> 8), gx = (j0 >> 1) - 1 + (rc & 255);
             const bool ok = gy >= 0 && gy < h4 && gx >= 0 && gx < w4;
-            const unsigned char* pl = a.dec1 + ((int64_t)n * 8 + plane) * (int64_t)h4 * w4 * 16;
+            const unsigned char* pl = args()->dec1 + ((int64_t)n * 8 + plane) * (int64_t)h4 * w4 * 16;
             r.g = ok ? pl + (uint32_t)(gy * w4 + gx) * 16u : zero;
             r.lds = D23_OFF_WIN + set * D23_WIN + 4 * D23_EPLANE + plane * D23_QPLANE + piece * 16;
         }
         return r;
     };
-    // this wave's pieces of every later tile: consumer wave c takes c + 8 j (j < D23_CPIECES), the producer waves the rest; their slot
-    // coordinates are kept packed, one register per piece (the asm in my_piece stops the compiler from hoisting their unpacked forms and
-    // the address arithmetic out of the tile loop into a dozen more live registers — those were spilled, and every reload of a spill is a
-    // vmcnt(0) in the middle of the tile)
-    const int my_e0 = consumer ? wv : 8 * D23_CPIECES + (wv - 8), my_de = consumer ? 8 : 4, my_np = consumer ? D23_CPIECES : (44 - 8 * D23_CPIECES) / 4;
-    int my_rc[D23_CPIECES];
+    // The pieces of every later tile: with D23_CPIECES = 6 the consumer waves take all 44 (wave c: c + 8 j while < 44 — their period has
+    // slack at the barrier, the producer's has none), otherwise the producer waves share the rest.  The slot coordinates are kept packed,
+    // two pieces per register (the asm below stops the compiler from hoisting their unpacked forms and the address arithmetic out of the
+    // tile loop into a dozen more live registers — those were spilled, and every reload of a spill is a vmcnt(0) in the middle of the tile).
+    constexpr int PREST = (44 - 8 * D23_CPIECES + 3) / 4;                // pieces per producer wave (0 when the consumers take all)
+    const int my_e0 = consumer ? wv : 8 * D23_CPIECES + (wv - 8), my_de = consumer ? 8 : 4;
+    int my_rc2[(D23_CPIECES + 1) / 2];
 #pragma unroll
-    for (int j = 0; j < D23_CPIECES; ++j) my_rc[j] = piece_rc(min(my_e0 + my_de * j, 43));
+    for (int j = 0; j < (D23_CPIECES + 1) / 2; ++j)
+        my_rc2[j] = piece_rc(min(my_e0 + my_de * (2 * j), 43)) | (piece_rc(min(my_e0 + my_de * (2 * j + 1), 43)) << 16);
     auto stage_mine = [&](int k) __attribute__((always_inline)) {
         int n, i0, j0;
         tile_of(k, n, i0, j0);
 #pragma unroll
         for (int j = 0; j < D23_CPIECES; ++j) {
-            if (j < my_np) {                                             // wave-uniform
-                int rc = my_rc[j];
-                asm volatile("" : "+v"(rc));
-                const Piece pc = piece_of(my_e0 + my_de * j, rc, n, i0, j0, k & 1);
+            const int e = my_e0 + my_de * j;
+            if (e < 44 && (consumer || j < PREST)) {                     // wave-uniform
+                int rc2 = my_rc2[j >> 1];
+                asm volatile("" : "+v"(rc2));
+                const Piece pc = piece_of(e, (rc2 >> (16 * (j & 1))) & 0xFFFF, n, i0, j0, k & 1);
                 d23_dma(pc.g, smem + pc.lds);
             }
         }
@@ -247,9 +269,10 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             const int lic = min(c_li, h - 1), ljc = min(c_lj, w - 1);
             const uint32_t pob = (__umul24((uint32_t)(2 * lic + ra), (uint32_t)a.W) + (uint32_t)(2 * ljc)) * 4u;
             auto load_cands = [&](int ch) __attribute__((always_inline)) {
+                const auto ap = args();
 #pragma unroll
                 for (int kc = 0; kc < 6; ++kc)
-                    cv[kc][ch] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.cand[kc]) + (int64_t)c_n * a.cand_bstride_b[kc] + (pob + (uint32_t)ch * a.cand_cstride_b[kc]));
+                    cv[kc][ch] = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(ap->cand[kc]) + (int64_t)c_n * ap->cand_bstride_b[kc] + (pob + (uint32_t)ch * ap->cand_cstride_b[kc]));
             };
             load_cands(0);
             load_cands(1);
@@ -315,9 +338,12 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             // its end the candidates have returned, and that is where this wave's LDS-DMA pieces of tile k + 2 go: an LDS-DMA instruction
             // waits for every earlier vector-memory operation of its wave, so here it costs its own round trip only.
             const bool live = c_li < h && c_lj < w;
-            const float t = a.t[c_n];
+            const float t = args()->t[c_n];
             const double w1 = (double)t, w0 = (double)(1.0f - t);
             const double inv_T = 1.0 / a.T;
+            // out = sum_k wo_k cand_k / sum_k wo_k with wo_k = w_k softmax_k (fLDRnet.py:517-524): the softmax's own normalisation cancels
+            // in that quotient, so the weights stay unnormalised (w_k exp(s_k - max)) — one fp64 division and six products per pixel less
+            // than the literal order; the quotient differs from it by rounding only (~1e-16 relative)
             double wo[2][6], inv_div[2];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
@@ -325,22 +351,18 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                 double s[6], mx = -1.0e300;
 #pragma unroll
                 for (int kc = 0; kc < 6; ++kc) { s[kc] = (double)acc3[rb][kc] * inv_T; mx = s[kc] > mx ? s[kc] : mx; }
-                double sum = 0.0;
 #pragma unroll
-                for (int kc = 0; kc < 6; ++kc) { s[kc] = exp(s[kc] - mx); sum += s[kc]; }
-                const double inv_sum = 1.0 / sum;
-#pragma unroll
-                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * (s[kc] * inv_sum);
+                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * exp(s[kc] - mx);
                 double div = ((wo[rb][0] + wo[rb][1]) + wo[rb][2]) + wo[rb][3];      // fLDRnet.py:517
                 div = div + (wo[rb][4] + wo[rb][5]);                                // :522
-                inv_div[rb] = 1.0 / div;
+                inv_div[rb] = d23_rcp(div);
             }
             D23_STAMP(st4)
             if (k + 2 < my_tiles) stage_mine(k + 2);                        // into the window set produce(k) read before the last barrier
             D23_STAMP(st5)
             if (live) {
 #pragma clang fp contract(off)
-                OUT* out = static_cast<OUT*>(a.out);
+                OUT* out = static_cast<OUT*>(args()->out);
                 const int64_t po = (int64_t)(2 * c_li + ra) * a.W + 2 * c_lj;
                 double res[2][3];
 #pragma unroll
@@ -384,6 +406,10 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
     } else {
     // =============================== PRODUCER (waves 8-11): dec2 of one tile ===============================
         const int pw = wv - 8;                                               // producer wave 0 .. 3
+#ifndef D23_PRIO
+#define D23_PRIO 0
+#endif
+        __builtin_amdgcn_s_setprio(D23_PRIO);                                // the producer is the longer chain of the period: its instructions go first
         // Which tile pixel a lane's MFMA column is: the (8 + 2) x (32 + 2) tile splits into four parity classes (row & 1, column & 1) of
         // 5 x 17 pixels; a lane serves ONE class (ln & 3) in all its blocks — pixel index inside the class = 4 block + (ln >> 2), 22 blocks
         // (+ 2 of padding) over 4 waves.  With the parities fixed per lane, the nearest-x2 index of a dec1 tap (dy, dx) is
