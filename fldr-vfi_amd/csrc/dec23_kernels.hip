@@ -169,14 +169,16 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
     // with ordinary loads at the start of their period and write them to LDS at its end.
     struct Piece { const unsigned char* g; int lds; };
     // piece e of a tile's windows; `rc` = (row << 8 | column) of this lane's slot inside the window
-    auto piece_rc = [&](int e) __attribute__((always_inline)) -> int {
+    auto piece_rc = [&](int e, int ln_) __attribute__((always_inline)) -> int {
         if (e < 28) {
             const int i = e - ((e * 37) >> 8) * 7;                       // e % 7 for e < 28
-            const int sl = (i < 6 ? i * 64 : D23_EH * D23_EW - 64) + lane;
-            return ((sl / D23_EW) << 8) | (sl % D23_EW);
+            const int sl = (i < 6 ? i * 64 : D23_EH * D23_EW - 64) + ln_;
+            const int r = (sl * 57) >> 11;                               // sl / 36 for sl < 432
+            return (r << 8) | (sl - r * D23_EW);
         }
-        const int sl = ((e & 1) ? D23_QH * D23_QW - 64 : 0) + lane;
-        return ((sl / D23_QW) << 8) | (sl % D23_QW);
+        const int sl = ((e & 1) ? D23_QH * D23_QW - 64 : 0) + ln_;
+        const int r = (sl * 57) >> 10;                                   // sl / 18 for sl < 108
+        return (r << 8) | (sl - r * D23_QW);
     };
     auto piece_of = [&](int e, int rc, int n, int i0, int j0, int set) __attribute__((always_inline)) -> Piece {
         Piece r;
@@ -200,25 +202,22 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
         return r;
     };
     // The pieces of every later tile: with D23_CPIECES = 6 the consumer waves take all 44 (wave c: c + 8 j while < 44 — their period has
-    // slack at the barrier, the producer's has none), otherwise the producer waves share the rest.  The slot coordinates are kept packed,
-    // two pieces per register (the asm below stops the compiler from hoisting their unpacked forms and the address arithmetic out of the
-    // tile loop into a dozen more live registers — those were spilled, and every reload of a spill is a vmcnt(0) in the middle of the tile).
+    // slack at the barrier, the producer's has none), otherwise the producer waves share the rest.  The slot coordinates are recomputed
+    // per tile from an opaque copy of the lane number (a handful of vector instructions): left to itself the compiler hoists them and the
+    // address arithmetic out of the tile loop into a dozen live registers — those were spilled, and every reload of a spill is an
+    // s_waitcnt vmcnt(0) in the middle of the tile.
     constexpr int PREST = (44 - 8 * D23_CPIECES + 3) / 4;                // pieces per producer wave (0 when the consumers take all)
     const int my_e0 = consumer ? wv : 8 * D23_CPIECES + (wv - 8), my_de = consumer ? 8 : 4;
-    int my_rc2[(D23_CPIECES + 1) / 2];
-#pragma unroll
-    for (int j = 0; j < (D23_CPIECES + 1) / 2; ++j)
-        my_rc2[j] = piece_rc(min(my_e0 + my_de * (2 * j), 43)) | (piece_rc(min(my_e0 + my_de * (2 * j + 1), 43)) << 16);
     auto stage_mine = [&](int k) __attribute__((always_inline)) {
         int n, i0, j0;
         tile_of(k, n, i0, j0);
+        int ln_op = lane;
+        asm volatile("" : "+v"(ln_op));                                  // (opaque: the slot arithmetic below stays inside the tile loop)
 #pragma unroll
         for (int j = 0; j < D23_CPIECES; ++j) {
             const int e = my_e0 + my_de * j;
             if (e < 44 && (consumer || j < PREST)) {                     // wave-uniform
-                int rc2 = my_rc2[j >> 1];
-                asm volatile("" : "+v"(rc2));
-                const Piece pc = piece_of(e, (rc2 >> (16 * (j & 1))) & 0xFFFF, n, i0, j0, k & 1);
+                const Piece pc = piece_of(e, piece_rc(e, ln_op), n, i0, j0, k & 1);
                 d23_dma(pc.g, smem + pc.lds);
             }
         }
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
         int n, i0, j0;
         tile_of(0, n, i0, j0);
         for (int e = wv; e < 44; e += D23_THREADS / 64) {
-            const Piece pc = piece_of(e, piece_rc(e), n, i0, j0, 0);
+            const Piece pc = piece_of(e, piece_rc(e, lane), n, i0, j0, 0);
             d23_dma(pc.g, smem + pc.lds);
         }
     }
@@ -344,15 +343,18 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             // out = sum_k wo_k cand_k / sum_k wo_k with wo_k = w_k softmax_k (fLDRnet.py:517-524): the softmax's own normalisation cancels
             // in that quotient, so the weights stay unnormalised (w_k exp(s_k - max)) — one fp64 division and six products per pixel less
             // than the literal order; the quotient differs from it by rounding only (~1e-16 relative)
+            // Instruction diet of the same quotient (every step changes the literal order's result by rounding only, ~1e-16 relative, against
+            // a 3e-6 bound): the maximum is taken on the fp32 logits (x -> x / T is monotone), logit / T - max is one fma, and the blend below
+            // is an fma chain.
             double wo[2][6], inv_div[2];
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-#pragma clang fp contract(off)
-                double s[6], mx = -1.0e300;
+                float mx32 = acc3[rb][0];
 #pragma unroll
-                for (int kc = 0; kc < 6; ++kc) { s[kc] = (double)acc3[rb][kc] * inv_T; mx = s[kc] > mx ? s[kc] : mx; }
+                for (int kc = 1; kc < 6; ++kc) mx32 = fmaxf(mx32, acc3[rb][kc]);
+                const double nmx = -((double)mx32 * inv_T);
 #pragma unroll
-                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * exp(s[kc] - mx);
+                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * exp(__builtin_fma((double)acc3[rb][kc], inv_T, nmx));
                 double div = ((wo[rb][0] + wo[rb][1]) + wo[rb][2]) + wo[rb][3];      // fLDRnet.py:517
                 div = div + (wo[rb][4] + wo[rb][5]);                                // :522
                 inv_div[rb] = d23_rcp(div);
@@ -369,12 +371,9 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                     for (int ch = 0; ch < 3; ++ch) {
-                        double v[6];
+                        double o = wo[rb][0] * (double)(rb ? cv[0][ch].y : cv[0][ch].x);       // :518-521
 #pragma unroll
-                        for (int kc = 0; kc < 6; ++kc) v[kc] = wo[rb][kc] * (double)(rb ? cv[kc][ch].y : cv[kc][ch].x);
-                        double o = v[0] + v[1];                                 // :518
-                        o = o + (v[2] + v[3]);                                  // :520
-                        o = o + (v[4] + v[5]);                                  // :521
+                        for (int kc = 1; kc < 6; ++kc) o = __builtin_fma(wo[rb][kc], (double)(rb ? cv[kc][ch].y : cv[kc][ch].x), o);
                         res[rb][ch] = o * inv_div[rb];                          // :524
                     }
 #pragma unroll
@@ -406,10 +405,6 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
     } else {
     // =============================== PRODUCER (waves 8-11): dec2 of one tile ===============================
         const int pw = wv - 8;                                               // producer wave 0 .. 3
-#ifndef D23_PRIO
-#define D23_PRIO 0
-#endif
-        __builtin_amdgcn_s_setprio(D23_PRIO);                                // the producer is the longer chain of the period: its instructions go first
         // Which tile pixel a lane's MFMA column is: the (8 + 2) x (32 + 2) tile splits into four parity classes (row & 1, column & 1) of
         // 5 x 17 pixels; a lane serves ONE class (ln & 3) in all its blocks — pixel index inside the class = 4 block + (ln >> 2), 22 blocks
         // (+ 2 of padding) over 4 waves.  With the parities fixed per lane, the nearest-x2 index of a dec1 tap (dy, dx) is
