@@ -394,7 +394,8 @@ _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 #            compiled into the TEST build only since round 4 (cross-check of acc64): selecting it outside fldr_hip.test_hooks() raises.
 # Environment switches of the product path (everything else below is a module attribute that tests / tools flip to reach a cross-check
 # kernel, not a deployment knob): FLDR_SPLAT (operator-level splat kernel), FLDR_SPLAT_FEATURES=gather (deterministic feature splats),
-# FLDR_PCA_F32=1 (fp32 PCA residual), FLDR_CONV_PRECISION (split | fp32 | fp16), FLDR_LIB (an experimental build of the library).
+# FLDR_PCA_F32=1 (fp32 PCA residual), FLDR_DEC23=0 (dec2 and dec3 as two kernels), FLDR_CONV_PRECISION (split | fp32 | fp16), FLDR_LIB (an
+# experimental build of the library).
 SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
 # Warped feature maps of the flow estimator (fLDRnet.py:386-387): "strip" (default) = the global-atomic scatter kernel +
 # normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
@@ -1348,6 +1349,7 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
 
 
 # dec2 -> dec3 -> blend in one persistent producer / consumer kernel (fldr_dec23_synth): dec2's packed output never reaches HBM
+# (FLDR_DEC23=0: conv2d_spk + dec3_synth, the form the fused kernel is tested against)
 DEC23_FUSED = os.environ.get("FLDR_DEC23", "1") != "0"
 
 

@@ -416,11 +416,13 @@ FLDR_API int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const floa
 
 /* dec2 -> dec3 -> softmax / blend in ONE persistent kernel (csrc/dec23_kernels.hip; fLDRnet.py:638-643, 511-524): dec2 = ReLU(conv3x3(
  * cat(nearest-x2(dec1), enc1)) + bias), 48 -> 16 channels at half resolution, is produced tile by tile in LDS by four waves of a
- * workgroup while four others run fldr_dec3_synth_spk's matrix phases and fp64 tail on the previous tile: dec2's output (141 MB at 4K)
- * is never written or read back.  dec1_spk: packed 32 channels at [H/4, W/4]; enc1_spk: packed 16 channels at [H/2, W/2] (whole tensors:
+ * persistent workgroup while eight others run fldr_dec3_synth_spk's matrix phases and the fp64 tail on the previous tile: dec2's output
+ * (141 MB at 4K) is never written or read back.  dec1_spk: packed 32 channels at [H/4, W/4]; enc1_spk: packed 16 channels at [H/2, W/2] (whole tensors:
  * fldr_spk_bytes per sample); w2pack: fldr_dec23_prepack(dec2.weight [16,48,3,3]) (fldr_dec23_prepack_size floats, 16-byte aligned);
- * w3m: fldr_dec3_prepack_spk(dec3.weight); candidates / t / T / outputs as fldr_dec3_synth_spk.  H, W multiples of 4.  Results agree with
- * fldr_conv2d_spk + fldr_dec3_synth_spk to fp32 accumulation rounding (the tap-major summation order of its dec2 differs). */
+ * w3m: fldr_dec3_prepack_spk(dec3.weight); candidates / t / T / outputs as fldr_dec3_synth_spk.  H, W multiples of 4.  Candidates may be
+ * views (per-candidate strides, as I0 / I1 are planes of the frame-pair tensor).  Results agree with fldr_conv2d_spk + fldr_dec3_synth_spk
+ * to fp32 accumulation rounding in dec2 (tap-major summation) and fp64 rounding in the tail (unnormalised softmax weights, fma blend:
+ * the same quotient). */
 FLDR_API int64_t fldr_dec23_prepack_size(void);
 FLDR_API int fldr_dec23_prepack(const float* dec2_weight, float* wpack, fldr_stream_t stream);
 FLDR_API int fldr_dec23_synth(const void* dec1_spk, const void* enc1_spk, const float* w2pack, const float* bias2, const float* w3m, const float* bias3,
