@@ -89,7 +89,8 @@ struct D23Args {
     uint32_t cand_cstride_b[6];
     const float* t;                // [N]
     double T;
-    void* out;                     // [N,3,H,W] fp64 or fp32
+    void* out;                     // [N,3,H,W] fp64 or fp32, or the rounded 8-bit frame [N,3,Hc,Wc] (cropped; Wc even)
+    int Hc, Wc;
     int N, H, W;                   // full resolution
     int tiles_x, per_sample, total, per_xcd, wgs_per_xcd;
 };
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             // fp64 softmax / T + blend of the quad's row `ra` (final_kernels.hip, same arithmetic).  The softmax half needs no candidate; by
             // its end the candidates have returned, and that is where this wave's LDS-DMA pieces of tile k + 2 go: an LDS-DMA instruction
             // waits for every earlier vector-memory operation of its wave, so here it costs its own round trip only.
-            const bool live = c_li < h && c_lj < w;
+            const bool live = c_li < h && c_lj < w && (sizeof(OUT) != 1 || (2 * c_li + ra < a.Hc && 2 * c_lj < a.Wc));
             const float t = args()->t[c_n];
             const double w1 = (double)t, w0 = (double)(1.0f - t);
             const double inv_T = 1.0 / a.T;
@@ -365,7 +366,6 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             if (live) {
 #pragma clang fp contract(off)
                 OUT* out = static_cast<OUT*>(args()->out);
-                const int64_t po = (int64_t)(2 * c_li + ra) * a.W + 2 * c_lj;
                 double res[2][3];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
@@ -376,11 +376,30 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                         for (int kc = 1; kc < 6; ++kc) o = __builtin_fma(wo[rb][kc], (double)(rb ? cv[kc][ch].y : cv[kc][ch].x), o);
                         res[rb][ch] = o * inv_div[rb];                          // :524
                     }
+                if constexpr (sizeof(OUT) == 1) {
+                    // the rounded 8-bit frame (fldr_frame_metrics' arithmetic: utils.py:685-688, np.around), cropped to Hc x Wc: two pixels = one
+                    // 16-bit store per channel — three stores behind the DMA pieces, as the frame's
+                    const uint32_t po = (uint32_t)(2 * c_li + ra) * (uint32_t)a.Wc + (uint32_t)(2 * c_lj);
 #pragma unroll
-                for (int ch = 0; ch < 3; ++ch) {
-                    char* o = reinterpret_cast<char*>(out + ((int64_t)c_n * 3 + ch) * HW) + (uint32_t)po * (uint32_t)sizeof(OUT);
-                    if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0][ch], res[1][ch]);
-                    else *reinterpret_cast<float2*>(o) = make_float2((float)res[0][ch], (float)res[1][ch]);
+                    for (int ch = 0; ch < 3; ++ch) {
+                        unsigned q[2];
+#pragma unroll
+                        for (int rb = 0; rb < 2; ++rb) {
+                            double v = (res[rb][ch] + 1.0) / 2.0;
+                            v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+                            q[rb] = (unsigned)(int)rint(v * 255.0);
+                        }
+                        unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((int64_t)c_n * 3 + ch) * ((int64_t)a.Hc * a.Wc) + po;
+                        *reinterpret_cast<unsigned short*>(o) = (unsigned short)(q[0] | (q[1] << 8));
+                    }
+                } else {
+                    const int64_t po = (int64_t)(2 * c_li + ra) * a.W + 2 * c_lj;
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) {
+                        char* o = reinterpret_cast<char*>(out + ((int64_t)c_n * 3 + ch) * HW) + (uint32_t)po * (uint32_t)sizeof(OUT);
+                        if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0][ch], res[1][ch]);
+                        else *reinterpret_cast<float2*>(o) = make_float2((float)res[0][ch], (float)res[1][ch]);
+                    }
                 }
             }
             // (the barrier's vmcnt(3) counts on three stores behind the DMA pieces: a wave with no live pixel waits for everything)
@@ -587,9 +606,14 @@ extern "C" int fldr_dec23_prepack(const float* dec2_weight, float* wpack, fldr_s
 
 extern "C" int fldr_dec23_synth(const void* dec1_spk, const void* enc1_spk, const float* w2pack, const float* bias2, const float* w3m, const float* bias3,
                                 const float* const cand[6], const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
-                                double* out_f64, float* out_f32, int N, int H, int W, fldr_stream_t stream) {
+                                double* out_f64, float* out_f32, uint8_t* out_u8, int H_u8, int W_u8, int N, int H, int W, fldr_stream_t stream) {
     FLDR_CHECK_ARG(dec1_spk && enc1_spk && w2pack && bias2 && w3m && bias3 && cand && cand_bstride && cand_cstride && t && N > 0 && H > 0 && W > 0);
-    FLDR_CHECK_ARG((out_f64 != nullptr) != (out_f32 != nullptr));
+    FLDR_CHECK_ARG((out_f64 != nullptr) + (out_f32 != nullptr) + (out_u8 != nullptr) == 1);
+    if (out_u8) {                                                        // the cropped 8-bit frame: pairs of pixels are stored together
+        FLDR_CHECK_ARG(H_u8 > 0 && W_u8 > 0 && H_u8 <= H && W_u8 <= W && (reinterpret_cast<uintptr_t>(out_u8) & 1) == 0);
+        if (W_u8 & 1) return FLDR_E_SHAPE;
+        if ((int64_t)H_u8 * W_u8 >= (1ll << 31)) return FLDR_E_SHAPE;
+    }
     if ((H | W) & 3) return FLDR_E_SHAPE;                                // dec1 lives at a quarter of the resolution
     if ((int64_t)H * W * 8 >= (1ll << 32)) return FLDR_E_SHAPE;          // 32-bit byte offsets inside a plane
     FLDR_CHECK_ARG(((reinterpret_cast<uintptr_t>(out_f64) & 15) | (reinterpret_cast<uintptr_t>(out_f32) & 7)) == 0);
@@ -602,7 +626,8 @@ extern "C" int fldr_dec23_synth(const void* dec1_spk, const void* enc1_spk, cons
         if (cand_cstride[k] < 0 || cand_bstride[k] < 0 || 2 * cand_cstride[k] * 4 + (int64_t)H * W * 4 >= (1ll << 32)) return FLDR_E_SHAPE;   // 32-bit offsets inside a sample
         a.cand[k] = cand[k]; a.cand_bstride_b[k] = cand_bstride[k] * 4; a.cand_cstride_b[k] = (uint32_t)(cand_cstride[k] * 4);
     }
-    a.t = t; a.T = T_param; a.out = out_f64 ? static_cast<void*>(out_f64) : static_cast<void*>(out_f32);
+    a.t = t; a.T = T_param; a.out = out_f64 ? static_cast<void*>(out_f64) : (out_f32 ? static_cast<void*>(out_f32) : static_cast<void*>(out_u8));
+    a.Hc = out_u8 ? H_u8 : H; a.Wc = out_u8 ? W_u8 : W;
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = fldr_cdiv(W / 2, D23_TW);
     a.per_sample = a.tiles_x * fldr_cdiv(H / 2, D23_TH);
@@ -610,13 +635,16 @@ extern "C" int fldr_dec23_synth(const void* dec1_spk, const void* enc1_spk, cons
     a.total = a.per_sample * N;
     a.per_xcd = (a.total + 7) / 8;
     a.wgs_per_xcd = a.per_xcd < 32 ? a.per_xcd : 32;                     // one workgroup per CU (159 KB of LDS)
-    static std::atomic<uint64_t> attr64{0}, attr32{0};
+    static std::atomic<uint64_t> attr64{0}, attr32{0}, attr8{0};
     if (out_f64) {
         if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&dec23_synth_kernel<double>), D23_LDS, attr64)) return e;
         hipLaunchKernelGGL((dec23_synth_kernel<double>), dim3(8 * a.wgs_per_xcd), dim3(D23_THREADS), D23_LDS, fldr_s(stream), a);
-    } else {
+    } else if (out_f32) {
         if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&dec23_synth_kernel<float>), D23_LDS, attr32)) return e;
         hipLaunchKernelGGL((dec23_synth_kernel<float>), dim3(8 * a.wgs_per_xcd), dim3(D23_THREADS), D23_LDS, fldr_s(stream), a);
+    } else {
+        if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&dec23_synth_kernel<uint8_t>), D23_LDS, attr8)) return e;
+        hipLaunchKernelGGL((dec23_synth_kernel<uint8_t>), dim3(8 * a.wgs_per_xcd), dim3(D23_THREADS), D23_LDS, fldr_s(stream), a);
     }
     FLDR_LAUNCH_RET();
 }

@@ -179,6 +179,7 @@ class DCTXVFInet(nn.Module):
 class DCTVFInet(nn.Module):
     def __init__(self, args, output_size, output_size_test, output_size_val):
         super().__init__()
+        self.emit_u8 = None      # (H, W): the next forward returns the cropped 8-bit frame (fldr_harness.interpolate_u8)
         self.args = args
         self.device = torch.device('cuda:' + str(args.gpu) if torch.cuda.is_available() else 'cpu')
         self.nf = nf = int(args.dctvfi_nf * args.img_ch)
@@ -339,7 +340,10 @@ class DCTVFInet(nn.Module):
                 and tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and tuple(unet.dec2.weight.shape) == (16, 48, 3, 3)):
             # dec2 + dec3 + softmax/T + blend in one persistent kernel: neither dec2's output nor refine_out is ever stored
             dec1p, enc1p = unet.forward_until_dec1(srcs)
-            out = fldr_hip.dec23_synth(dec1p, enc1p, unet.dec2.weight, unet.dec2.bias, unet.dec3.weight, unet.dec3.bias, cands, t4, T)
+            # emit_u8 = (H, W) (set by fldr_harness.interpolate_u8 around a call): the cropped frame rounded to 8 bits comes straight out of
+            # the kernel's fp64 blend instead of the fp64 frame (run_on_your_images.py:100-109 needs nothing else)
+            out = fldr_hip.dec23_synth(dec1p, enc1p, unet.dec2.weight, unet.dec2.bias, unet.dec3.weight, unet.dec3.bias, cands, t4, T,
+                                       u8_crop=getattr(self, "emit_u8", None))
         elif tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and H % 2 == 0 and W % 2 == 0:
             # dec3 + softmax/T + blend in one kernel; refine_out (6 full-resolution planes) is never stored
             out = fldr_hip.dec3_synth(unet.forward_until_dec2(srcs, packed_out=fldr_hip.DEC3_MFMA and fldr_hip.use_spk()),

@@ -232,6 +232,9 @@ def interpolate_multi(model, args, frames, t_values, pyramid=None, streams=None)
     return outs
 
 
+U8_DIRECT = True      # interpolate_u8 without a ground truth: the 8-bit frame straight from the synthesis kernel (False: fp64 frame + fldr_frame_metrics)
+
+
 def interpolate_u8(model, args, frames_u8, t_value, target_u8=None, want_ssim=False):
     """End-to-end on the device: uint8 frames [B,2,3,H,W] (I0, I1) -> normalise + reflect pad + bicubic pyramid
     (fldr_ingest_u8 / fldr_pyramid_bicubic) -> forward -> rounded uint8 frame [B,3,H,W] (and, with a uint8 ground
@@ -241,7 +244,19 @@ def interpolate_u8(model, args, frames_u8, t_value, target_u8=None, want_ssim=Fa
     B, T, C, H, W = frames_u8.shape
     with torch.no_grad():
         pyr = fldr_hip.ingest_pyramid(frames_u8, args.S_tst + 1)
-        pred, _ = model([None] * (args.S_tst + 1), t_value, normInput=pyr, is_training=False, validation=False)
+        # without a ground truth nothing but the rounded frame is wanted: the fused synthesis kernel emits it directly (the fp64 frame is
+        # then never written); the model ignores the request on the paths that cannot honour it and returns the fp64 frame as ever
+        vfi = getattr(model, "vfinet", None)
+        direct = U8_DIRECT and target_u8 is None and vfi is not None and W % 2 == 0
+        if direct:
+            vfi.emit_u8 = (H, W)
+        try:
+            pred, _ = model([None] * (args.S_tst + 1), t_value, normInput=pyr, is_training=False, validation=False)
+        finally:
+            if direct:
+                vfi.emit_u8 = None
+        if pred.dtype == torch.uint8:
+            return pred.contiguous(), None
         sse, img = fldr_hip.frame_metrics(pred, min(H, pred.shape[2]), min(W, pred.shape[3]), target_u8, want_u8=True)
         ssim = fldr_hip.ssim_y_u8(img, target_u8) if (want_ssim and target_u8 is not None) else None
     if sse is None:

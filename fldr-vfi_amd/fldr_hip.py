@@ -184,8 +184,8 @@ _SIGNATURES = {
     "fldr_dec23_prepack_size": (ctypes.c_int64, []),
     "fldr_dec23_prepack": (ctypes.c_int, [_c_float_p, _c_float_p, ctypes.c_void_p]),
     "fldr_dec23_synth": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_p, _c_float_p, _c_float_p, _c_float_p, ctypes.POINTER(ctypes.c_void_p),
-                                        ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p]
-                         + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
+                                        ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64), _c_float_p, ctypes.c_double, _c_float_p, _c_float_p,
+                                        ctypes.c_void_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_ingest_u8": (ctypes.c_int, [ctypes.c_void_p, _c_float_p] + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_pyramid_bicubic": (ctypes.c_int, [_c_float_p, _c_float_p] + [ctypes.c_int] * 4 + [ctypes.c_void_p]),
     "fldr_ingest_pyramid_u8": (ctypes.c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)] + [ctypes.c_int] * 6 + [ctypes.c_void_p]),
@@ -201,7 +201,7 @@ _TEST_BUILD_ONLY = ("fldr_softsplat_tile", "fldr_softsplat_tile_strided", "fldr_
 EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_") and n not in _TEST_BUILD_ONLY)
 HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_") or n in _TEST_BUILD_ONLY)
 TEST_LIB_PATH = os.path.join(_HERE, "libfldr_hip_test.so")
-ABI_VERSION = 103                # include/fldr_hip.h: FLDR_VERSION
+ABI_VERSION = 104                # include/fldr_hip.h: FLDR_VERSION
 # entry points the DEFAULT 4K forward / bench / harness call: a variant library (FLDR_LIB) that lacks one of them fails at load
 _DEFAULT_PATH = ("fldr_version", "fldr_error_string", "fldr_sizeof_desc", "fldr_range_status", "fldr_ring_status", "fldr_pca_prepack",
                  "fldr_pca_project_pyramid", "fldr_conv2d_spk", "fldr_conv2d_spk_levels", "fldr_conv_spk_prepack", "fldr_conv2d_s2_split",
@@ -1353,9 +1353,11 @@ def dec3_synth(d2, weight, bias, cands, t, T_param, out_dtype=torch.float64, wan
 DEC23_FUSED = os.environ.get("FLDR_DEC23", "1") != "0"
 
 
-def dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, T_param, out_dtype=torch.float64):
+def dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, T_param, out_dtype=torch.float64, u8_crop=None):
     """PCARefineUNet.dec2 (on cat(nearest-x2(dec1), enc1), ReLU) + dec3 (on the nearest-x2 upsampled result) + softmax / T + blend
-    (fLDRnet.py:638-643, 511-524) in one kernel.  dec1p: Spk [N,32,H/4,W/4]; enc1p: Spk [N,16,H/2,W/2]; w2 [16,48,3,3], w3 [6,16,3,3]."""
+    (fLDRnet.py:638-643, 511-524) in one kernel.  dec1p: Spk [N,32,H/4,W/4]; enc1p: Spk [N,16,H/2,W/2]; w2 [16,48,3,3], w3 [6,16,3,3].
+    u8_crop = (Hc, Wc) (Wc even): instead of the fp64 / fp32 frame, the frame cropped to Hc x Wc and rounded to 8 bits
+    (frame_metrics' arithmetic) as a uint8 tensor [N,3,Hc,Wc]."""
     N, c1, h4, w4 = dec1p.shape
     N2, c2, h, w = enc1p.shape
     assert isinstance(dec1p, Spk) and isinstance(enc1p, Spk) and N == N2 and c1 == 32 and c2 == 16 and h == 2 * h4 and w == 2 * w4
@@ -1386,11 +1388,19 @@ def dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, T_param, out_dtype=torch
         keep.append(c)
         ptrs[k] = c.data_ptr()
     t = t.reshape(N).contiguous().float()
-    out = torch.empty(N, 3, H, W, device=w2.device, dtype=out_dtype)
-    o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
-    o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
+    o64 = o32 = o8 = None
+    hc = wc = 0
+    if u8_crop is not None:
+        hc, wc = int(u8_crop[0]), int(u8_crop[1])
+        assert 0 < hc <= H and 0 < wc <= W and wc % 2 == 0
+        out = torch.empty(N, 3, hc, wc, device=w2.device, dtype=torch.uint8)
+        o8 = _dev(out, "out", torch.uint8)
+    else:
+        out = torch.empty(N, 3, H, W, device=w2.device, dtype=out_dtype)
+        o64 = _dev(out, "out", torch.float64) if out_dtype == torch.float64 else None
+        o32 = _dev(out, "out", torch.float32) if out_dtype == torch.float32 else None
     _check(lib().fldr_dec23_synth(ctypes.c_void_p(dec1p.ptr), ctypes.c_void_p(enc1p.ptr), _dev(w2p, "w2pack"), _dev(b2.detach(), "bias2"), _dev(w3m, "w3m"),
-                                  _dev(b3.detach(), "bias3"), ptrs, strides, cstrides, _dev(t, "t"), float(T_param), o64, o32, N, H, W, _stream()),
+                                  _dev(b3.detach(), "bias3"), ptrs, strides, cstrides, _dev(t, "t"), float(T_param), o64, o32, o8, hc, wc, N, H, W, _stream()),
            "fldr_dec23_synth")
     return out
 

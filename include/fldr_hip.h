@@ -22,9 +22,10 @@
 extern "C" {
 #endif
 
-#define FLDR_VERSION 103          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_sizeof_desc(3..5);
+#define FLDR_VERSION 104          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_sizeof_desc(3..5);
                                      103: fldr_range_status is 0 / 1 again, the ring status has its own entry (fldr_ring_status),
-                                     fldr_enc1_fused — a caller built against an older header must be rebuilt */
+                                     fldr_enc1_fused; 104: fldr_dec23_prepack / fldr_dec23_synth (with the rounded 8-bit frame as a
+                                     third output form) — a caller built against an older header must be rebuilt */
 
 #define FLDR_E_ARG   (-1)         /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define FLDR_E_SHAPE (-2)         /* shape constraint violated (e.g. H,W not multiples of 8 for the PCA) */
@@ -422,12 +423,14 @@ FLDR_API int fldr_dec3_synth_spk(const void* d2_spk, const float* wm, const floa
  * w3m: fldr_dec3_prepack_spk(dec3.weight); candidates / t / T / outputs as fldr_dec3_synth_spk.  H, W multiples of 4.  Candidates may be
  * views (per-candidate strides, as I0 / I1 are planes of the frame-pair tensor).  Results agree with fldr_conv2d_spk + fldr_dec3_synth_spk
  * to fp32 accumulation rounding in dec2 (tap-major summation) and fp64 rounding in the tail (unnormalised softmax weights, fma blend:
- * the same quotient). */
+ * the same quotient).  Exactly one of out_f64 / out_f32 / out_u8: out_u8 [N,3,H_u8,W_u8] is the frame cropped to H_u8 x W_u8 (W_u8
+ * even), rounded to 8 bits with fldr_frame_metrics' arithmetic (utils.py:685-688, np.around) straight from the fp64 blend — the
+ * uint8-in / uint8-out callers (run_on_your_images.py:100-109) then never write or re-read the 212 MB fp64 frame. */
 FLDR_API int64_t fldr_dec23_prepack_size(void);
 FLDR_API int fldr_dec23_prepack(const float* dec2_weight, float* wpack, fldr_stream_t stream);
 FLDR_API int fldr_dec23_synth(const void* dec1_spk, const void* enc1_spk, const float* w2pack, const float* bias2, const float* w3m, const float* bias3,
                      const float* const cand[6], const int64_t cand_bstride[6], const int64_t cand_cstride[6], const float* t, double T_param,
-                     double* out_f64, float* out_f32, int N, int H, int W, fldr_stream_t stream);
+                     double* out_f64, float* out_f32, uint8_t* out_u8, int H_u8, int W_u8, int N, int H, int W, fldr_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Callers either side of the path, on the device (the reference does these on the CPU).

@@ -1581,6 +1581,47 @@ def test_gpu_metrics_and_u8_roundtrip(hip, oracle, weights, dev, model):
     assert abs(ps[0] - want) < 1e-9
 
 
+@pytest.mark.parametrize("size", [(256, 384), (200, 330), (270, 482), (200, 331)])
+def test_interpolate_u8_direct_frame_equals_rounded_fp64_frame(hip, dev, model, size):
+    """Without a ground truth interpolate_u8 takes the rounded 8-bit frame straight out of the fused synthesis kernel (fldr_dec23_synth's
+    out_u8: the fp64 frame is never written): the same bytes as rounding the fp64 frame with fldr_frame_metrics — sizes that need
+    padding and a crop, an odd width (falls back to the fp64 frame + frame_metrics)."""
+    import fldr_harness as Hn
+    m, a = model
+    H, W = size
+    u8 = Hn.synthetic_pair(H, W, seed=21).unsqueeze(0).to(dev)
+    t = torch.tensor([[0.5]], device=dev)
+    img, none = Hn.interpolate_u8(m, a, u8, t)
+    assert none is None and img.dtype == torch.uint8 and img.shape == (1, 3, H, W)
+    assert m.vfinet.emit_u8 is None
+    with torch.no_grad():
+        pyr = hip.ingest_pyramid(u8, a.S_tst + 1)
+        pred, _ = m([None] * (a.S_tst + 1), t, normInput=pyr, is_training=False, validation=False)
+    assert pred.dtype == torch.float64
+    _, ref = hip.frame_metrics(pred, H, W, None, want_u8=True)
+    assert torch.equal(img, ref)
+    hip.check_range()
+
+
+def test_dec23_synth_u8_output_with_crop(hip, dev):
+    """fldr_dec23_synth's third output form against its fp64 frame rounded by fldr_frame_metrics: crops that cut tiles, two samples."""
+    g = _gen(46)
+    N, h, w = 2, 40, 72
+    dec1p = hip.spk_pack((torch.rand(N, 32, h // 2, w // 2, generator=g) * 1.5).to(dev))
+    enc1p = hip.spk_pack((torch.rand(N, 16, h, w, generator=g) * 1.5).to(dev))
+    w2, b2 = (torch.randn(16, 48, 3, 3, generator=g) / 12).to(dev), (torch.randn(16, generator=g) * 0.2).to(dev)
+    w3, b3 = (torch.randn(6, 16, 3, 3, generator=g) / 6).to(dev), (torch.randn(6, generator=g) * 0.3).to(dev)
+    cands = [(torch.rand(N, 3, 2 * h, 2 * w, generator=g) * 2.4 - 1.2).to(dev) for _ in range(6)]      # beyond [-1, 1]: the clamp acts
+    t = torch.tensor([[0.25], [0.5]], device=dev)
+    frame = hip.dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, 1.5616)
+    for (Hc, Wc) in ((2 * h, 2 * w), (2 * h - 5, 2 * w - 6), (17, 34)):
+        got = hip.dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, 1.5616, u8_crop=(Hc, Wc))
+        _, ref = hip.frame_metrics(frame, Hc, Wc, None, want_u8=True)
+        assert got.dtype == torch.uint8 and got.shape == (N, 3, Hc, Wc) and torch.equal(got, ref)
+    with pytest.raises(Exception):
+        hip.dec23_synth(dec1p, enc1p, w2, b2, w3, b3, cands, t, 1.5616, u8_crop=(10, 11))      # odd width
+
+
 @pytest.mark.parametrize("size", [(96, 128), (61, 203), (7, 9), (540, 960)])
 def test_gpu_ssim_y_matches_oracle(hip, oracle, dev, size):
     """fldr_ssim_y_u8 (utils.ssim_bgr on the device, 8f-3) against the oracle's restatement on seeded frames, a batch of

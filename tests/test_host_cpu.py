@@ -39,8 +39,8 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in texported if not n.startswith("fldr_")], sorted(n for n in texported if not n.startswith("fldr_"))[:10]
     assert declared <= texported and texported - declared <= hooks_decl, sorted(texported - declared - hooks_decl)
     assert set(fldr_hip.HOOKS) <= texported, sorted(set(fldr_hip.HOOKS) - texported)
-    assert fldr_hip.lib().fldr_version() == 103 == fldr_hip.ABI_VERSION
-    assert re.search(r"#define FLDR_VERSION 103\b", hdr)
+    assert fldr_hip.lib().fldr_version() == 104 == fldr_hip.ABI_VERSION
+    assert re.search(r"#define FLDR_VERSION 104\b", hdr)
     assert fldr_hip.lib().fldr_error_string(-2) == b"fldr: shape constraint violated"
 
 
