@@ -361,7 +361,10 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                 inv_div[rb] = d23_rcp(div);
             }
             D23_STAMP(st4)
+            // (pinned between the candidates' last use above... and the frame stores below: the barrier's vmcnt(3) relies on exactly this order)
+            __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < my_tiles) stage_mine(k + 2);                        // into the window set produce(k) read before the last barrier
+            __builtin_amdgcn_sched_barrier(0);
             D23_STAMP(st5)
             if (live) {
 #pragma clang fp contract(off)
