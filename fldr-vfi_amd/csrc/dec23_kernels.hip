@@ -369,39 +369,35 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             if (live) {
 #pragma clang fp contract(off)
                 OUT* out = static_cast<OUT*>(args()->out);
-                double res[2][3];
+                // channel by channel: blend both pixels of the row, store (two values live, not six)
+                const uint32_t po8 = (uint32_t)(2 * c_li + ra) * (uint32_t)a.Wc + (uint32_t)(2 * c_lj);
+                const int64_t po = (int64_t)(2 * c_li + ra) * a.W + 2 * c_lj;
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int ch = 0; ch < 3; ++ch) {
+                    double res[2];
 #pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
+                    for (int rb = 0; rb < 2; ++rb) {
                         double o = wo[rb][0] * (double)(rb ? cv[0][ch].y : cv[0][ch].x);       // :518-521
 #pragma unroll
                         for (int kc = 1; kc < 6; ++kc) o = __builtin_fma(wo[rb][kc], (double)(rb ? cv[kc][ch].y : cv[kc][ch].x), o);
-                        res[rb][ch] = o * inv_div[rb];                          // :524
+                        res[rb] = o * inv_div[rb];                              // :524
                     }
-                if constexpr (sizeof(OUT) == 1) {
-                    // the rounded 8-bit frame (fldr_frame_metrics' arithmetic: utils.py:685-688, np.around), cropped to Hc x Wc: two pixels = one
-                    // 16-bit store per channel — three stores behind the DMA pieces, as the frame's
-                    const uint32_t po = (uint32_t)(2 * c_li + ra) * (uint32_t)a.Wc + (uint32_t)(2 * c_lj);
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
+                    if constexpr (sizeof(OUT) == 1) {
+                        // the rounded 8-bit frame (fldr_frame_metrics' arithmetic: utils.py:685-688, np.around), cropped to Hc x Wc: two pixels =
+                        // one 16-bit store per channel — three stores behind the DMA pieces, as the frame's
                         unsigned q[2];
 #pragma unroll
                         for (int rb = 0; rb < 2; ++rb) {
-                            double v = (res[rb][ch] + 1.0) / 2.0;
+                            double v = (res[rb] + 1.0) / 2.0;
                             v = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
                             q[rb] = (unsigned)(int)rint(v * 255.0);
                         }
-                        unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((int64_t)c_n * 3 + ch) * ((int64_t)a.Hc * a.Wc) + po;
+                        unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((int64_t)c_n * 3 + ch) * ((int64_t)a.Hc * a.Wc) + po8;
                         *reinterpret_cast<unsigned short*>(o) = (unsigned short)(q[0] | (q[1] << 8));
-                    }
-                } else {
-                    const int64_t po = (int64_t)(2 * c_li + ra) * a.W + 2 * c_lj;
-#pragma unroll
-                    for (int ch = 0; ch < 3; ++ch) {
+                    } else {
                         char* o = reinterpret_cast<char*>(out + ((int64_t)c_n * 3 + ch) * HW) + (uint32_t)po * (uint32_t)sizeof(OUT);
-                        if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0][ch], res[1][ch]);
-                        else *reinterpret_cast<float2*>(o) = make_float2((float)res[0][ch], (float)res[1][ch]);
+                        if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0], res[1]);
+                        else *reinterpret_cast<float2*>(o) = make_float2((float)res[0], (float)res[1]);
                     }
                 }
             }
