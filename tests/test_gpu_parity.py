@@ -242,6 +242,27 @@ def test_channel_strided_frames_read_in_place(hip, dev):
     assert torch.equal(hip.softsplat_fused(views[1], r["flow_t1"], r["z1"], "softmax"), w1)
 
 
+def test_model_fused_synthesis_matches_the_two_kernel_form(hip, dev, model):
+    """The model's default synthesis (fldr_dec23_synth: dec2 + dec3 + blend in one kernel) against its two-kernel form (conv2d_spk for dec2,
+    then dec3_synth — what FLDR_DEC23=0 selects and what sizes that are not multiples of 4 at half resolution fall back to): same frame to
+    fp32 accumulation rounding of dec2 + fp64 rounding of the tail."""
+    import fldr_harness as Hn
+    m, a = model
+    for (H, W, seed) in ((256, 384, 11), (200, 330, 12)):
+        f = Hn.frames_from_uint8(Hn.synthetic_pair(H, W, seed=seed)).to(dev)
+        t = torch.tensor([[0.375]], device=dev)
+        assert hip.DEC23_FUSED
+        fused = Hn.interpolate(m, a, f, t)
+        hip.DEC23_FUSED = False
+        try:
+            two = Hn.interpolate(m, a, f, t)
+        finally:
+            hip.DEC23_FUSED = True
+        assert fused.dtype == two.dtype == torch.float64 and fused.shape == two.shape == (1, 3, H, W)
+        _cmp(fused, two, atol=3e-6, what="fused synthesis vs dec2 + dec3 kernels %dx%d" % (H, W))
+    hip.check_range()
+
+
 def test_graphed_interpolator_replays_the_eager_forward(hip, dev, model):
     """fldr_harness.GraphedInterpolator (the opt-in hipGraph replay of the harness; bench.py's steps are its replays): captured on one
     pair, fed two other pairs of the same shape — every replay == the eager forward of that pair, bit for bit; a prebuilt pyramid as the
