@@ -52,6 +52,9 @@
 #ifndef D23_CPIECES
 #define D23_CPIECES 6                         // window pieces per consumer wave (of 44; the producer waves share the rest)
 #endif
+#ifndef D23_EXP
+#define D23_EXP d23_exp_nonpos
+#endif
 #ifndef D23_NB
 #define D23_NB 3                              // pixel blocks per fetch / MFMA unit of the producer (6 blocks per wave and K-step)
 #endif
@@ -118,6 +121,28 @@ __device__ __forceinline__ double d23_rcp(double x) {
     r = __builtin_fma(r, e, r);
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
+}
+
+// exp(x) for x <= 0 (a softmax argument after the maximum is subtracted) to ~1e-13 relative — three orders below what the fp32 logits carry —
+// in 16 instructions: n = round(x / ln 2), r = x - n ln 2 in two steps (|r| <= 0.347), the Taylor polynomial of degree 10 in Horner form
+// (|r|^11 / 11! < 2.2e-13), scaled by 2^n (v_ldexp_f64: anything below the denormals becomes 0, as exp's own underflow).  The library
+// exp costs ~24 with its range checks and its last two ulps.
+__device__ __forceinline__ double d23_exp_nonpos(double x) {
+    const double n = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(n, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(n, -1.90821492927058770002e-10, r);
+    double p = 2.7557319223985890653e-07;                               // 1 / 10!
+    p = __builtin_fma(p, r, 2.7557319223985892511e-06);                 // 1 / 9!
+    p = __builtin_fma(p, r, 2.4801587301587301566e-05);                 // 1 / 8!
+    p = __builtin_fma(p, r, 1.9841269841269841253e-04);                 // 1 / 7!
+    p = __builtin_fma(p, r, 1.3888888888888889419e-03);                 // 1 / 6!
+    p = __builtin_fma(p, r, 8.3333333333333332177e-03);                 // 1 / 5!
+    p = __builtin_fma(p, r, 4.1666666666666664354e-02);                 // 1 / 4!
+    p = __builtin_fma(p, r, 1.6666666666666665741e-01);                 // 1 / 3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)n);
 }
 
 template <int I, int N, typename F>
@@ -355,7 +380,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                 for (int kc = 1; kc < 6; ++kc) mx32 = fmaxf(mx32, acc3[rb][kc]);
                 const double nmx = -((double)mx32 * inv_T);
 #pragma unroll
-                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * exp(__builtin_fma((double)acc3[rb][kc], inv_T, nmx));
+                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * D23_EXP(__builtin_fma((double)acc3[rb][kc], inv_T, nmx));
                 double div = ((wo[rb][0] + wo[rb][1]) + wo[rb][2]) + wo[rb][3];      // fLDRnet.py:517
                 div = div + (wo[rb][4] + wo[rb][5]);                                // :522
                 inv_div[rb] = d23_rcp(div);
@@ -429,7 +454,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
         //     (cy + ((pyb + dy) >> 1), cx + ((pxb + dx) >> 1)) = (cy, cx) + {0, pyb, 1} rows + {0, pxb, 1} columns:
         // one register per block (qr) + three per lane (qsel) + an immediate, instead of four registers per block.
         const int pyb = ln & 1, pxb = (ln >> 1) & 1;
-        int pyx[6], qr[6], eoff[6], qsel[2][2];
+        int pyx[6], qr[6], eoff[6], soff[6], qsel[2][2];
         const bool etap1 = (lg >> 1) != 0;                                   // enc1 steps: this lane group's tap is 2 j + 1 (else 2 j)
         const int egrp = (lg & 1) * 2 * D23_EPLANE;
         float bias2_r[4];
@@ -442,6 +467,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                 const int py = 2 * cy + pyb, px = 2 * cx + pxb;
                 pyx[i] = (py << 8) | px;
                 eoff[i] = D23_OFF_WIN + (py * D23_EW + px) * 16;
+                soff[i] = (lg >> 1) * 2 * D23_OPLANE + (py * D23_OW + px) * 16 + (lg & 1) * 8;     // this lane's piece of the pixel's record in a tile buffer
                 qr[i] = D23_OFF_WIN + 4 * D23_EPLANE + 2 * lg * D23_QPLANE + (cy * D23_QW + cx) * 16;
             }
 #pragma unroll
@@ -505,25 +531,35 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             fetch(std::integral_constant<int, 0>{});
             d23_static_for<0, NU>(unit);
             D23_STAMP(st2)
-            // epilogue: scale, bias, ReLU, exact zeros outside the image, split, one 8-byte piece (4 channels) of the pixel's packed record
+            // epilogue: scale, bias, ReLU, exact zeros outside the image (tiles on the frame's border only: wave-uniform test), split with ONE
+            // range guard for the wave's 24 values, one 8-byte piece (4 channels) of each pixel's packed record
             unsigned char* tb = smem + D23_OFF_B + (k & 1) * 4 * D23_OPLANE;
+            const bool border = i0 < 1 || i0 + D23_TH + 1 > h || j0 < 1 || j0 + D23_TW + 1 > w;     // the 10 x 34 pixels are not all inside the image
+            float xs[24];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xs[4 * i + r] = fmaxf(acc[i][r] * inv_scale2 + bias2_r[r], 0.0f);
+            if (border) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const int gy = i0 - 1 + (pyx[i] >> 8), gx = j0 - 1 + (pyx[i] & 255);
+                    const bool inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xs[4 * i + r] = inside ? xs[4 * i + r] : 0.0f;
+                }
+            }
+            _Float16 hs[24], ls[24];
+            bool bad = false;
+            fldr_split_hl_group(xs, hs, ls, bad);
+            fldr_note_range(bad);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const int py = pyx[i] >> 8, px = pyx[i] & 255;
-                const int gy = i0 - 1 + py, gx = j0 - 1 + px;
-                const bool inside = gy >= 0 && gy < h && gx >= 0 && gx < w;
-                float xs[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) xs[r] = inside ? fmaxf(acc[i][r] * inv_scale2 + bias2_r[r], 0.0f) : 0.0f;
-                _Float16 hs[4], ls[4];
-                bool bad = false;
-                fldr_split_hl_group(xs, hs, ls, bad);
-                fldr_note_range(bad);
                 if ((pw * 6 + i) * 4 + (ln >> 2) < 85) {
                     // channels 4 lg .. 4 lg + 3: group lg >> 1, second half of the record for odd lg; planes: [g0 hi, g0 lo, g1 hi, g1 lo]
-                    unsigned char* d = tb + (lg >> 1) * 2 * D23_OPLANE + (py * D23_OW + px) * 16 + (lg & 1) * 8;
-                    *reinterpret_cast<d23_h4*>(d) = d23_h4{hs[0], hs[1], hs[2], hs[3]};
-                    *reinterpret_cast<d23_h4*>(d + D23_OPLANE) = d23_h4{ls[0], ls[1], ls[2], ls[3]};
+                    unsigned char* d = tb + soff[i];
+                    *reinterpret_cast<d23_h4*>(d) = d23_h4{hs[4 * i], hs[4 * i + 1], hs[4 * i + 2], hs[4 * i + 3]};
+                    *reinterpret_cast<d23_h4*>(d + D23_OPLANE) = d23_h4{ls[4 * i], ls[4 * i + 1], ls[4 * i + 2], ls[4 * i + 3]};
                 }
             }
             // the next tile reads the other window set

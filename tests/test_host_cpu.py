@@ -352,3 +352,31 @@ def test_evaluate_dir_walk_sharding_and_reduction(tmp_path):
     assert r0["frames"] == 2 and r1["frames"] == 1
     assert (r0["psnr"] * 2 + r1["psnr"] * 1) / 3 == pytest.approx(full["psnr"], rel=1e-12)
     assert Hn.reduce_sums([1.5, 2.0, 3.0]) == [1.5, 2.0, 3.0]
+
+
+def test_dec23_softmax_exp_polynomial_is_accurate_to_1e12():
+    """dec23_kernels.hip::d23_exp_nonpos (the fused synthesis kernel's exp for softmax arguments <= 0): its constants, read from the source,
+    evaluated in numpy fp64 the way the kernel evaluates them — relative error below 1e-12 over [-745, 0] (the fp32 logits carry ~6e-8),
+    exact 1 at 0, 0 beyond the denormals."""
+    import math
+    src = open(os.path.join(ROOT, "fldr-vfi_amd", "csrc", "dec23_kernels.hip")).read()
+    body = src[src.index("double d23_exp_nonpos(double x) {"):]
+    body = body[:body.index("return __builtin_ldexp")]
+    body = re.sub(r"//[^\n]*", "", body)                                 # (the comments name the factorials)
+    nums = [float(v) for v in re.findall(r"-?\d+\.\d+(?:e[-+]\d+)?", body)]
+    assert abs(nums[0] - 1.4426950408889634) < 1e-15 and abs(nums[1] + math.log(2)) < 1e-9 and abs(nums[2]) < 1e-9
+    coef = nums[3:]
+    assert len(coef) == 11 and coef[-1] == coef[-2] == 1.0 and coef[-3] == 0.5
+    for k, c in zip(range(10, 0, -1), coef[:-1]):
+        assert abs(c * math.factorial(k) - 1.0) < 1e-15                  # Taylor coefficients 1 / k!
+    x = np.concatenate([-np.abs(np.random.default_rng(0).standard_normal(400000)) * 30, -np.linspace(0, 745, 100001)])
+    n = np.rint(x * nums[0])
+    r = x + n * nums[1]
+    r = r + n * nums[2]
+    pl = np.full_like(x, coef[0])
+    for c in coef[1:]:
+        pl = pl * r + c
+    got, ref = np.ldexp(pl, n.astype(np.int64)), np.exp(x)
+    m = ref > 1e-300
+    assert np.max(np.abs(got[m] - ref[m]) / ref[m]) < 1e-12
+    assert got[np.argmax(x)] == 1.0 and np.all(np.ldexp(pl[:4], np.full(4, -1200)) == 0.0)
