@@ -251,13 +251,14 @@ def test_model_fused_synthesis_matches_the_two_kernel_form(hip, dev, model):
     for (H, W, seed) in ((256, 384, 11), (200, 330, 12)):
         f = Hn.frames_from_uint8(Hn.synthetic_pair(H, W, seed=seed)).to(dev)
         t = torch.tensor([[0.375]], device=dev)
-        assert hip.DEC23_FUSED
-        fused = Hn.interpolate(m, a, f, t)
-        hip.DEC23_FUSED = False
+        was = hip.DEC23_FUSED                                               # (False when the suite runs under FLDR_DEC23=0)
         try:
+            hip.DEC23_FUSED = True
+            fused = Hn.interpolate(m, a, f, t)
+            hip.DEC23_FUSED = False
             two = Hn.interpolate(m, a, f, t)
         finally:
-            hip.DEC23_FUSED = True
+            hip.DEC23_FUSED = was
         assert fused.dtype == two.dtype == torch.float64 and fused.shape == two.shape == (1, 3, H, W)
         _cmp(fused, two, atol=3e-6, what="fused synthesis vs dec2 + dec3 kernels %dx%d" % (H, W))
     hip.check_range()
