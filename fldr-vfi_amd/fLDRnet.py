@@ -121,9 +121,12 @@ class DCTXVFInet(nn.Module):
         y = fldr_hip.conv2d_spk([pca if pca_spk is None else pca_spk], c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
         return fldr_hip.conv2d_spk([y], c2.weight, c2.bias, relu=True, residual=pca, want_f32=True, want_spk=True)
 
-    def forward(self, input_gpuList, t_value, normInput=0, is_training=True, validation=False, epoch=0, frameT=None):
+    def forward(self, input_gpuList, t_value, normInput=0, is_training=True, validation=False, epoch=0, frameT=None, *, emit_u8=None):
         """input_gpuList: ignored placeholders (the reference overwrites them, fLDRnet.py:134); t_value [B,1];
-        normInput: list of S_tst+1 tensors [B,3,2,H/2^i,W/2^i].  Returns (out fp64 [B,3,<=2160,<=4096], flow|None)."""
+        normInput: list of S_tst+1 tensors [B,3,2,H/2^i,W/2^i].  Returns (out fp64 [B,3,<=2160,<=4096], flow|None).
+        emit_u8 = (H, W) (keyword-only, not in the reference's signature; fldr_harness.interpolate_u8): return the frame cropped to H x W and
+        rounded to 8 bits straight from the synthesis kernel where the fused kernel runs (the fp64 frame is then never written); paths that
+        cannot honour it return the fp64 frame as ever — the caller looks at the dtype."""
         if is_training:
             raise NotImplementedError("fldr-hip implements the inference (test) branch only")
         B2, C2 = t_value.size()
@@ -141,9 +144,9 @@ class DCTXVFInet(nn.Module):
             B = x_l[0].shape[0]
             nch = a.dctvfi_nf * 6
             # all six projections in two launches (pass A: per-level min / max, pass B: emit): fLDRnet.py:133-146
-            # rec_ctx_ds of ALL levels in two launches; the features exist split-packed only and the second convolution adds them back
-            # from the packed tensor (hi + lo: the fp32 feature up to 2^-22 relative, |x| <= 1), so that the rescale launch writes no
-            # fp32 copy (71 MB of 141 per 4K forward).  FLDR_PCA_F32=1: the fp32 residual (see fldr_hip.PCA_F32).
+            # rec_ctx_ds of ALL levels in two launches.  The second convolution adds the PCA features back (fLDRnet.py:162): from their fp32
+            # copy (default, fldr_hip.PCA_F32: the parity configuration), or — FLDR_PCA_F32=0, opt-in — from the split-packed tensor (hi + lo:
+            # the fp32 feature up to 2^-22 relative, |x| <= 1), in which case the rescale launch writes no fp32 copy (71 MB of 141 per 4K forward).
             levels_batched = bool(a.ref_feat_extrac and spk and B == 1 and fldr_hip.LEVEL_BATCH and fldr_hip.spk_variant() == 1)
             packed_only = levels_batched and not fldr_hip.PCA_F32
             r = to_pca_diff_f32_pyramid([x_l[i].reshape(B * 6, x_l[i].shape[3], x_l[i].shape[4]) for i in range(n_levels)],
@@ -172,14 +175,13 @@ class DCTXVFInet(nn.Module):
             state = {"key": (x_l[0], x_l[0]._version), "flow0": flow}
             self._pair_state = state if self.pair_cache else None
         out, refined = self.vfinet._synthesise(state["flow0"], x_l[0], t4, validation,
-                                               cache=state if self.pair_cache else None)
+                                               cache=state if self.pair_cache else None, u8_crop=emit_u8)
         return out[:, :, :self.output_size_test[0], :self.output_size_test[1]], refined                # :222
 
 
 class DCTVFInet(nn.Module):
     def __init__(self, args, output_size, output_size_test, output_size_val):
         super().__init__()
-        self.emit_u8 = None      # (H, W): the next forward returns the cropped 8-bit frame (fldr_harness.interpolate_u8)
         self.args = args
         self.device = torch.device('cuda:' + str(args.gpu) if torch.cuda.is_available() else 'cpu')
         self.nf = nf = int(args.dctvfi_nf * args.img_ch)
@@ -291,7 +293,7 @@ class DCTVFInet(nn.Module):
         return flow_l
 
     # ---- level 0 (fLDRnet.py:400-535) ------------------------------------------------------------
-    def _synthesise(self, flow_l, x_l, t_value, validation, cache=None):
+    def _synthesise(self, flow_l, x_l, t_value, validation, cache=None, u8_crop=None):
         a = self.args
         B = flow_l.shape[0]
         t4 = t_value.view(B, 1, 1, 1).float()
@@ -340,10 +342,10 @@ class DCTVFInet(nn.Module):
                 and tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and tuple(unet.dec2.weight.shape) == (16, 48, 3, 3)):
             # dec2 + dec3 + softmax/T + blend in one persistent kernel: neither dec2's output nor refine_out is ever stored
             dec1p, enc1p = unet.forward_until_dec1(srcs)
-            # emit_u8 = (H, W) (set by fldr_harness.interpolate_u8 around a call): the cropped frame rounded to 8 bits comes straight out of
-            # the kernel's fp64 blend instead of the fp64 frame (run_on_your_images.py:100-109 needs nothing else)
+            # u8_crop = (H, W) (DCTXVFInet.forward's emit_u8): the cropped frame rounded to 8 bits comes straight out of the kernel's fp64
+            # blend instead of the fp64 frame (run_on_your_images.py:100-109 needs nothing else)
             out = fldr_hip.dec23_synth(dec1p, enc1p, unet.dec2.weight, unet.dec2.bias, unet.dec3.weight, unet.dec3.bias, cands, t4, T,
-                                       u8_crop=getattr(self, "emit_u8", None))
+                                       u8_crop=u8_crop)
         elif tuple(unet.dec3.weight.shape) == (6, 16, 3, 3) and H % 2 == 0 and W % 2 == 0:
             # dec3 + softmax/T + blend in one kernel; refine_out (6 full-resolution planes) is never stored
             out = fldr_hip.dec3_synth(unet.forward_until_dec2(srcs, packed_out=fldr_hip.DEC3_MFMA and fldr_hip.use_spk()),

@@ -246,15 +246,9 @@ def interpolate_u8(model, args, frames_u8, t_value, target_u8=None, want_ssim=Fa
         pyr = fldr_hip.ingest_pyramid(frames_u8, args.S_tst + 1)
         # without a ground truth nothing but the rounded frame is wanted: the fused synthesis kernel emits it directly (the fp64 frame is
         # then never written); the model ignores the request on the paths that cannot honour it and returns the fp64 frame as ever
-        vfi = getattr(model, "vfinet", None)
-        direct = U8_DIRECT and target_u8 is None and vfi is not None and W % 2 == 0
-        if direct:
-            vfi.emit_u8 = (H, W)
-        try:
-            pred, _ = model([None] * (args.S_tst + 1), t_value, normInput=pyr, is_training=False, validation=False)
-        finally:
-            if direct:
-                vfi.emit_u8 = None
+        direct = U8_DIRECT and target_u8 is None and W % 2 == 0 and hasattr(model, "vfinet")
+        pred, _ = model([None] * (args.S_tst + 1), t_value, normInput=pyr, is_training=False, validation=False,
+                        **({"emit_u8": (H, W)} if direct else {}))       # (an explicit argument of the call: no state on the model)
         if pred.dtype == torch.uint8:
             return pred.contiguous(), None
         sse, img = fldr_hip.frame_metrics(pred, min(H, pred.shape[2]), min(W, pred.shape[3]), target_u8, want_u8=True)

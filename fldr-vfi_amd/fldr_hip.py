@@ -394,24 +394,33 @@ _MODES = {"summation": 0, "average": 1, "linear": 2, "softmax": 3}
 #            compiled into the TEST build only since round 4 (cross-check of acc64): selecting it outside fldr_hip.test_hooks() raises.
 # Environment switches of the product path (everything else below is a module attribute that tests / tools flip to reach a cross-check
 # kernel, not a deployment knob): FLDR_SPLAT (operator-level splat kernel), FLDR_SPLAT_FEATURES=gather (deterministic feature splats),
-# FLDR_PCA_F32=1 (fp32 PCA residual), FLDR_DEC23=0 (dec2 and dec3 as two kernels), FLDR_CONV_PRECISION (split | fp32 | fp16), FLDR_LIB (an
+# FLDR_PCA_F32=0 (PCA features split-packed only: opt-in, not the parity configuration), FLDR_DEC23=0 (dec2 and dec3 as two kernels), FLDR_CONV_PRECISION (split | fp32 | fp16), FLDR_LIB (an
 # experimental build of the library).
 SPLAT_KERNEL = os.environ.get("FLDR_SPLAT", "auto")
-# Warped feature maps of the flow estimator (fLDRnet.py:386-387): "strip" (default) = the global-atomic scatter kernel +
-# normalisation pass (fastest: 266 us per 4K forward); "gather" = the deterministic atomic-free gather of
-# splat_gather_kernels.hip (bitwise run-to-run reproducible output frames; measured 531 us per forward: every match costs a
-# 48-load body whose latency the few waves of a feature map cannot hide).
-SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")   # acc64 (default since round 3: fp64 LDS-atomic tiles) | gather (deterministic, opt-in)
+# Warped feature maps of the flow estimator (fLDRnet.py:386-387): "acc64" (default since round 3) = destination-owned tiles of fp64 LDS
+# accumulators, both directions per launch (splat_acc64_kernels.hip; deterministic); "gather" = the atomic-free gather of
+# splat_gather_kernels.hip (opt-in: ~2x slower, every match costs a 48-load body whose latency the few waves of a feature map cannot hide).
+SPLAT_FEATURES = os.environ.get("FLDR_SPLAT_FEATURES", "acc64")
+if SPLAT_FEATURES not in ("acc64", "gather"):
+    raise ValueError("FLDR_SPLAT_FEATURES=%r: expected 'acc64' (default) or 'gather' (the scatter kernel 'strip' of rounds 1-2 is retired)" % SPLAT_FEATURES)
+if SPLAT_KERNEL not in ("auto", "acc64", "strip", "tile"):
+    raise ValueError("FLDR_SPLAT=%r: expected auto | acc64 | strip | tile" % SPLAT_KERNEL)
+# Switches of earlier rounds that no longer exist: setting one has no effect, say so once instead of silently ignoring it.
+_RETIRED_ENV = ("FLDR_PREP_SPLIT", "FLDR_LEVEL_BATCH", "FLDR_ENC3_SPLIT", "FLDR_ENC3_PAIR", "FLDR_S2_SPK", "FLDR_SPLAT_BOUNDS", "FLDR_DEC3_MFMA",
+                "FLDR_RESIZE_BOUNDS", "FLDR_PCA_RAW_MIN_BYTES", "FLDR_INGEST_FUSED")
+for _n in _RETIRED_ENV:
+    if _n in os.environ:
+        import warnings
+        warnings.warn("%s is set but is no longer a switch of fldr_hip (retired; see DESIGN.md section 1 for the current ones)" % _n, stacklevel=2)
 # rec_ctx_ds of all pyramid levels in two launches (fldr_conv2d_spk_levels) instead of two per level
 LEVEL_BATCH = True
-# 0 (default since round 5): the PCA features exist split-packed only — rec_ctx_ds.2 adds hi + lo of the packed feature (the fp32
-# feature up to 2^-22 relative: 2.4e-7 for |x| <= 1; every golden / oracle bound holds, tests/test_gpu_parity.py) and the rescale
-# launch writes half the bytes (71 of 141 MB per 4K forward).  1: the features are also written as fp32 and the residual is that
-# tensor (tracks the oracle's features to the last bits).  The difference only shows where the problem itself is ill-conditioned:
-# on the strong-non-rigid-motion 4K stress pair it flips ONE nearly empty target cell of a feature splat (hole or full value), which
-# the reference's own fp32 atomics do from run to run; the test of that pair bounds the error by the conditioning the oracle reports
-# (oracle.splat_ill_conditioned_cells).
-PCA_F32 = os.environ.get("FLDR_PCA_F32", "0") == "1"
+# 1 (default; the parity configuration): the PCA rescale launch writes the features as fp32 next to the split-packed tensor and
+# rec_ctx_ds.2 adds that fp32 tensor (tracks the oracle's features to the last bits).  FLDR_PCA_F32=0 (opt-in, +0.4 % throughput):
+# the features exist split-packed only and rec_ctx_ds.2 adds hi + lo of the packed feature (the fp32 feature up to 2^-22 relative,
+# 2.4e-7 for |x| <= 1; 71 instead of 141 MB written per 4K forward).  Every golden bound holds in both modes; the opt-in mode is NOT
+# the parity default because on the strong-non-rigid-motion 4K stress pair that 2.4e-7 flips one nearly empty target cell of a feature
+# splat and a 24 x 46 px patch of the frame then differs from the oracle by up to 0.145 (tests/test_gpu_fullsize.py reports it).
+PCA_F32 = os.environ.get("FLDR_PCA_F32", "1") != "0"
 
 
 # Bounds table of the level-0 image splats: "lowres" (default) = from the low-resolution flow the upsampled flow_t is made of

@@ -229,6 +229,22 @@ def bwarp(x, flo, withmask=True):
     return out * mask
 
 
+BWARP_MASK_THRESHOLD = 0.999   # fLDRnet.py:573
+
+
+def bwarp_mask_value(shape, flo):
+    """Test diagnostic (not part of the reference): the value the hard threshold of bwarp is applied to (fLDRnet.py:569-574),
+    [B,1,H,W].  A pixel whose value lies within a rounding error of 0.999 is ill-conditioned: the reference's own grid_sample
+    flips it between "kept" and "zeroed" with any re-association of the grid arithmetic; tests confine differences to such pixels."""
+    B, _, H, W = shape
+    xx = torch.arange(0, W).view(1, 1, 1, W).expand(B, 1, H, W)
+    yy = torch.arange(0, H).view(1, 1, H, 1).expand(B, 1, H, W)
+    vgrid = torch.cat((xx, yy), 1).float() + flo
+    gx = 2.0 * vgrid[:, 0] / max(W - 1, 1) - 1.0
+    gy = 2.0 * vgrid[:, 1] / max(H - 1, 1) - 1.0
+    return F.grid_sample(torch.ones(B, 1, H, W), torch.stack((gx, gy), dim=3), align_corners=False)
+
+
 # --------------------------------------------------------------------------
 # network pieces  (fLDRnet.py)
 # --------------------------------------------------------------------------

@@ -75,18 +75,34 @@ def clean_launcher():
     """run(cmd, env, timeout) -> dict(rc, stdout, stderr), executed by the GPU-clean helper process started in pytest_configure."""
     import json
     import select
+    import time
     if _launcher is None or _launcher.poll() is not None:
         pytest.skip("the GPU-clean launcher does not exist in sessions that exclude the gpu marker")
 
+    pending = bytearray()                       # bytes of the helper's stdout read past the last reply line (raw fd: select() stays exact)
+
     def run(cmd, env=None, timeout=600):
+        if _launcher.poll() is not None:
+            pytest.fail("the GPU-clean launcher helper is gone (rc %s): an earlier request missed its deadline and it was killed" % _launcher.returncode)
         _launcher.stdin.write(json.dumps({"cmd": cmd, "env": env, "timeout": timeout}) + "\n")
         _launcher.stdin.flush()
-        # the reply is read with a deadline (the helper's own timeout + the time it grants the killed group + slack)
-        ready, _, _ = select.select([_launcher.stdout], [], [], timeout + 60)
-        if not ready:
-            _launcher.kill()
-            return {"rc": -998, "stdout": "", "stderr": "the launcher helper did not answer within %d s (killed)" % (timeout + 60)}
-        return json.loads(_launcher.stdout.readline())
+        # the reply is read with a deadline (the helper's own timeout + the time it grants the killed group + slack), from the raw file
+        # descriptor: select() on a buffered text wrapper cannot see data that already sits in Python's buffer
+        fd = _launcher.stdout.fileno()
+        deadline = time.monotonic() + timeout + 60
+        while b"\n" not in pending:
+            left = deadline - time.monotonic()
+            ready = select.select([fd], [], [], max(left, 0.0))[0] if left > 0 else []
+            if not ready:
+                _launcher.kill()
+                return {"rc": -998, "stdout": "", "stderr": "the launcher helper did not answer within %d s (killed)" % (timeout + 60)}
+            chunk = os.read(fd, 1 << 16)
+            if not chunk:
+                return {"rc": -997, "stdout": "", "stderr": "the launcher helper closed its output (rc %s)" % _launcher.poll()}
+            pending.extend(chunk)
+        line, _, rest = bytes(pending).partition(b"\n")
+        pending[:] = rest
+        return json.loads(line.decode())
     return run
 
 

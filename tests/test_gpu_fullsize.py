@@ -126,21 +126,27 @@ def test_4k_strong_nonrigid_motion_matches_oracle(hip, dev, model, oracle, weigh
     shift: displacements up to ~85 px that change from pixel to pixel, large occluded / disoccluded borders) — the flows the
     scatter kernels find hardest, through the model rather than through operator tests — against the oracle.
 
-    The bound follows the CONDITIONING of the problem, which the oracle reports (oracle.splat_ill_conditioned_cells: target cells of a
-    feature splat whose normaliser is > 0 and < 1e-4 within +-1e-3 px of the flow — one grazing source decides between a hole and a
-    full value; the reference's own fp32 atomics flip such a cell from run to run):
-      * no such cell: the backward warp's hard mask threshold (fLDRnet.py:573-574) may still flip on isolated pixels — at most
-        one value in a million beyond 1e-4;
-      * some: a flipped cell changes the flow of the levels below it in a patch of the frame (measured with the packed-only PCA
-        residual, whose features differ from the oracle's by 2.4e-7: one cell, a 24 x 46 px patch, 4.9e-5 of the values, 91.7 dB)
-        — at most 2e-4 of the values beyond 1e-4, and never more than 5e-5 per ill-conditioned cell.
-    Mean error and PSNR bounds hold in both cases."""
+    The parity configuration (fp32 PCA residual, the default) meets the bound of every other whole-frame test: the backward warp's
+    hard mask threshold (fLDRnet.py:573-574) may flip on isolated pixels — at most one value in a million beyond 1e-4 — mean error
+    <= 1e-6, >= 90 dB.  No allowance is derived from the oracle's conditioning report; it is printed for the record only.
+
+    FLDR_PCA_F32=0 (features split-packed only; opt-in, NOT the parity configuration) is run on the same pair and reported: its
+    2.4e-7 feature difference flips one nearly empty target cell of a feature splat at the frame border on this pair (a 24 x 46 px
+    patch, 4.9e-5 of the values beyond 1e-4, 91.7 dB).  Its assertions: the differences beyond 1e-4 stay inside ONE bounded patch
+    (<= 64 x 64 px) per ill-conditioned cell the oracle reports — anything outside it fails — and mean error / PSNR as above."""
     import fldr_harness as Hn
     m, a = model
     Hs, Ws = 2160, 3840
     frames = Hn.frames_from_uint8(Hn.synthetic_pair_varying(Hs, Ws, seed=31, zoom=1.025, rot_deg=0.8, shift=(7.0, -4.0)))
     t = torch.tensor([[0.375]])
+    assert hip.PCA_F32, "the parity configuration adds the fp32 PCA features in rec_ctx_ds.2"
     out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    hip.check_range()
+    try:
+        hip.PCA_F32 = False
+        out_packed = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    finally:
+        hip.PCA_F32 = True
     hip.check_range()
     torch.set_num_threads(max(1, min(16, torch.get_num_threads())))
     keep = {}
@@ -151,6 +157,19 @@ def test_4k_strong_nonrigid_motion_matches_oracle(hip, dev, model, oracle, weigh
     frac = (err > 1e-4).double().mean().item()
     p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
     print("3840x2160 strong non-rigid motion: max|err| %.2e mean %.2e, %.2e of the values beyond 1e-4, PSNR(8-bit) %.1f dB; "
-          "ill-conditioned feature-splat cells per level (oracle, eps %.0e, +-%.0e px): %s"
+          "ill-conditioned feature-splat cells per level (oracle, eps %.0e, +-%.0e px; not used by the bound): %s"
           % (err.max().item(), err.mean().item(), frac, p, oracle.SPLAT_COND_EPS, oracle.SPLAT_COND_DELTA, keep["ill_conditioned_splat_cells"]))
-    assert frac <= (1e-6 if n_ill == 0 else min(2e-4, 5e-5 * n_ill)) and err.mean().item() <= 1e-6 and p >= 90.0
+    assert frac <= 1e-6 and err.mean().item() <= 1e-6 and p >= 90.0
+    # --- the opt-in packed-residual mode
+    errp = (out_packed.double().cpu() - ref.double()).abs()
+    badp = (errp > 1e-4).any(1)[0]                                        # [H, W]
+    fracp = (errp > 1e-4).double().mean().item()
+    pp = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out_packed[0]))
+    ys, xs = torch.nonzero(badp, as_tuple=True)
+    box = (int(ys.min()), int(ys.max()), int(xs.min()), int(xs.max())) if len(ys) else None
+    print("  FLDR_PCA_F32=0 (opt-in): max|err| %.2e mean %.2e, %.2e of the values beyond 1e-4, PSNR(8-bit) %.1f dB, bounding box of the "
+          "pixels beyond 1e-4 (y0, y1, x0, x1): %s" % (errp.max().item(), errp.mean().item(), fracp, pp, box))
+    assert errp.mean().item() <= 1e-6 and pp >= 90.0
+    if fracp > 1e-6:
+        assert n_ill >= 1, "differences beyond 1e-4 without any ill-conditioned splat cell"
+        assert n_ill == 1 and box[1] - box[0] < 64 and box[3] - box[2] < 64, "differences beyond 1e-4 outside one 64 x 64 patch: %s" % (box,)

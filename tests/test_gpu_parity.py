@@ -22,16 +22,36 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-def _cmp(got, ref, atol, rtol=0.0, max_outlier_frac=0.0, what=""):
+def _cmp(got, ref, atol, rtol=0.0, max_outlier_frac=0.0, what="", ill=None, outlier_atol=None):
+    """Every element within atol + rtol |ref|.  Exceptions are conditioning-derived only: `ill` (a boolean tensor broadcastable to
+    the outputs) marks the positions the ORACLE reports as ill-conditioned (a hard threshold within rounding of its operand):
+    elements beyond the tolerance must all lie there.  `max_outlier_frac` (with `outlier_atol`: the bound the outliers still
+    meet) is for rounding-boundary cases only — a last-bit difference of a cast — never an unbounded allowance."""
     got = got.detach().double().cpu()
     ref = ref.detach().double().cpu()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert torch.isfinite(got).all(), what + ": non-finite values"
     err = (got - ref).abs()
     bad = err > (atol + rtol * ref.abs())
+    if ill is not None:
+        stray = bad & ~ill.expand_as(bad)
+        assert not stray.any(), "%s: %d elements beyond tol outside the ill-conditioned positions (of %d beyond tol, %d ill-conditioned), max err there %.3e" % (
+            what, int(stray.sum()), int(bad.sum()), int(ill.expand_as(bad).sum()), err[stray].max().item())
+        return err[~ill.expand_as(bad)].max().item() if (~ill.expand_as(bad)).any() else 0.0
     frac = bad.double().mean().item()
     assert frac <= max_outlier_frac, "%s: %.3g of elements beyond tol, max err %.3e" % (what, frac, err.max().item())
+    if max_outlier_frac > 0.0:
+        assert outlier_atol is not None and err.max().item() <= outlier_atol, "%s: outlier of %.3e (allowed %s)" % (what, err.max().item(), outlier_atol)
     return err.max().item()
+
+
+BWARP_BAND = 1e-4       # |mask value - 0.999| below which the backward warp's hard threshold (fLDRnet.py:573-574) is ill-conditioned
+
+
+def _bwarp_ill(oracle, shape, flo):
+    """Pixels whose backward-warp mask value (oracle.bwarp_mask_value: what fLDRnet.py:573 thresholds) lies within BWARP_BAND of the
+    threshold: the only positions where the HIP kernel's mask may differ from the reference's."""
+    return (oracle.bwarp_mask_value(shape, flo) - oracle.BWARP_MASK_THRESHOLD).abs() < BWARP_BAND
 
 
 @pytest.fixture(scope="module")
@@ -973,7 +993,7 @@ def test_pca_matches_reference_golden_and_oracle(hip, oracle, weights, golden, d
     ref = oracle.to_pca_diff(big, weights["Mean8"], weights["EV8"], weights["meanVec8"])
     _cmp(pca_comp.to_pca_diff(big.to(dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8), ref, atol=1e-12, what="pca f64")
     _cmp(pca_comp.to_pca_diff_f32(big.to(dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8), ref.float(), atol=0.0,
-         what="pca f32 (bit exact after the cast)", max_outlier_frac=1e-4)
+         what="pca f32 (bit exact after the cast)", max_outlier_frac=1e-4, outlier_atol=2.0 ** -24)   # (at most the last bit of the cast, values in [-1, 1])
     with pytest.raises(Exception, match="not padded right"):
         pca_comp.to_pca_diff(torch.zeros(6, 20, 16, device=dev), m.params[0], a, m.Mean8, m.EV8, m.meanVec8)
 
@@ -981,12 +1001,13 @@ def test_pca_matches_reference_golden_and_oracle(hip, oracle, weights, golden, d
 # ---------------------------------------------------------------------------------------------------
 # backward warp, splat metric, resize
 # ---------------------------------------------------------------------------------------------------
-def test_bwarp_matches_reference_golden(hip, golden, dev, model):
+def test_bwarp_matches_reference_golden(hip, oracle, golden, dev, model):
     m, _ = model
     g = golden("ops")
     x, flo = torch.from_numpy(g["bwarp_x"]).to(dev), torch.from_numpy(g["bwarp_flo"]).to(dev)
-    _cmp(m.vfinet.bwarp(x, flo, withmask=True), torch.from_numpy(g["bwarp_out"]), atol=1e-5, max_outlier_frac=2e-3,
-         what="bwarp mask")
+    ill = _bwarp_ill(oracle, x.shape, torch.from_numpy(g["bwarp_flo"]))
+    print("bwarp golden: %d of %d pixels within %.0e of the mask threshold" % (int(ill.sum()), ill.numel(), BWARP_BAND))
+    _cmp(m.vfinet.bwarp(x, flo, withmask=True), torch.from_numpy(g["bwarp_out"]), atol=1e-5, ill=ill, what="bwarp mask")
     _cmp(m.vfinet.bwarp(x, flo, withmask=False), torch.from_numpy(g["bwarp_out_nomask"]), atol=1e-5, what="bwarp nomask")
 
 
@@ -998,15 +1019,17 @@ def test_bwarp_tscaled_zmetric_resize(hip, oracle, dev):
     f10 = (torch.rand(N, 2, H, W, generator=g) - 0.5) * 14
     f01 = (torch.rand(N, 2, H, W, generator=g) - 0.5) * 14
     t = torch.tensor([0.125, 0.7]).view(N, 1, 1, 1)
+    # differences beyond the tolerance only where the oracle's mask value sits on the hard threshold (fLDRnet.py:573-574)
     ref = oracle.bwarp(f10 * t, (1 - t) * f01)
     got = hip.bwarp_tscaled(f10.to(dev), f01.to(dev), t.to(dev), "t", "1-t")
-    _cmp(got, ref, atol=1e-5, max_outlier_frac=2e-3, what="flowback_0")
+    ills = [_bwarp_ill(oracle, f10.shape, (1 - t) * f01), _bwarp_ill(oracle, f01.shape, t * f10), _bwarp_ill(oracle, I1.shape, f01)]
+    print("pixels within %.0e of the mask threshold: %s of %d" % (BWARP_BAND, [int(i.sum()) for i in ills], ills[0].numel()))
+    _cmp(got, ref, atol=1e-5, ill=ills[0], what="flowback_0")
     ref = oracle.bwarp(f01 * (1 - t), t * f10)
-    _cmp(hip.bwarp_tscaled(f01.to(dev), f10.to(dev), t.to(dev), "1-t", "t"), ref, atol=1e-5, max_outlier_frac=2e-3,
-         what="flowback_1")
+    _cmp(hip.bwarp_tscaled(f01.to(dev), f10.to(dev), t.to(dev), "1-t", "t"), ref, atol=1e-5, ill=ills[1], what="flowback_1")
     alpha = -1.894
     zref = torch.mean(alpha * torch.abs(I0 - oracle.bwarp(I1, f01)), dim=1, keepdim=True)
-    _cmp(hip.zmetric(I0.to(dev), I1.to(dev), f01.to(dev), alpha), zref, atol=1e-5, max_outlier_frac=2e-3, what="zmetric")
+    _cmp(hip.zmetric(I0.to(dev), I1.to(dev), f01.to(dev), alpha), zref, atol=1e-5, ill=ills[2], what="zmetric")
     lo = torch.randn(N, 4, 9, 15, generator=g)
     _cmp(hip.resize_bilinear(lo.to(dev), 18, 30, mul=2.0),
          F.interpolate(lo, size=(18, 30), mode="bilinear", align_corners=False) * 2.0, atol=1e-6, what="resize x2")
@@ -1136,6 +1159,167 @@ def test_model_matches_reference_golden(hip, oracle, golden, dev, model, case):
     p = Hn.psnr(Hn.to_uint8_image(ref[0]), Hn.to_uint8_image(out[0]))
     print("%s: max|err| %.2e, PSNR(8-bit) gpu vs reference %.1f dB" % (case, err, p))
     assert p > 90.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# the REFERENCE's stand-alone stage vectors (tests/golden/ops.npz, tools/make_golden.py op_cases) on the HIP stacks with the SHIPPED
+# weights — the magnitudes the fp16 split's pre-scaling and range guard actually see (the per-layer tests above use random weights)
+# ---------------------------------------------------------------------------------------------------
+def test_rec_ctx_ds_matches_reference_golden(hip, golden, dev, model):
+    """rec_ctx_ds(x) + x (fLDRnet.py:44-49,162) of the reference on its own input vector."""
+    m, _ = model
+    g = golden("ops")
+    err = _cmp(m.extract_features(torch.from_numpy(g["feat_in"]).to(dev)), torch.from_numpy(g["rec_ctx_ds_out"]), atol=2e-5, rtol=1e-5,
+               what="rec_ctx_ds vs reference")
+    print("rec_ctx_ds vs reference: max|err| %.2e (|ref| <= %.1f)" % (err, float(np.abs(g["rec_ctx_ds_out"]).max())))
+    hip.check_range()
+
+
+def test_conv_flow_bottom_matches_reference_golden(hip, golden, dev, model):
+    """conv_flow_bottom (fLDRnet.py:318-327,379-380): five layers, the first four outputs of the last one."""
+    m, _ = model
+    g = golden("ops")
+    f = torch.from_numpy(g["feat_in"]).to(dev)
+    got = m.vfinet.estimate_flow(f, None)
+    assert got.shape == (1, 4, 20, 28)
+    err = _cmp(got, torch.from_numpy(g["conv_flow_bottom_out"][:, :4]), atol=2e-5, rtol=1e-5, what="conv_flow_bottom vs reference")
+    print("conv_flow_bottom vs reference: max|err| %.2e" % err)
+    hip.check_range()
+
+
+def test_conv_flow1_matches_reference_golden(hip, golden, dev, model):
+    """conv_flow1 (fLDRnet.py:329,389-390) on a 96-channel vector: as one source, and as the two 48-channel sources the model passes
+    (feature half + warped half: the concat is never built)."""
+    m, _ = model
+    g = golden("ops")
+    f = torch.from_numpy(g["feat_in"]).to(dev)
+    f1 = m.vfinet.conv_flow1
+    ref = torch.from_numpy(g["conv_flow1_out"])
+    fp = hip.spk_pack(f)
+    one = hip.conv2d_spk([fp], f1.weight, f1.bias)
+    two = hip.conv2d_spk([fp.narrow(0, 48), fp.narrow(48, 48)], f1.weight, f1.bias)
+    err = _cmp(one, ref, atol=2e-5, rtol=1e-5, what="conv_flow1 vs reference")
+    assert torch.equal(one, two)
+    print("conv_flow1 vs reference: max|err| %.2e" % err)
+    hip.check_range()
+
+
+def test_conv_flow2_matches_reference_golden(hip, golden, dev, model):
+    """conv_flow2 (fLDRnet.py:331-345,391) on the reference's 100-channel vector, fed as the model feeds it: three sources
+    (48 + 48 + 4 channels), activations split-packed between the five layers."""
+    m, _ = model
+    g = golden("ops")
+    x = torch.from_numpy(g["flow2_in"]).to(dev)
+    ca, cb, up = hip.spk_pack(x[:, :48].contiguous()), hip.spk_pack(x[:, 48:96].contiguous()), x[:, 96:].contiguous()
+    got = m.vfinet._chain([ca, cb, hip.spk_pack(up)], m.vfinet.conv_flow2, (0, 2, 4, 6, 8))
+    err = _cmp(got, torch.from_numpy(g["conv_flow2_out"]), atol=2e-5, rtol=1e-5, what="conv_flow2 vs reference")
+    print("conv_flow2 vs reference: max|err| %.2e" % err)
+    hip.check_range()
+
+
+def test_refine_unet_matches_reference_golden(hip, golden, dev, model):
+    """PCARefineUNet.forward (fLDRnet.py:619-644) of the reference on its own 26-channel input, three ways: from the concatenated tensor;
+    from the ten source tensors the model passes (never concatenated: enc1 assembles them); and through the product's two-kernel tail
+    (dec2 -> packed -> dec3 phase convolutions on the matrix cores, want_refine)."""
+    m, _ = model
+    g = golden("ops")
+    u = torch.from_numpy(g["unet_in"]).to(dev)
+    ref = torch.from_numpy(g["unet_out"])
+    unet = m.vfinet.refine_unet
+    got = unet(u)
+    err = _cmp(got, ref, atol=1e-4, rtol=1e-5, what="refine_unet(cat) vs reference")
+    parts = [3, 3, 3, 3, 2, 2, 2, 2, 3, 3]
+    srcs, c0 = [], 0
+    for c in parts:
+        srcs.append(u[:, c0:c0 + c].contiguous())
+        c0 += c
+    assert torch.equal(unet(srcs), got)
+    d2p = unet.forward_until_dec2(srcs, packed_out=True)
+    cands = [torch.zeros(1, 3, 64, 96, device=dev) for _ in range(6)]
+    _, refine = hip.dec3_synth(d2p, unet.dec3.weight, unet.dec3.bias, cands, torch.tensor([[0.5]], device=dev), 1.5616, want_refine=True)
+    err2 = _cmp(refine, ref, atol=1e-4, rtol=1e-5, what="dec3 phase convolutions (matrix cores) vs reference")
+    print("refine_unet vs reference: max|err| %.2e (generic dec3), %.2e (phase-convolution dec3); |ref| <= %.1f" % (err, err2, float(ref.abs().max())))
+    hip.check_range()
+
+
+@pytest.mark.parametrize("case", ["model_256x256_t0500", "model_200x500_t0125"])
+def test_level0_stages_match_reference_golden(hip, oracle, golden, dev, model, case):
+    """Level 0 of the reference's own forward, stage by stage on the HIP path with the shipped weights: the level-0 PCA projection and
+    features (pca0 / feat0), then — driven exactly like DCTVFInet._synthesise — the 26 planes of the UNet input (fLDRnet.py:480; crops
+    of the reference's concat), the two backward-warped frames of the splat metric (im_1_0 / im_0_1, :442-446) and the UNet's output
+    (:501; crops).  Differences beyond the tolerance are confined to pixels whose backward-warp mask value sits on its hard threshold
+    (computed by the oracle from the flows the GPU itself produced)."""
+    import fldr_harness as Hn
+    import pca_comp
+    m, a = model
+    g = golden(case)
+    frames = Hn.frames_from_uint8(torch.from_numpy(g["frames_u8"])).to(dev)
+    tv = float(g["t"])
+    t = torch.tensor([[tv]], device=dev)
+    pyr = Hn.build_pyramid(Hn.pad_frames(frames, a), a)
+    H, W = pyr[0].shape[3:]
+    with torch.no_grad():
+        pca0 = pca_comp.to_pca_diff_f32(pyr[0].reshape(6, H, W), m.params[0], a, m.Mean8, m.EV8, m.meanVec8).view(1, 96, H // 8, W // 8)
+        _cmp(pca0, torch.from_numpy(g["pca0"]), atol=2e-6, what="pca L0")
+        feat0 = m.extract_features(pca0)
+        _cmp(feat0, torch.from_numpy(g["feat0"]), atol=2e-5, what="feat L0")
+        # the forward's own (all-level, packed) feature path at level 0 — the loop of test_model_matches_reference_golden stops at level 1
+        _, pcs = pca_comp.to_pca_diff_f32_pyramid([pyr[i].reshape(6, pyr[i].shape[3], pyr[i].shape[4]) for i in range(6)], m.params, a,
+                                                  m.Mean8, m.EV8, m.meanVec8, want_spk=True, want_f32=False)
+        pp = [hip.Spk(pcs[i].buf, (1, 96, pyr[i].shape[3] // 8, pyr[i].shape[4] // 8)) for i in range(6)]
+        c0, c2 = m.rec_ctx_ds[0], m.rec_ctx_ds[2]
+        ys = hip.conv2d_spk_levels(pp, c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
+        fl = hip.conv2d_spk_levels(ys, c2.weight, c2.bias, relu=True, residuals=pp, want_f32=True, want_spk=True)
+        _cmp(fl[0][0], torch.from_numpy(g["feat0"]), atol=2e-5, what="feat L0, packed residual")
+        flow = None
+        for level in range(5, -1, -1):
+            h, w = pyr[level].shape[3:]
+            pca = pca_comp.to_pca_diff_f32(pyr[level].reshape(6, h, w), m.params[level], a, m.Mean8, m.EV8, m.meanVec8).view(1, 96, h // 8, w // 8)
+            flow = m.vfinet.estimate_flow(m.extract_features(pca), flow)
+        # --- DCTVFInet._synthesise up to the UNet, tensors kept
+        vfi = m.vfinet
+        T, za0, za1 = vfi._host_scalars()
+        t4 = t.view(1, 1, 1, 1).float()
+        I0, I1 = pyr[0][:, :, 0], pyr[0][:, :, 1]
+        r = hip.level0_prep(flow, I0, I1, t4, H, W, za0, za1, withmask=True, want_z=True)
+        bw = hip.splat_bounds_upsampled_pair(flow, t4, "images", 8, H, W)
+        warped0, warped1 = hip.softsplat_acc64([I0, I1], [r["flow_t0"], r["flow_t1"]], [r["z0"], r["z1"]], "softmax", bounds_ws=bw)
+        srcs = [I0, I1, warped0, warped1, r["flow_t0"], r["flow_t1"], r["flowback_0"], r["flowback_1"], r["im0_tot"], r["im1_tot"]]
+        cat = torch.cat([s.contiguous() for s in srcs], 1)
+        refine = vfi.refine_unet(srcs)
+        d2p = vfi.refine_unet.forward_until_dec2(srcs, packed_out=True)
+        cands = [warped0, warped1, r["im0_tot"], r["im1_tot"], I0, I1]
+        out2, refine2 = hip.dec3_synth(d2p, vfi.refine_unet.dec3.weight, vfi.refine_unet.dec3.bias, cands, t4, T, want_refine=True)
+        # the metric's backward-warped frames (:443,446): public ops on the x8 flows the prep kernel never stores
+        U = lambda f: 8 * F.interpolate(f, scale_factor=(8, 8), mode="bilinear", align_corners=False)
+        f10, f01 = U(flow[:, :2].cpu()), U(flow[:, 2:].cpu())
+        im_1_0 = hip.bwarp(I1.contiguous(), f01.to(dev))
+        im_0_1 = hip.bwarp(I0.contiguous(), f10.to(dev))
+    # ill-conditioned pixels of each hard mask, from the GPU's own flows (oracle arithmetic on the CPU)
+    tc = tv
+    ill_fb0 = _bwarp_ill(oracle, (1, 2, H, W), (1 - tc) * f01)
+    ill_fb1 = _bwarp_ill(oracle, (1, 2, H, W), tc * f10)
+    ill_im0 = _bwarp_ill(oracle, (1, 3, H, W), r["flowback_0"].cpu()) | ill_fb0
+    ill_im1 = _bwarp_ill(oracle, (1, 3, H, W), r["flowback_1"].cpu()) | ill_fb1
+    none = torch.zeros(1, 1, H, W, dtype=torch.bool)
+    ill26 = torch.cat([none.expand(1, 12, H, W), none.expand(1, 4, H, W), ill_fb0.expand(1, 2, H, W), ill_fb1.expand(1, 2, H, W),
+                       ill_im0.expand(1, 3, H, W), ill_im1.expand(1, 3, H, W)], 1)
+    ill_m10, ill_m01 = _bwarp_ill(oracle, (1, 3, H, W), f01), _bwarp_ill(oracle, (1, 3, H, W), f10)
+    worst = {}
+    for ci, (y0, x0, hh, ww) in enumerate(g["crops"]):
+        sl = (Ellipsis, slice(int(y0), int(y0 + hh)), slice(int(x0), int(x0 + ww)))
+        # planes 12-25 carry flows in pixels of the frame (x8 upsampled): tolerance relative to their magnitude
+        worst["cat26"] = max(worst.get("cat26", 0.0), _cmp(cat[sl], torch.from_numpy(g["cat26_crops"][ci]), atol=1e-4, rtol=1e-4, ill=ill26[sl],
+                                                           what="UNet input planes, crop %d" % ci))
+        worst["im_1_0"] = max(worst.get("im_1_0", 0.0), _cmp(im_1_0[sl], torch.from_numpy(g["im_1_0_crops"][ci]), atol=1e-4, ill=ill_m10[sl], what="im_1_0 crop %d" % ci))
+        worst["im_0_1"] = max(worst.get("im_0_1", 0.0), _cmp(im_0_1[sl], torch.from_numpy(g["im_0_1_crops"][ci]), atol=1e-4, ill=ill_m01[sl], what="im_0_1 crop %d" % ci))
+        for name, rf in (("refine_out", refine), ("refine_out (phase-convolution dec3)", refine2)):
+            worst[name] = max(worst.get(name, 0.0), _cmp(rf[sl], torch.from_numpy(g["refine_out_crops"][ci]), atol=5e-4, rtol=1e-4, what="%s crop %d" % (name, ci)))
+    np.testing.assert_allclose(refine.double().sum((0, 2, 3)).cpu().numpy(), g["refine_out_sum"], rtol=1e-5, atol=0.5)
+    ref = torch.from_numpy(g["out"]).double()[:, :, :H, :W]
+    worst["frame (two-kernel tail)"] = _cmp(out2, ref, atol=2e-5, what="frame from dec3_synth")
+    print("%s level 0 vs reference: %s; ill-conditioned mask pixels %d" % (case, ", ".join("%s %.2e" % kv for kv in worst.items()), int(ill26.any(1).sum())))
+    hip.check_range()
 
 
 def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
@@ -1615,7 +1799,7 @@ def test_interpolate_u8_direct_frame_equals_rounded_fp64_frame(hip, dev, model, 
     t = torch.tensor([[0.5]], device=dev)
     img, none = Hn.interpolate_u8(m, a, u8, t)
     assert none is None and img.dtype == torch.uint8 and img.shape == (1, 3, H, W)
-    assert m.vfinet.emit_u8 is None
+    assert not hasattr(m.vfinet, "emit_u8")                              # the request is an argument of the call, not model state
     with torch.no_grad():
         pyr = hip.ingest_pyramid(u8, a.S_tst + 1)
         pred, _ = m([None] * (a.S_tst + 1), t, normInput=pyr, is_training=False, validation=False)
