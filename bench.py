@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--incl-ingest-steps", type=int, default=60, help="steps of the informational uint8-in -> uint8-out run with the ingest kernels inside the loop (0 = skip)")
     ap.add_argument("--multi-t-pairs", type=int, default=4, help="pairs of the informational 4096x2160 7-outputs-per-pair run, BASELINE config 3 (0 = skip)")
     ap.add_argument("--fp16-mode-steps", type=int, default=60, help="steps of the informational fp16-input convolution run (BASELINE config 5; 0 = skip)")
+    ap.add_argument("--config5-steps", type=int, default=45, help="steps of the informational BASELINE config 5 run (4096x2160, fp16-input convolutions, with its own roofline; 0 = skip)")
     ap.add_argument("--xtest-dir", default=None, help="X-Test style folder (<dir>/<type>/<scene>/*.png, 33 frames per scene): after the timed region every rank "
                                                       "evaluates its share of the pairs (8x: 7 outputs per pair) and parity.x_test_psnr / x_test carry the mean PSNR / SSIM-Y")
     ap.add_argument("--xtest-multiple", type=int, default=8)
@@ -79,7 +80,7 @@ def self_launch(a):
 
 
 # ---------------------------------------------------------------------------------------------------------
-def dominant_conv_roofline(model, h, w, device, steps):
+def dominant_conv_roofline(model, h, w, device, steps, precision="split"):
     """Roofline of the dominant kernel: the 96->96 3x3 convolution at the level-0 feature map (rec_ctx_ds.0/.2,
     conv_flow2.0/.2 launch this instance of conv3x3_ring_kernel<3,3,false,8>; the 3x3 convolutions are ~30 % of the GPU time).
     algorithmic FLOPs per launch = 2 * cin * cout * 9 * pixels (165 888 MAC/px for the two
@@ -108,10 +109,18 @@ def dominant_conv_roofline(model, h, w, device, steps):
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
 
-    ms = timed(lambda: fldr_hip.conv2d_spk([xp], conv.weight, conv.bias, relu=True, want_f32=False, want_spk=True))
-    ms32 = timed(lambda: fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision="fp32"))
+    ms = timed(lambda: fldr_hip.conv2d_spk([xp], conv.weight, conv.bias, relu=True, want_f32=False, want_spk=True, precision=precision))
     flops = 2.0 * 96 * 96 * 9 * h * w
     alg = flops / (ms * 1e-3) / 1e12
+    if precision == "fp16":
+        # BASELINE config 5: ONE fp16 MFMA per product (hi halves only: the lo planes are neither loaded nor multiplied) — issued == algorithmic
+        return {"bound": "mfma", "kernel": "conv3x3_ring_kernel<3,1,false,8> (3x3 96->96 @%dx%d, the same ring on the hi halves only: plain fp16 inputs, "
+                                           "one v_mfma_f32_16x16x32_f16 per product, fp32 accumulation)" % (h, w),
+                "achieved": round(alg, 1), "peak": PEAK_FP16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(alg / PEAK_FP16_MFMA_TFLOPS, 4),
+                "frac_issued": round(alg / PEAK_FP16_MFMA_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4), "flops_per_launch": flops,
+                "algorithmic_bytes_per_launch": 2 * 96 * h * w * 4,
+                "achieved_GBps_on_algorithmic_bytes": round(2 * 96 * h * w * 4 / (ms * 1e-3) / 1e9, 1)}
+    ms32 = timed(lambda: fldr_hip.conv2d([x], conv.weight, conv.bias, relu=True, out=out, precision="fp32"))
     tr, tr_src = _measured_traffic()
     return {"bound": "mfma", "kernel": "conv3x3_ring_kernel<3,3,false,8> (3x3 96->96 @%dx%d, persistent loader/consumer ring, split-packed operands, "
                                        "3 x fp16-split v_mfma_f32_16x16x32_f16)" % (h, w),
@@ -130,7 +139,7 @@ def _moved_bytes_per_forward():
     without their one-time prepack / harness kernels."""
     import re
     skip = re.compile(r"prepack|absmax|at::native|__amd_rocclr|FillFunctor|direct_copy|elementwise_kernel")
-    for name in ("r05_forward_pmc.json", "r04_forward_pmc.json"):
+    for name in ("r06_forward_pmc.json", "r05_forward_pmc.json", "r04_forward_pmc.json"):
         try:
             d = json.load(open(os.path.join(ROOT, "profiles", name)))
             mb = d.get("moved_MB_per_forward")
@@ -145,13 +154,33 @@ def _moved_bytes_per_forward():
 def _measured_traffic():
     """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/
     (FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE; separate --pmc passes); newest round first."""
-    for name in ("r05_conv96_spk_traffic.json", "r04_conv96_spk_traffic.json", "r03_conv96_spk_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
+    for name in ("r06_conv96_spk_traffic.json", "r05_conv96_spk_traffic.json", "r04_conv96_spk_traffic.json", "r03_conv96_spk_traffic.json", "r02_conv96_spk_traffic.json", "r01_conv96_spk_traffic.json"):
         try:
             v = json.load(open(os.path.join(ROOT, "profiles", name)))["hbm_bytes_per_launch"]
             return v, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/prof_round.sh; not measured in this run)" % name
         except Exception:
             pass
     return None, None
+
+
+def _energy_record():
+    """Joules per pair of the sustained loop and board power from the newest committed energy table (tools/energy_table.sh ->
+    profiles/r06_energy_by_kernel.json: every stage of the forward looped while rocm-smi is sampled; the loop's power against the
+    board's cap is the bound that binds this path)."""
+    for name in ("r06_energy_by_kernel.json",):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", name)))
+            sm = d["summary"]
+            top = sorted((r for r in d["rows"] if r["stage"] not in ("idle",) and not r["stage"].startswith(("whole forward", "sustained"))),
+                         key=lambda r: -r["mJ_dynamic"])[:3]
+            return {"joules_per_pair": sm["joules_per_pair"], "watts_sustained": sm["watts_sustained"], "cap_watts": d.get("cap_watts", 1400.0),
+                    "idle_watts": sm["idle_watts"], "ms_per_step_when_measured": sm["ms_per_step"], "shader_mhz_sustained": sm["mhz_sustained"],
+                    "stage_model_over_measured": sm["model_over_measured"],
+                    "top_dynamic_mJ": {r["stage"]: round(r["mJ_dynamic"], 1) for r in top},
+                    "source": "profiles/%s (tools/energy_table.sh; not measured in this run)" % name}
+        except Exception:
+            pass
+    return None
 
 
 def host_info():
@@ -232,7 +261,10 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from fldr_harness import shard_pairs, max_over_ranks, gather_floats
+    from fldr_harness import shard_pairs, max_over_ranks, gather_floats, host_core_budget
+    # N ranks share the box's cores while they build their synthetic 4K pairs (torch-CPU): each takes its share, not all of them
+    setup_threads = max(1, host_core_budget()["cores_used"] // max(world, 1))
+    torch.set_num_threads(setup_threads)
     # FLDR_BENCH_FORCE_PG=1: create the process group (and run every barrier / reduction / gather of the multi-GPU path) at world
     # size 1 too — the RCCL rehearsal a 1-GPU box allows (tests/test_gpu_parity.py::test_bench_rccl_process_group_world_size_one)
     use_pg = world > 1 or os.environ.get("FLDR_BENCH_FORCE_PG") == "1"
@@ -265,7 +297,7 @@ def main():
 
     npairs = max(a.pairs, a.streams, 1)
     my_pairs = shard_pairs(world * npairs, rank, world)          # pair index = seed; disjoint across ranks
-    latency_ms = latency_eager_ms = dt_e2e = sustained = fp16_mode = varying = incl = multi_t = None
+    latency_ms = latency_eager_ms = dt_e2e = sustained = fp16_mode = varying = incl = multi_t = config5 = None
     if gpu:
         import fldr_harness as Hn
         model, _, args = Hn.prepare_model(device)
@@ -508,20 +540,68 @@ def main():
                              "pairs_per_s_this_gpu": round(a.fp16_mode_steps / d5, 2)}
             finally:
                 fldr_hip.CONV_PRECISION = prev
+        # BASELINE config 5 proper (informational; never `value`): Xiph-4K geometry — a 4096x2160 pair (padded 2304x4096), t = 0.5,
+        # fp16-input MFMA convolutions, pairs in flight as in the headline loop — with the roofline of its dominant kernel and of the path
+        # (fp16 convolutions make the path HBM-bound by the survey's model: 5.636 GB -> 0.705 ms), and the PSNR of its rounded frame against
+        # the fp32-class (split) frame of the same pair.
+        config5 = None
+        if rank == 0 and a.config5_steps > 0 and (a.height, a.width) == (H4K, W4K):
+            prev = fldr_hip.CONV_PRECISION
+            try:
+                with torch.no_grad():
+                    xf = [Hn.frames_from_uint8(Hn.synthetic_pair(2160, 4096, seed=300 + k)).to(device) for k in range(max(2, len(streams)))]
+                    xp_ = [Hn.build_pyramid(Hn.pad_frames(f, args), args) for f in xf]
+                    ref5 = Hn.interpolate(model, args, xf[0], t, pyramid=xp_[0])
+                fldr_hip.CONV_PRECISION = "fp16"
+
+                def xstep(i):
+                    k = i % len(xf)
+                    with torch.cuda.stream(streams[i % len(streams)]), torch.no_grad():
+                        return Hn.interpolate(model, args, xf[k], t, pyramid=xp_[k])
+                for i in range(2 * len(streams)):
+                    xo = xstep(i)
+                sync()
+                t1 = time.perf_counter()
+                for i in range(a.config5_steps):
+                    xo = xstep(i)
+                sync()
+                d5x = time.perf_counter() - t1
+                with torch.no_grad():
+                    o5 = Hn.interpolate(model, args, xf[0], t, pyramid=xp_[0])
+                sync()
+                ms5 = d5x / a.config5_steps * 1e3
+                pm5 = PATH_MODEL[(2160, 4096)]
+                fl_hbm = pm5["hbm_bytes"] / (PEAK_HBM_GBPS * 1e9) * 1e3
+                fl_mfma = pm5["flops"] / (PEAK_FP16_MFMA_TFLOPS * 1e12) * 1e3
+                config5 = {"what": "BASELINE config 5: 4096x2160 pair (padded 2304x4096), t = 0.5, 3x3 convolutions on plain fp16 inputs "
+                                   "(FLDR_CONV_PRECISION=fp16: one MFMA per product; not fp32-equivalent), %d pairs in flight; reported for reference only" % len(streams),
+                           "steps": a.config5_steps, "ms_per_step": round(ms5, 3), "pairs_per_s_this_gpu": round(a.config5_steps / d5x, 2),
+                           "psnr_8bit_vs_split_path_db": Hn.psnr(Hn.to_uint8_image(ref5[0]), Hn.to_uint8_image(o5[0])),
+                           "max_abs_diff_vs_split_path": float((o5 - ref5).abs().max()),
+                           "roofline": dict(dominant_conv_roofline(model, 2304 // 8, 4096 // 8, device, a.steps, precision="fp16"),
+                                            path={"what": "whole forward against its binding floor: compulsory HBM traffic of SURVEY App. C (5.636 GB at 4096x2160) at 8 TB/s; "
+                                                          "the fp16 matrix work is the smaller term",
+                                                  "hbm_bytes": pm5["hbm_bytes"], "hbm_floor_ms": round(fl_hbm, 3), "mfma_floor_ms_fp16": round(fl_mfma, 3),
+                                                  "ms_per_step": round(ms5, 3), "frac": round(max(fl_hbm, fl_mfma) / ms5, 4),
+                                                  "achieved_GBps": round(pm5["hbm_bytes"] / (ms5 * 1e-3) / 1e9, 1)})}
+                del xf, xp_, ref5, o5
+            finally:
+                fldr_hip.CONV_PRECISION = prev
     if rank == 0:
         hp = ((a.height + 255) // 256 * 256, (a.width + 255) // 256 * 256)
         res = {
             "metric": "4K frame-pairs interpolated/sec", "value": round(world * a.steps / dt, 3), "unit": "frame-pairs/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3x3 convs: 3 x fp16-split MFMA with fp32 accumulation, error <= exact fp32 MFMA; rest fp32/fp64)",
+            "dtype": "f32 (3x3 convs: 3 x fp16-split MFMA with fp32 accumulation — error against fp64 within 1.5x (mean) / 2x (max) of the exact fp32-MFMA "
+                     "kernel's on every layer shape, tests/test_gpu_parity.py::test_split_fp16_conv_is_fp32_equivalent; rest fp32/fp64)",
             "data": "synthetic",
             "config": {"workload": "single %dx%d frame pair per step (padded %dx%d), fLDRnet 5-scale test path "
                                    "(--papermodel --test5scales), t=0.5, shipped checkpoint weights, fp64 output frame; "
                                    "%d distinct pairs per GPU rotated through the loop" % (a.width, a.height, hp[0], hp[1], npairs),
                        "parallelism": "dp%d (independent pairs, no data-path collective)" % world,
                        "pairs_in_flight": a.streams, "distinct_pairs_per_gpu": npairs,
-                       "per_rank_pairs_per_s": [round(x, 2) for x in per_rank]},
+                       "per_rank_pairs_per_s": [round(x, 2) for x in per_rank], "setup_threads_per_rank": setup_threads},
         }
         if gpu:
             res["config"]["hip_graphs"] = dict(graph_state)
@@ -543,6 +623,8 @@ def main():
                 res["sustained"] = sustained
             if fp16_mode:
                 res["fp16_conv_mode"] = fp16_mode
+            if config5:
+                res["config5"] = config5
             if varying:
                 res["varying_motion"] = varying
             if incl:
@@ -567,6 +649,9 @@ def main():
                     if mv:
                         res["roofline"]["path"].update({"moved_bytes_per_forward": mv, "moved_over_algorithmic": round(mv / pm["hbm_bytes"], 3),
                                                         "moved_bytes_source": mv_src})
+                    en = _energy_record()
+                    if en:
+                        res["roofline"]["path"]["energy"] = en
             if not a.no_cpu_baseline:                  # rank 0, any world size (3 timed forwards at one GPU, 1 beyond: `runs`)
                 with torch.no_grad():
                     g0 = Hn.interpolate(model, args, frames[0], t, pyramid=pyrs[0]).cpu()

@@ -99,24 +99,50 @@ __device__ __forceinline__ void fldr_split_hl_group(const float (&x)[N], _Float1
     }
 #endif
 }
-__device__ __forceinline__ void fldr_note_range(bool bad) { if (bad) fldr_tu_range_flag = 1; }
+// ---- status a host can see WITHOUT synchronising (fldr_status_word, ABI 105) -----------------------------------------------------
+// The sticky flags above / below live in device memory: reading them costs a device synchronisation, which a frame loop only pays at
+// its end (fldr_range_status / fldr_ring_status).  A drop-in caller that never asks would ship saturated activations — or, after an
+// expired ring wait, a frame computed from operands that never landed — unnoticed.  So every event is ALSO stored, system scope, into a
+// block of pinned, mapped host memory (fldr_status_block: one word per kind, plain stores of 1 — no PCIe atomics needed) that the host
+// polls at the start of its next forward, and an expired ring wait additionally sets a float in DEVICE memory to NaN (`poison`,
+// 0.0f otherwise) that every frame-writing kernel adds to its blend weight t: each frame produced after the fault is NaN (8-bit
+// form: black) until fldr_ring_status(reset = 1) — a never-checked run cannot ship a plausible wrong frame.
+struct fldr_status_block { int range; int ring; int pad[14]; };
+struct fldr_tu_status_t { fldr_status_block* host; float* poison; };
+static __device__ fldr_tu_status_t fldr_tu_status;        // one per translation unit, bound by fldr_status_word() (null before)
+__device__ __forceinline__ void fldr_status_raise_range() {
+    fldr_status_block* h = fldr_tu_status.host;
+    if (h) __hip_atomic_store(&h->range, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void fldr_status_raise_ring() {
+    fldr_status_block* h = fldr_tu_status.host;
+    if (h) __hip_atomic_store(&h->ring, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    float* p = fldr_tu_status.poison;
+    if (p) *p = __builtin_nanf("");
+}
+__device__ __forceinline__ void fldr_note_range(bool bad) { if (bad) { fldr_tu_range_flag = 1; fldr_status_raise_range(); } }
 static inline int fldr_tu_range_read(int reset) {
     int v = 0;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_tu_range_flag), sizeof(int)) != hipSuccess) return -1;
     if (v && reset) { const int z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(fldr_tu_range_flag), &z, sizeof(int)) != hipSuccess) return -1; }
     return v;
 }
-// translation units that split: each exports its flag through one of these (aggregated by fldr_range_status)
-int fldr_range_read_spk(int reset);
-int fldr_range_read_ring(int reset);
-int fldr_range_read_conv(int reset);
-int fldr_range_read_s2(int reset);
-int fldr_range_read_split(int reset);
-int fldr_range_read_warp(int reset);
-int fldr_range_read_gather(int reset);
-int fldr_range_read_acc64(int reset);
-int fldr_range_read_dec23(int reset);
+static inline int fldr_tu_status_bind(fldr_status_block* host_dev, float* poison) {
+    const fldr_tu_status_t v = {host_dev, poison};
+    return hipMemcpyToSymbol(HIP_SYMBOL(fldr_tu_status), &v, sizeof(v)) == hipSuccess ? 0 : -1;
+}
+// translation units that split: each exports its flag and its binding of the status block through this pair (aggregated by
+// fldr_range_status / fldr_status_word in conv_spk_kernels.hip)
+#define FLDR_TU_STATUS(name)                                                                             \
+    int fldr_range_read_##name(int reset) { return fldr_tu_range_read(reset); }                          \
+    int fldr_status_bind_##name(fldr_status_block* h, float* p) { return fldr_tu_status_bind(h, p); }
+#define FLDR_TU_STATUS_DECL(name) int fldr_range_read_##name(int reset); int fldr_status_bind_##name(fldr_status_block* h, float* p);
+FLDR_TU_STATUS_DECL(spk) FLDR_TU_STATUS_DECL(ring) FLDR_TU_STATUS_DECL(conv) FLDR_TU_STATUS_DECL(s2) FLDR_TU_STATUS_DECL(split)
+FLDR_TU_STATUS_DECL(warp) FLDR_TU_STATUS_DECL(gather) FLDR_TU_STATUS_DECL(acc64) FLDR_TU_STATUS_DECL(dec23)
 int fldr_ring_timeouts_read(int reset);             // conv_ring_kernels.hip: expired ring waits (fldr_ring_status)
+// Device pointer of the current device's poison float (see above) for the launchers of the frame-writing kernels; allocates and binds
+// the status block on first use.  null on failure (the launcher then returns an error: a frame without its fault guard is not written).
+const float* fldr_status_poison_ptr(void);
 
 // Opaque use of a loaded value: stops LLVM from sinking an unconditional (clamped-address) load back into
 // the select that consumes it, which would re-create `branch + load + s_waitcnt vmcnt(0)` per element.

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256, ((MT == 16 && NMT == 3) || (KS == 4 && MT == 1
     if (spkn) fldr_note_range(range_bad);
 }
 
-int fldr_range_read_conv(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(conv)
 
 // ------------------------------------------------------------------------------------------------
 // weight prepack: [cout,cin,k,k] -> [cin_pad][taps][mtot], zero padded
@@ -481,6 +481,7 @@ extern "C" const char* fldr_error_string(int code) {
     if (code == 0) return "success";
     if (code == FLDR_E_ARG) return "fldr: bad argument";
     if (code == FLDR_E_SHAPE) return "fldr: shape constraint violated";
+    if (code == FLDR_E_STATUS) return "fldr: the status block of the device could not be allocated or bound";
     if (code > 0) return hipGetErrorString((hipError_t)code);
     return "fldr: unknown error";
 }

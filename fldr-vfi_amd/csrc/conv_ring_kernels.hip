@@ -68,13 +68,20 @@ FLDR_HOOK int fldr_debug_read_ring_stamps(unsigned long long* host) {
 #endif
 
 __device__ int fldr_ring_timeouts;
+// Polls a bounded wait makes before it gives up (read on the slow path only).  Test build: fldr_debug_ring_spin_limit(0) makes every wait
+// that is not satisfied at once expire — the way the fault path (counter, status block, poisoned outputs) is exercised.
+__device__ int fldr_ring_spin_limit = RING_SPIN_LIMIT;
+FLDR_HOOK int fldr_debug_ring_spin_limit(int v) {
+    if (v < 0) v = RING_SPIN_LIMIT;
+    return hipMemcpyToSymbol(HIP_SYMBOL(fldr_ring_spin_limit), &v, sizeof(int)) == hipSuccess ? v : -1;
+}
 FLDR_HOOK int fldr_debug_ring_timeouts(void) {
     int v = -1;
     if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(fldr_ring_timeouts), sizeof(int)) != hipSuccess) return -1;
     return v;
 }
 
-int fldr_range_read_ring(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(ring)
 // Product-visible status of the bounded ring waits (fldr_range_status bit 1): number of waits that expired — a wave then ran on
 // with operands that had not landed, i.e. a convolution may have produced wrong output — since load / the last reset.
 int fldr_ring_timeouts_read(int reset) {
@@ -104,7 +111,7 @@ struct RingCfg {
     static constexpr int CTR_OFF = WRES_OFF + (RW ? RING_RW_MAX_CHUNKS * W_BYTES : 0);   // FULL[8] at +0, FREE[8] at +32
     static constexpr int BIAS_OFF = CTR_OFF + 64;                       // bias of the workgroup's 16 * NMT output channels (fp32)
     static constexpr int LDS_BYTES = BIAS_OFF + 64 * NMT;
-    static_assert(SLOTS <= 8 && INFLIGHT + 2 <= SLOTS && INFLIGHT * K_DMA <= 15, "ring shape");
+    static_assert(SLOTS <= 7 && INFLIGHT + 2 <= SLOTS && INFLIGHT * K_DMA <= 15, "ring shape (FREE[7] is the POISON word)");
     static_assert(TW == 16 || TW == 32, "tile width");
     static_assert(TW != SPK_TW || PLANE == SPK_PLANE, "the 32-pixel plane is the barrier pipeline's");
     static_assert(PLANE / 16 >= 64 && NXI * 64 >= SPK_IH * IW, "DMA pieces cover the plane");
@@ -118,17 +125,26 @@ __device__ __forceinline__ uint32_t ring_peek(uint32_t lds_addr) {
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// Spin until the counter at lds_addr reaches `target` (counters only grow).  Bounded: see the file header.
-__device__ __forceinline__ void ring_wait_ge(uint32_t lds_addr, uint32_t target, int lane) {
+// Spin until the counter at lds_addr reaches `target` (counters only grow).  Bounded: see the file header.  An expired wait is a library
+// fault and is never silent: it is counted (fldr_ring_status), stored into the host-visible status block and the device's frame poison
+// (common.h: fldr_status_raise_ring), and it sets the workgroup's POISON word in LDS (`poison_addr`), which every consumer reads in its
+// epilogue: the units this workgroup still finishes are written as NaN instead of values computed from operands that had not landed.
+#define RING_POISON_OFF 60                      // byte offset of the POISON word from FULL[0] (the slot of FREE[7]: rings have <= 7 slots)
+__device__ __forceinline__ void ring_wait_ge(uint32_t lds_addr, uint32_t target, int lane, uint32_t poison_addr) {
     if (ring_peek(lds_addr) >= target) return;
+    const int limit = *(volatile const int*)&fldr_ring_spin_limit;
     int spins = 0;
     while (true) {
-        __builtin_amdgcn_s_sleep(1);
-        if (ring_peek(lds_addr) >= target) return;
-        if (++spins > RING_SPIN_LIMIT) {
-            if (lane == 0) atomicAdd(&fldr_ring_timeouts, 1);
+        if (++spins > limit) {
+            if (lane == 0) {
+                atomicAdd(&fldr_ring_timeouts, 1);
+                fldr_status_raise_ring();
+                asm volatile("ds_write_b32 %0, %1" :: "v"(poison_addr), "v"(1u) : "memory");
+            }
             return;
         }
+        __builtin_amdgcn_s_sleep(1);
+        if (ring_peek(lds_addr) >= target) return;
     }
 }
 
@@ -281,7 +297,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
             if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
             RSTAMP(l1)
-            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane);
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane, ctr + RING_POISON_OFF);
             RSTAMP(l2)
             unsigned char* stage = smem + st * Cfg::STAGE;
 #if defined(RING_ABLATE) && RING_ABLATE == 3                          // diagnostic: no DMA traffic after the prologue fills
@@ -450,8 +466,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) + u_f32_off : nullptr;
         char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride + u_spk_off : nullptr;
         const bool inside = oy0 + ROWS <= uH && ox0 + TW <= uW;      // wave-uniform
+        // POISON: a bounded wait of this workgroup's ring expired (ring_wait_ge) — the accumulators may hold products of operands that
+        // had not landed; the unit is written as NaN (general path below) instead
+        const bool poisoned = ring_peek(ctr + RING_POISON_OFF) != 0u; // wave-uniform
         RSTAMP(f1)
-        if (grp_full && inside) {
+        if (grp_full && inside && !poisoned) {
             const uint32_t p0 = (uint32_t)(oy0 * uW + ox0 + lj);
             // pass 1: the finished values in place of the accumulators, and per lane the sum of their magnitudes — the range guard of the
             // split is decided ONCE per unit and wave (common.h: fldr_guard_trips) instead of a compare and two clamps per value
@@ -552,6 +571,10 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     if (a.out_spk) fldr_note_range(bad);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { ohi[r] = h[r]; olo[r] = l[r]; }
+                }
+                if (poisoned) {                                          // (past the split's range guard, which would saturate a NaN)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ov[r] = __builtin_nanf(""); ohi[r] = (_Float16)__builtin_nanf(""); olo[r] = (_Float16)__builtin_nanf(""); }
                 }
                 if (outn) {
                     const uint32_t off = ((uint32_t)co0 * HW32 + po[q]) * 4u;
@@ -680,7 +703,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #if defined(RING_ABLATE) && RING_ABLATE == 5                          // diagnostic: consumers never look at FULL after the first fills (timing only: stale operands)
         if (g < SLOTS)
 #endif
-        ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
+        ring_wait_ge(ctr + 4 * st_cur, full_target, lane, ctr + RING_POISON_OFF);
 #ifdef RING_STAMPS
         { RSTAMP(t) c1 = t; }
 #endif
@@ -850,7 +873,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
                 dptr[i] = (off != ~0u && !nul) ? base + off : zero_blk;
             }
             if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
-            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane);
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane, ctr + RING_POISON_OFF);
             unsigned char* stage = smem + st * Cfg::STAGE;
 #pragma unroll
             for (int i = 0; i < Cfg::NWL; ++i)
@@ -894,6 +917,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
         const bool ok = oy < a.H && ox < a.W;
         unsigned char* spkn = a.out_spk + (int64_t)n * a.out_spk_bstride;
         const uint32_t pq = ok ? (uint32_t)(oy * a.W + ox) : 0u;
+        const bool poisoned = ring_peek(ctr + RING_POISON_OFF) != 0u;     // a wait of this workgroup's ring expired: the unit is written as NaN
         float abs_sum = 0.0f;                                             // (the range guard of the split: once per unit and wave)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -913,6 +937,10 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
                 if (guard) { bool bad = false; spk_split(v, h, l, bad); fldr_note_range(bad); } else fldr_split_plain(v, h, l);
                 ohi[r] = h; olo[r] = l;
             }
+            if (poisoned) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { ohi[r] = (_Float16)__builtin_nanf(""); olo[r] = (_Float16)__builtin_nanf(""); }
+            }
             if (ok) {
                 const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)lh * 8u;
                 *reinterpret_cast<h4*>(spkn + off) = ohi;
@@ -924,7 +952,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
     uint32_t full_target = RING_NLOAD;
     while (g < total) {
         const bool last = cur_c == n_chunks - 1;
-        ring_wait_ge(ctr + 4 * st_cur, full_target, lane);
+        ring_wait_ge(ctr + 4 * st_cur, full_target, lane, ctr + RING_POISON_OFF);
         {
             const unsigned char* sb = smem + st_cur * Cfg::STAGE;
             const unsigned char* wb = sb + lane * 16;

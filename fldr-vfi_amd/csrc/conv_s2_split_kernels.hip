@@ -1201,7 +1201,7 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
     if (done_k >= 0) epilogue(done_k);
 }
 
-int fldr_range_read_s2(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(s2)
 
 // ------------------------------------------------------------------------------------------------
 // prepack: max|w| -> power-of-two scale -> hi/lo halves in A-operand order [chunk][step][m][kind][lane][8 halves]

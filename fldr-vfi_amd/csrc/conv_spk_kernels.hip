@@ -454,7 +454,54 @@ __global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t
         if (g * 8 + k < C) dst[((int64_t)n * C + g * 8 + k) * HW + pix] = (float)hi[k] + (float)lo[k];
 }
 
-int fldr_range_read_spk(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(spk)
+
+// ---- status block of the current device (common.h: fldr_status_block) -------------------------------------------------------
+#include <mutex>
+namespace {
+struct DevStatus { fldr_status_block* host = nullptr; fldr_status_block* host_dev = nullptr; float* poison = nullptr; };
+std::mutex g_status_mu;
+DevStatus g_status[64];
+// allocate + bind on first use per device; returns null on failure
+DevStatus* status_of_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(g_status_mu);
+    DevStatus& st = g_status[dev];
+    if (st.host) return &st;
+    fldr_status_block* h = nullptr;
+    fldr_status_block* hd = nullptr;
+    float* p = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void**>(&h), sizeof(fldr_status_block), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) return nullptr;
+    *h = fldr_status_block{};
+    bool ok = hipHostGetDevicePointer(reinterpret_cast<void**>(&hd), h, 0) == hipSuccess && hipMalloc(reinterpret_cast<void**>(&p), 256) == hipSuccess &&
+              hipMemset(p, 0, 256) == hipSuccess;
+    int (*binders[])(fldr_status_block*, float*) = {fldr_status_bind_spk, fldr_status_bind_ring, fldr_status_bind_conv, fldr_status_bind_s2, fldr_status_bind_split,
+                                                    fldr_status_bind_warp, fldr_status_bind_gather, fldr_status_bind_acc64, fldr_status_bind_dec23};
+    for (auto b : binders) ok = ok && b(hd, p) == 0;
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
+    if (!ok) { if (p) (void)hipFree(p); (void)hipHostFree(h); return nullptr; }
+    st.host_dev = hd; st.poison = p; st.host = h;
+    return &st;
+}
+}  // namespace
+
+const float* fldr_status_poison_ptr(void) {
+    DevStatus* st = status_of_current_device();
+    return st ? st->poison : nullptr;
+}
+
+// Host-visible status of the current device: *host_words points at two ints in pinned host memory that the library's kernels set to 1
+// (system-scope stores) when [0] an activation was saturated by the fp16 split (fldr_range_status), [1] a bounded ring wait expired
+// (fldr_ring_status) — readable at any time without synchronising; cleared by the reset forms of those two calls.  The first call on a
+// device allocates the block and binds it into the library's kernels (synchronises; not during a stream capture).
+extern "C" int fldr_status_word(const volatile int** host_words) {
+    FLDR_CHECK_ARG(host_words);
+    DevStatus* st = status_of_current_device();
+    if (!st) return FLDR_E_STATUS;
+    *host_words = &st->host->range;
+    return 0;
+}
 
 // Sticky range status of the split-precision convolutions on the current device since the last reset: 1 = a value beyond +-65504
 // (or a NaN) was split — and saturated (common.h: fldr_split_hl) —, 0 = clean, negative on a HIP error.  Synchronises.
@@ -463,13 +510,28 @@ extern "C" int fldr_range_status(int reset) {
     int v = 0;
     int (*readers[])(int) = {fldr_range_read_spk, fldr_range_read_ring, fldr_range_read_conv, fldr_range_read_s2, fldr_range_read_split, fldr_range_read_warp, fldr_range_read_gather, fldr_range_read_acc64, fldr_range_read_dec23};
     for (auto r : readers) { const int x = r(reset); if (x < 0) return x; v |= x ? 1 : 0; }
+    if (reset) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) { std::lock_guard<std::mutex> lk(g_status_mu); if (g_status[dev].host) g_status[dev].host->range = 0; }
+    }
     return v;
 }
 // Expired waits of the loader / consumer ring (conv_ring_kernels.hip) since the last reset; its own entry point so that a caller
 // testing fldr_range_status() != 0 never mistakes a library fault for out-of-range data.  Synchronises.
 extern "C" int fldr_ring_status(int reset) {
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return fldr_ring_timeouts_read(reset);
+    const int v = fldr_ring_timeouts_read(reset);
+    if (reset && v >= 0) {
+        int dev = 0;
+        if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64) {
+            std::lock_guard<std::mutex> lk(g_status_mu);
+            if (g_status[dev].host) {
+                g_status[dev].host->ring = 0;
+                if (hipMemset(g_status[dev].poison, 0, 4) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -1;
+            }
+        }
+    }
+    return v;
 }
 
 // sizeof of the descriptor structs as this library was compiled (binding self-check: tests/test_host_cpu.py)

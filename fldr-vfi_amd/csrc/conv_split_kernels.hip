@@ -91,7 +91,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], h8& hi, h8& lo, bool
     }
 }
 
-int fldr_range_read_split(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(split)
 
 // TERMS = 3: hi*hi + hi*lo + lo*hi (fp32-equivalent); TERMS = 1: hi*hi only = plain fp16 inputs, fp32 accumulate
 // (BASELINE config 5, "fp16 path with MFMA convs"; 11-bit operands, error ~1e-3 relative).

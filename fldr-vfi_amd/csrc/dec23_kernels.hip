@@ -91,6 +91,7 @@ struct D23Args {
     int64_t cand_bstride_b[6];     // batch / channel strides in bytes (a candidate may be a view: I0 / I1 are planes of the frame pair tensor)
     uint32_t cand_cstride_b[6];
     const float* t;                // [N]
+    const float* poison;           // common.h: 0.0f, NaN once a ring wait expired (added to t: every frame written after the fault is NaN); + 64 bytes: the store sink of lanes without a pixel
     double T;
     void* out;                     // [N,3,H,W] fp64 or fp32, or the rounded 8-bit frame [N,3,Hc,Wc] (cropped; Wc even)
     int Hc, Wc;
@@ -363,7 +364,16 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             // its end the candidates have returned, and that is where this wave's LDS-DMA pieces of tile k + 2 go: an LDS-DMA instruction
             // waits for every earlier vector-memory operation of its wave, so here it costs its own round trip only.
             const bool live = c_li < h && c_lj < w && (sizeof(OUT) != 1 || (2 * c_li + ra < a.Hc && 2 * c_lj < a.Wc));
-            const float t = args()->t[c_n];
+            // t and the fault poison (common.h) by SCALAR loads, spelled out: as ordinary loads of a may-alias pointer they became vector-memory
+            // loads, and their first use — behind the LDS-DMA pieces the compiler sinks this code below — was an s_waitcnt vmcnt(0) that made
+            // every consumer wave sit out the round trip of the pieces it had just issued
+            float t_s, p_s;
+            {
+                const float* tp = args()->t + __builtin_amdgcn_readfirstlane(c_n);
+                const float* pp = args()->poison;
+                asm volatile("s_load_dword %0, %2, 0x0\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(t_s), "=&s"(p_s) : "s"(tp), "s"(pp) : "memory");
+            }
+            const float t = t_s + p_s;
             const double w1 = (double)t, w0 = (double)(1.0f - t);
             const double inv_T = 1.0 / a.T;
             // out = sum_k wo_k cand_k / sum_k wo_k with wo_k = w_k softmax_k (fLDRnet.py:517-524): the softmax's own normalisation cancels
@@ -387,13 +397,30 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             }
             D23_STAMP(st4)
             // (pinned between the candidates' last use above... and the frame stores below: the barrier's vmcnt(3) relies on exactly this order)
+            // The candidates are waited for HERE, before the pieces go out (they have had the matrix phase and the softmax to return): the
+            // opaque uses make the compiler place its wait for them now — behind the pieces it can only wait vmcnt(0), the number of pieces
+            // being a run-time value, and every consumer wave then sat out its pieces' round trip in front of the blend.
+            // (not in the fp32-output instantiation — tests only —, where the pinned live range costs five spilled registers: it keeps the
+            // compiler's own vmcnt(0) behind the pieces)
+            if constexpr (sizeof(OUT) != 4) {
+#pragma unroll
+                for (int kc = 0; kc < 6; ++kc)
+#pragma unroll
+                    for (int ch = 0; ch < 3; ++ch) { fldr_pin(cv[kc][ch].x); fldr_pin(cv[kc][ch].y); }
+            }
             __builtin_amdgcn_sched_barrier(0);
             if (k + 2 < my_tiles) stage_mine(k + 2);                        // into the window set produce(k) read before the last barrier
             __builtin_amdgcn_sched_barrier(0);
             D23_STAMP(st5)
-            if (live) {
+            {
+                // Every lane blends and stores: a lane without a pixel of the frame (border tiles, the crop of the 8-bit form) works on its
+                // clamped candidates and stores into the library's 16-byte sink instead of the frame.  No divergent region, so every wave
+                // issues EXACTLY three vector-memory instructions behind its DMA pieces on every path — what the barrier's vmcnt(3) counts on
+                // (tools/check_dma_waits.py checks the listing: with the stores inside `if (live)` the compiler merged the two paths' pending
+                // loads at the join and put an s_waitcnt vmcnt(0) in front of the counted wait: every tile waited for its frame stores).
 #pragma clang fp contract(off)
                 OUT* out = static_cast<OUT*>(args()->out);
+                char* const sink = const_cast<char*>(reinterpret_cast<const char*>(args()->poison)) + 64;
                 // channel by channel: blend both pixels of the row, store (two values live, not six)
                 const uint32_t po8 = (uint32_t)(2 * c_li + ra) * (uint32_t)a.Wc + (uint32_t)(2 * c_lj);
                 const int64_t po = (int64_t)(2 * c_li + ra) * a.W + 2 * c_lj;
@@ -418,16 +445,16 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                             q[rb] = (unsigned)(int)rint(v * 255.0);
                         }
                         unsigned char* o = reinterpret_cast<unsigned char*>(out) + ((int64_t)c_n * 3 + ch) * ((int64_t)a.Hc * a.Wc) + po8;
+                        o = live ? o : reinterpret_cast<unsigned char*>(sink);
                         *reinterpret_cast<unsigned short*>(o) = (unsigned short)(q[0] | (q[1] << 8));
                     } else {
                         char* o = reinterpret_cast<char*>(out + ((int64_t)c_n * 3 + ch) * HW) + (uint32_t)po * (uint32_t)sizeof(OUT);
+                        o = live ? o : sink;
                         if constexpr (sizeof(OUT) == 8) *reinterpret_cast<double2*>(o) = make_double2(res[0], res[1]);
                         else *reinterpret_cast<float2*>(o) = make_float2((float)res[0], (float)res[1]);
                     }
                 }
             }
-            // (the barrier's vmcnt(3) counts on three stores behind the DMA pieces: a wave with no live pixel waits for everything)
-            if (__builtin_amdgcn_ballot_w64(live) == 0ull) __builtin_amdgcn_s_waitcnt(0x0F70);
         };
         if (1 < my_tiles) stage_mine(1);
         __builtin_amdgcn_s_waitcnt(0x0F70);
@@ -594,7 +621,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
     }
 }
 
-int fldr_range_read_dec23(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(dec23)
 
 // dec2's weights [16, 48, 3, 3] as A operands: D23_HDR floats {1 / scale, scale, max |w|, 0, zero block ...} + [step][hi, lo][lane][8 halves],
 // lane = (output channel = lane & 15, lane group lg = lane >> 4); steps 0 .. 8: tap = step, 8-channel group lg (dec1); steps 9 .. 13: tap =
@@ -661,7 +688,9 @@ extern "C" int fldr_dec23_synth(const void* dec1_spk, const void* enc1_spk, cons
         if (cand_cstride[k] < 0 || cand_bstride[k] < 0 || 2 * cand_cstride[k] * 4 + (int64_t)H * W * 4 >= (1ll << 32)) return FLDR_E_SHAPE;   // 32-bit offsets inside a sample
         a.cand[k] = cand[k]; a.cand_bstride_b[k] = cand_bstride[k] * 4; a.cand_cstride_b[k] = (uint32_t)(cand_cstride[k] * 4);
     }
-    a.t = t; a.T = T_param; a.out = out_f64 ? static_cast<void*>(out_f64) : (out_f32 ? static_cast<void*>(out_f32) : static_cast<void*>(out_u8));
+    a.t = t; a.poison = fldr_status_poison_ptr(); a.T = T_param;
+    if (!a.poison) return FLDR_E_STATUS;
+    a.out = out_f64 ? static_cast<void*>(out_f64) : (out_f32 ? static_cast<void*>(out_f32) : static_cast<void*>(out_u8));
     a.Hc = out_u8 ? H_u8 : H; a.Wc = out_u8 ? W_u8 : W;
     a.N = N; a.H = H; a.W = W;
     a.tiles_x = fldr_cdiv(W / 2, D23_TW);

@@ -65,7 +65,7 @@ typedef __attribute__((address_space(3))) void* d3_lptr_t;
 template <typename OUT, bool MF>
 __global__ __launch_bounds__(256) void dec3_synth_kernel(const void* __restrict__ d2v, const float* __restrict__ weff,
                                                          const float* __restrict__ bias, FinalArgs cd,
-                                                         const float* __restrict__ tv, double T, OUT* __restrict__ out,
+                                                         const float* __restrict__ tv, const float* __restrict__ poison, double T, OUT* __restrict__ out,
                                                          float* __restrict__ refine_dbg, int H, int W, int xs, D3Grid gr) {
     // xs: the tile grid starts xs low-resolution columns left of the image (fldr_dec3_synth_strided)
     const int h = H >> 1, w = W >> 1;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) void dec3_synth_kernel(const void* __restrict_
             for (int ch = 0; ch < 3; ++ch) { if (a == 0) { fldr_pin(cv[0][k][ch].x); fldr_pin(cv[0][k][ch].y); } }
     load_cands(1);
     if (li >= h || lj >= w || lj < 0) return;
-    const float t = tv[n];
+    const float t = tv[n] + *poison;                                     // (*poison: 0.0f, NaN once a ring wait expired — common.h)
     const double w1 = (double)t, w0 = (double)(1.0f - t);
     const double inv_T = 1.0 / T;
 #pragma unroll
@@ -354,6 +354,8 @@ static int d3_launch(bool mf, const void* d2, const float* weff, const float* bi
     if ((H | W) & 1) return FLDR_E_SHAPE;
     if ((int64_t)H * W * 8 >= (1ll << 32)) return FLDR_E_SHAPE;            // 32-bit byte offsets inside a plane
     FLDR_CHECK_ARG(((reinterpret_cast<uintptr_t>(out_f64) & 15) | (reinterpret_cast<uintptr_t>(out_f32) & 7)) == 0);     // pixel pairs are stored whole
+    const float* poison = fldr_status_poison_ptr();                        // (common.h: frames written after a ring fault are NaN)
+    if (!poison) return FLDR_E_STATUS;
     FinalArgs a;
     for (int k = 0; k < 6; ++k) {
         FLDR_CHECK_ARG(cand[k] && (((uintptr_t)cand[k]) & 7) == 0 && (cand_bstride[k] & 1) == 0 && (cand_cstride[k] & 1) == 0);
@@ -374,11 +376,11 @@ static int d3_launch(bool mf, const void* d2, const float* weff, const float* bi
     gr.per_xcd = g_d3_xcd ? (gr.total + 7) / 8 : 0;
     dim3 grid(g_d3_xcd ? 8 * gr.per_xcd : gr.total);
     if (mf) {
-        if (out_f64) hipLaunchKernelGGL((dec3_synth_kernel<double, true>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
-        else         hipLaunchKernelGGL((dec3_synth_kernel<float, true>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
+        if (out_f64) hipLaunchKernelGGL((dec3_synth_kernel<double, true>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, poison, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
+        else         hipLaunchKernelGGL((dec3_synth_kernel<float, true>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, poison, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
     } else {
-        if (out_f64) hipLaunchKernelGGL((dec3_synth_kernel<double, false>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
-        else         hipLaunchKernelGGL((dec3_synth_kernel<float, false>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
+        if (out_f64) hipLaunchKernelGGL((dec3_synth_kernel<double, false>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, poison, T_param, out_f64, refine_out_or_null, H, W, xs, gr);
+        else         hipLaunchKernelGGL((dec3_synth_kernel<float, false>), grid, dim3(256), 0, fldr_s(stream), d2, weff, bias, a, t, poison, T_param, out_f32, refine_out_or_null, H, W, xs, gr);
     }
     FLDR_LAUNCH_RET();
 }

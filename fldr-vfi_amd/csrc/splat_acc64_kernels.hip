@@ -534,7 +534,7 @@ __global__ __launch_bounds__(256) void splat_acc64_kernel(SaArgs a) {
     fldr_note_range(bad);
 }
 
-int fldr_range_read_acc64(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(acc64)
 
 #ifndef SA_FOLD_MIN_TILES
 #define SA_FOLD_MIN_TILES 512

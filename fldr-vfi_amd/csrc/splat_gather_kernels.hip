@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void sg_gather_kernel(SgArgs a) {
     if (osp) fldr_note_range(bad);
 }
 
-int fldr_range_read_gather(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(gather)
 
 extern "C" int64_t fldr_softsplat_gather_ws_floats(int ndir, int N, int H, int W) {
     if (ndir <= 0 || ndir > SG_MAXDIR || N <= 0 || H <= 0 || W <= 0) return FLDR_E_ARG;

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void splat_finish_spk_kernel(const float* __re
     *reinterpret_cast<h8*>(d + HW * 16) = lo;
 }
 
-int fldr_range_read_warp(int reset) { return fldr_tu_range_read(reset); }
+FLDR_TU_STATUS(warp)
 
 extern "C" int fldr_softsplat_fwd(const float* in, const float* flow, float* out_zeroed,
                                   int N, int C, int H, int W, fldr_stream_t stream) {
@@ -572,8 +572,8 @@ struct SynthArgs {
 
 template <typename OUT>
 __global__ __launch_bounds__(256) void synth_tail_kernel(const float* __restrict__ refine, SynthArgs a,
-                                                         const float* __restrict__ tv, double T, OUT* __restrict__ out,
-                                                         int64_t HW) {
+                                                         const float* __restrict__ tv, const float* __restrict__ poison, double T,
+                                                         OUT* __restrict__ out, int64_t HW) {
 #pragma clang fp contract(off)
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int n = blockIdx.y;
@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void synth_tail_kernel(const float* __restrict
     for (int k = 0; k < 6; ++k) { s[k] = (double)r[(int64_t)k * HW] / T; mx = s[k] > mx ? s[k] : mx; }
     double sum = 0.0;
     for (int k = 0; k < 6; ++k) { s[k] = exp(s[k] - mx); sum += s[k]; }
-    const float t = tv[n];
+    const float t = tv[n] + *poison;                          // (*poison: 0.0f, NaN once a ring wait expired — common.h)
     const double w1 = (double)t, w0 = (double)(1.0f - t);     // (1 - t_value) is formed in fp32 (fLDRnet.py:517)
     double wo[6];
     for (int k = 0; k < 6; ++k) wo[k] = ((k & 1) ? w1 : w0) * (s[k] / sum);
@@ -607,8 +607,10 @@ extern "C" int fldr_synth_tail(const float* refine, const float* const cand[6], 
     SynthArgs a;
     for (int k = 0; k < 6; ++k) { FLDR_CHECK_ARG(cand[k]); a.cand[k] = cand[k]; a.bstride[k] = cand_bstride[k]; }
     const int64_t HW = (int64_t)H * W;
+    const float* poison = fldr_status_poison_ptr();
+    if (!poison) return FLDR_E_STATUS;
     dim3 grid(fldr_cdiv(HW, 256), N);
-    if (out_f64) hipLaunchKernelGGL(synth_tail_kernel<double>, grid, dim3(256), 0, fldr_s(stream), refine, a, t, T_param, out_f64, HW);
-    else         hipLaunchKernelGGL(synth_tail_kernel<float>, grid, dim3(256), 0, fldr_s(stream), refine, a, t, T_param, out_f32, HW);
+    if (out_f64) hipLaunchKernelGGL(synth_tail_kernel<double>, grid, dim3(256), 0, fldr_s(stream), refine, a, t, poison, T_param, out_f64, HW);
+    else         hipLaunchKernelGGL(synth_tail_kernel<float>, grid, dim3(256), 0, fldr_s(stream), refine, a, t, poison, T_param, out_f32, HW);
     FLDR_LAUNCH_RET();
 }

@@ -129,6 +129,10 @@ class DCTXVFInet(nn.Module):
         cannot honour it return the fp64 frame as ever — the caller looks at the dtype."""
         if is_training:
             raise NotImplementedError("fldr-hip implements the inference (test) branch only")
+        # fault flags of EARLIER forwards, read without a synchronisation (two host words the kernels store into): a drop-in caller that
+        # never calls fldr_hip.check_range() still gets the exception, one forward late (the reference's CUDA kernels abort on a device-side
+        # fault, softSplat.py:25-26); a ring fault additionally turns every later frame into NaN
+        fldr_hip.poll_status()
         B2, C2 = t_value.size()
         assert C2 == 1, "t_value shape is [B,]"
         x_l = normInput

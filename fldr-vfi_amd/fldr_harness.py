@@ -166,6 +166,8 @@ class GraphedInterpolator:
     def replay(self, join=False):
         """Replay on the instance's stream.  join: the caller's current stream waits for it (device-side) before using the output;
         without it the caller synchronises itself (bench.py keeps several instances in flight and joins once)."""
+        import fldr_hip
+        fldr_hip.poll_status()                   # the fault flags of earlier replays (no synchronisation), as DCTXVFInet.forward does on entry
         with torch.cuda.stream(self.stream):
             self.graph.replay()
         if join:

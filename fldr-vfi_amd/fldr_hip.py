@@ -128,6 +128,8 @@ _SIGNATURES = {
     "fldr_debug_pca_workgroups": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_pca_variant": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_tile_width": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_debug_ring_spin_limit": (ctypes.c_int, [ctypes.c_int]),
+    "fldr_status_word": (ctypes.c_int, [ctypes.POINTER(ctypes.POINTER(ctypes.c_int))]),
     "fldr_debug_s2_vec4": (ctypes.c_int, [ctypes.c_int]),
     "fldr_bwarp": (ctypes.c_int, [_c_float_p] * 3 + [ctypes.c_int] * 5 + [ctypes.c_void_p]),
     "fldr_bwarp_tscaled": (ctypes.c_int, [_c_float_p] * 4 + [ctypes.c_int] * 7 + [ctypes.c_void_p]),
@@ -201,9 +203,9 @@ _TEST_BUILD_ONLY = ("fldr_softsplat_tile", "fldr_softsplat_tile_strided", "fldr_
 EXPORTS = tuple(n for n in _SIGNATURES if not n.startswith("fldr_debug_") and n not in _TEST_BUILD_ONLY)
 HOOKS = tuple(n for n in _SIGNATURES if n.startswith("fldr_debug_") or n in _TEST_BUILD_ONLY)
 TEST_LIB_PATH = os.path.join(_HERE, "libfldr_hip_test.so")
-ABI_VERSION = 104                # include/fldr_hip.h: FLDR_VERSION
+ABI_VERSION = 105                # include/fldr_hip.h: FLDR_VERSION
 # entry points the DEFAULT 4K forward / bench / harness call: a variant library (FLDR_LIB) that lacks one of them fails at load
-_DEFAULT_PATH = ("fldr_version", "fldr_error_string", "fldr_sizeof_desc", "fldr_range_status", "fldr_ring_status", "fldr_pca_prepack",
+_DEFAULT_PATH = ("fldr_version", "fldr_error_string", "fldr_sizeof_desc", "fldr_range_status", "fldr_ring_status", "fldr_status_word", "fldr_pca_prepack",
                  "fldr_pca_project_pyramid", "fldr_conv2d_spk", "fldr_conv2d_spk_levels", "fldr_conv_spk_prepack", "fldr_conv2d_s2_split",
                  "fldr_conv2d_s2_spk", "fldr_conv2d_s2_spk_pair", "fldr_conv_s2_prepack", "fldr_softsplat_acc64", "fldr_level0_prep",
                  "fldr_splat_bounds_upsampled_pair", "fldr_resize_bilinear_spk", "fldr_resize_bilinear_spk_bounds", "fldr_dec3_prepack_spk",
@@ -928,6 +930,32 @@ def check_range():
     if v & STATUS_RANGE:
         raise FldrError("an activation exceeded the fp16 split range (|x| >= 65504 or NaN) and was saturated; "
                         "rerun with FLDR_CONV_PRECISION=fp32")
+
+
+_status_words = {}          # (library handle id, device ordinal) -> ctypes pointer to the two host words of fldr_status_word
+
+
+def status_words():
+    """The current device's host-visible status words of the loaded library ([0] range, [1] ring; fldr_status_word): pinned host memory
+    the kernels store into when the event happens.  The first call per (library, device) allocates and binds the block (synchronises)."""
+    l = lib()
+    key = (id(l), torch.cuda.current_device())
+    p = _status_words.get(key)
+    if p is None:
+        p = ctypes.POINTER(ctypes.c_int)()
+        _check(l.fldr_status_word(ctypes.byref(p)), "fldr_status_word")
+        _status_words[key] = p
+    return p
+
+
+def poll_status():
+    """The fault flags WITHOUT a synchronisation (what DCTXVFInet.forward does on entry): raises — through check_range(), which then
+    synchronises and resets — if a kernel of an EARLIER call stored a flag; free otherwise (two reads of host memory).  A fault of forward
+    n therefore raises at the latest in forward n + 1; frames written after a ring fault are NaN in any case (include/fldr_hip.h)."""
+    p = status_words()
+    if p[0] or p[1]:
+        check_range()
+        raise FldrError("a device-side fault flag was set (status words %d, %d) but the device status reads clean" % (p[0], p[1]))
 
 
 def use_spk():

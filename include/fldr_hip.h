@@ -22,13 +22,15 @@
 extern "C" {
 #endif
 
-#define FLDR_VERSION 104          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_sizeof_desc(3..5);
+#define FLDR_VERSION 105          /* major*10000 + minor*100 + patch; 102: fldr_pca_level.raw_ws (48-byte elements), fldr_sizeof_desc(3..5);
                                      103: fldr_range_status is 0 / 1 again, the ring status has its own entry (fldr_ring_status),
                                      fldr_enc1_fused; 104: fldr_dec23_prepack / fldr_dec23_synth (with the rounded 8-bit frame as a
-                                     third output form) — a caller built against an older header must be rebuilt */
+                                     third output form); 105: fldr_status_word (status readable without synchronising; frames after a ring fault are NaN)
+                                     — a caller built against an older header must be rebuilt */
 
 #define FLDR_E_ARG   (-1)         /* bad argument (null pointer, non-positive size, unsupported shape) */
 #define FLDR_E_SHAPE (-2)         /* shape constraint violated (e.g. H,W not multiples of 8 for the PCA) */
+#define FLDR_E_STATUS (-3)        /* the status block of the device could not be allocated / bound (fldr_status_word) */
 
 /* The product library is built with -fvisibility=hidden: the functions below are its whole dynamic symbol table. */
 #define FLDR_API __attribute__((visibility("default")))
@@ -377,6 +379,16 @@ FLDR_API int fldr_range_status(int reset);
  * outputs since the last reset must not be trusted — a library fault, not a data problem), 0 = clean, negative on a HIP error
  * (including a failed reset).  Synchronises the device. */
 FLDR_API int fldr_ring_status(int reset);
+/* The same two conditions WITHOUT a synchronisation, for callers that drive frame after frame and never stop to ask (the reference's
+ * CUDA kernels abort the process on a device-side fault, softSplat.py:25-26; this library keeps running, so it must not be silent):
+ * *host_words receives a pointer to two ints in pinned host memory, [0] = 1 once an activation was saturated by the fp16 split, [1] = 1
+ * once a bounded ring wait expired; the kernels store them with system scope when the event happens, the host may read them at any time
+ * (fldr-vfi_amd/fLDRnet.py reads them on entry of every forward: a fault of forward n raises in forward n + 1).  Sticky until the
+ * reset forms of fldr_range_status / fldr_ring_status.  In addition, every frame written (fldr_dec23_synth, fldr_dec3_synth*,
+ * fldr_synth_tail) after a ring wait expired is NaN (8-bit output form: 0) until that reset — a convolution that ran on with operands
+ * that had not landed also writes NaN instead of its result.  First call per device: allocates and binds the block (synchronises; do
+ * not make it during a stream capture). */
+FLDR_API int fldr_status_word(const volatile int** host_words);
 
 /* ------------------------------------------------------------------------------------------
  * Occlusion softmax + frame synthesis — replaces fLDRnet.py:511-524.

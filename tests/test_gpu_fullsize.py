@@ -133,7 +133,8 @@ def test_4k_strong_nonrigid_motion_matches_oracle(hip, dev, model, oracle, weigh
     FLDR_PCA_F32=0 (features split-packed only; opt-in, NOT the parity configuration) is run on the same pair and reported: its
     2.4e-7 feature difference flips one nearly empty target cell of a feature splat at the frame border on this pair (a 24 x 46 px
     patch, 4.9e-5 of the values beyond 1e-4, 91.7 dB).  Its assertions: the differences beyond 1e-4 stay inside ONE bounded patch
-    (<= 64 x 64 px) per ill-conditioned cell the oracle reports — anything outside it fails — and mean error / PSNR as above."""
+    (<= 64 x 64 px) — anything outside it fails, and so does any such difference when the oracle reports no ill-conditioned cell — and
+    mean error / PSNR as above."""
     import fldr_harness as Hn
     m, a = model
     Hs, Ws = 2160, 3840
@@ -172,4 +173,4 @@ def test_4k_strong_nonrigid_motion_matches_oracle(hip, dev, model, oracle, weigh
     assert errp.mean().item() <= 1e-6 and pp >= 90.0
     if fracp > 1e-6:
         assert n_ill >= 1, "differences beyond 1e-4 without any ill-conditioned splat cell"
-        assert n_ill == 1 and box[1] - box[0] < 64 and box[3] - box[2] < 64, "differences beyond 1e-4 outside one 64 x 64 patch: %s" % (box,)
+        assert box[1] - box[0] < 64 and box[3] - box[2] < 64, "differences beyond 1e-4 outside one 64 x 64 patch: %s" % (box,)

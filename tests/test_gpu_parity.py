@@ -1024,9 +1024,11 @@ def test_bwarp_tscaled_zmetric_resize(hip, oracle, dev):
     got = hip.bwarp_tscaled(f10.to(dev), f01.to(dev), t.to(dev), "t", "1-t")
     ills = [_bwarp_ill(oracle, f10.shape, (1 - t) * f01), _bwarp_ill(oracle, f01.shape, t * f10), _bwarp_ill(oracle, I1.shape, f01)]
     print("pixels within %.0e of the mask threshold: %s of %d" % (BWARP_BAND, [int(i.sum()) for i in ills], ills[0].numel()))
-    _cmp(got, ref, atol=1e-5, ill=ills[0], what="flowback_0")
+    # (the warped planes are FLOWS of +-7 px that change by up to 14 between neighbours: 4e-5 is 3e-6 of their range, a sample-position
+    # rounding of 1e-6 px times that gradient — the 1e-5 of the unit-range image planes below scaled to the data)
+    _cmp(got, ref, atol=4e-5, ill=ills[0], what="flowback_0")
     ref = oracle.bwarp(f01 * (1 - t), t * f10)
-    _cmp(hip.bwarp_tscaled(f01.to(dev), f10.to(dev), t.to(dev), "1-t", "t"), ref, atol=1e-5, ill=ills[1], what="flowback_1")
+    _cmp(hip.bwarp_tscaled(f01.to(dev), f10.to(dev), t.to(dev), "1-t", "t"), ref, atol=4e-5, ill=ills[1], what="flowback_1")
     alpha = -1.894
     zref = torch.mean(alpha * torch.abs(I0 - oracle.bwarp(I1, f01)), dim=1, keepdim=True)
     _cmp(hip.zmetric(I0.to(dev), I1.to(dev), f01.to(dev), alpha), zref, atol=1e-5, ill=ills[2], what="zmetric")
@@ -1260,9 +1262,11 @@ def test_level0_stages_match_reference_golden(hip, oracle, golden, dev, model, c
     H, W = pyr[0].shape[3:]
     with torch.no_grad():
         pca0 = pca_comp.to_pca_diff_f32(pyr[0].reshape(6, H, W), m.params[0], a, m.Mean8, m.EV8, m.meanVec8).view(1, 96, H // 8, W // 8)
-        _cmp(pca0, torch.from_numpy(g["pca0"]), atol=2e-6, what="pca L0")
         feat0 = m.extract_features(pca0)
-        _cmp(feat0, torch.from_numpy(g["feat0"]), atol=2e-5, what="feat L0")
+        has_l0 = "pca0" in g.files                                         # (the 200x500 fixture is stored without its level-0 tensors)
+        if has_l0:
+            _cmp(pca0, torch.from_numpy(g["pca0"]), atol=2e-6, what="pca L0")
+            _cmp(feat0, torch.from_numpy(g["feat0"]), atol=2e-5, what="feat L0")
         # the forward's own (all-level, packed) feature path at level 0 — the loop of test_model_matches_reference_golden stops at level 1
         _, pcs = pca_comp.to_pca_diff_f32_pyramid([pyr[i].reshape(6, pyr[i].shape[3], pyr[i].shape[4]) for i in range(6)], m.params, a,
                                                   m.Mean8, m.EV8, m.meanVec8, want_spk=True, want_f32=False)
@@ -1270,7 +1274,10 @@ def test_level0_stages_match_reference_golden(hip, oracle, golden, dev, model, c
         c0, c2 = m.rec_ctx_ds[0], m.rec_ctx_ds[2]
         ys = hip.conv2d_spk_levels(pp, c0.weight, c0.bias, relu=True, want_f32=False, want_spk=True)
         fl = hip.conv2d_spk_levels(ys, c2.weight, c2.bias, relu=True, residuals=pp, want_f32=True, want_spk=True)
-        _cmp(fl[0][0], torch.from_numpy(g["feat0"]), atol=2e-5, what="feat L0, packed residual")
+        if has_l0:
+            _cmp(fl[0][0], torch.from_numpy(g["feat0"]), atol=2e-5, what="feat L0, packed residual")
+        else:
+            _cmp(fl[0][0], feat0, atol=1e-6, what="feat L0: packed residual vs fp32 residual")
         flow = None
         for level in range(5, -1, -1):
             h, w = pyr[level].shape[3:]
@@ -1309,12 +1316,12 @@ def test_level0_stages_match_reference_golden(hip, oracle, golden, dev, model, c
     for ci, (y0, x0, hh, ww) in enumerate(g["crops"]):
         sl = (Ellipsis, slice(int(y0), int(y0 + hh)), slice(int(x0), int(x0 + ww)))
         # planes 12-25 carry flows in pixels of the frame (x8 upsampled): tolerance relative to their magnitude
-        worst["cat26"] = max(worst.get("cat26", 0.0), _cmp(cat[sl], torch.from_numpy(g["cat26_crops"][ci]), atol=1e-4, rtol=1e-4, ill=ill26[sl],
+        worst["cat26"] = max(worst.get("cat26", 0.0), _cmp(cat[sl], torch.from_numpy(g["cat26_crops"][ci]), atol=3e-5, rtol=1e-5, ill=ill26[sl],
                                                            what="UNet input planes, crop %d" % ci))
-        worst["im_1_0"] = max(worst.get("im_1_0", 0.0), _cmp(im_1_0[sl], torch.from_numpy(g["im_1_0_crops"][ci]), atol=1e-4, ill=ill_m10[sl], what="im_1_0 crop %d" % ci))
-        worst["im_0_1"] = max(worst.get("im_0_1", 0.0), _cmp(im_0_1[sl], torch.from_numpy(g["im_0_1_crops"][ci]), atol=1e-4, ill=ill_m01[sl], what="im_0_1 crop %d" % ci))
+        worst["im_1_0"] = max(worst.get("im_1_0", 0.0), _cmp(im_1_0[sl], torch.from_numpy(g["im_1_0_crops"][ci]), atol=2e-5, ill=ill_m10[sl], what="im_1_0 crop %d" % ci))
+        worst["im_0_1"] = max(worst.get("im_0_1", 0.0), _cmp(im_0_1[sl], torch.from_numpy(g["im_0_1_crops"][ci]), atol=2e-5, ill=ill_m01[sl], what="im_0_1 crop %d" % ci))
         for name, rf in (("refine_out", refine), ("refine_out (phase-convolution dec3)", refine2)):
-            worst[name] = max(worst.get(name, 0.0), _cmp(rf[sl], torch.from_numpy(g["refine_out_crops"][ci]), atol=5e-4, rtol=1e-4, what="%s crop %d" % (name, ci)))
+            worst[name] = max(worst.get(name, 0.0), _cmp(rf[sl], torch.from_numpy(g["refine_out_crops"][ci]), atol=2e-4, rtol=1e-5, what="%s crop %d" % (name, ci)))
     np.testing.assert_allclose(refine.double().sum((0, 2, 3)).cpu().numpy(), g["refine_out_sum"], rtol=1e-5, atol=0.5)
     ref = torch.from_numpy(g["out"]).double()[:, :, :H, :W]
     worst["frame (two-kernel tail)"] = _cmp(out2, ref, atol=2e-5, what="frame from dec3_synth")
@@ -1580,6 +1587,76 @@ def test_dec2_dec3_fused_producer_consumer_kernel(hip, dev, shape):
     o32 = hip.dec23_synth(dec1p, enc1p, w2.to(dev), b2.to(dev), w3.to(dev), b3.to(dev), cands, t.to(dev), 1.5616, out_dtype=torch.float32)
     assert o32.dtype == torch.float32 and torch.equal(o32, out.float())
     hip.check_range()
+
+
+def test_ring_fault_poisons_outputs_and_raises_in_the_next_forward(hip, dev, model):
+    """The fault path of the convolution ring, forced through the test build (fldr_debug_ring_spin_limit(0): every wait that is not
+    satisfied at once expires — a consumer then runs on with operands that have not landed):
+      (i)   the convolution writes NaN instead of its result (fp32 and packed outputs), the event is counted (fldr_ring_status) and
+            stored into the host-visible status words without any synchronisation by the caller;
+      (ii)  a whole forward started while the flag is still unseen returns a NaN frame (every frame-writing kernel adds the device's
+            poison to its blend weight), never a plausible wrong one;
+      (iii) the NEXT model(...) call raises FldrError on entry (DCTXVFInet.forward polls the status words) — the drop-in path of
+            INTEGRATION.md section 1, where nobody calls check_range();
+      (iv)  after the reset that the exception performs, the same convolution and forward give their clean results again, bit for bit."""
+    import fldr_harness as Hn
+    m, a = model
+    g = _gen(77)
+    x = torch.rand(1, 96, 40, 64, generator=g).to(dev) * 2 - 1
+    c = m.rec_ctx_ds[0]
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(256, 256, seed=5)).to(dev)
+    t = torch.tensor([[0.5]], device=dev)
+    with hip.test_hooks() as L:
+        hip.check_range()
+        clean = hip.conv2d_spk([hip.spk_pack(x)], c.weight, c.bias, relu=True, want_f32=True, want_spk=True)
+        clean_frame = Hn.interpolate(m, a, frames, t)
+        words = hip.status_words()
+        assert words[0] == 0 and words[1] == 0
+        try:
+            assert L.fldr_debug_ring_spin_limit(0) == 0
+            bad = hip.conv2d_spk([hip.spk_pack(x)], c.weight, c.bias, relu=True, want_f32=True, want_spk=True)
+            torch.cuda.synchronize()
+            assert torch.isnan(bad[0]).all(), "a convolution whose ring waits expired must write NaN, not values"
+            assert torch.isnan(bad[1].float()).all()
+            assert words[1] == 1 and words[0] == 0                       # visible to the host with no library call at all
+            assert L.fldr_debug_ring_timeouts() > 0
+            assert L.fldr_debug_ring_spin_limit(-1) == 1 << 21           # waits are patient again; the flag is still set and unseen
+        finally:
+            L.fldr_debug_ring_spin_limit(-1)
+        # (ii) callers that do not look at the flags: every frame-writing kernel is poisoned
+        pyr = Hn.build_pyramid(Hn.pad_frames(frames, a), a)
+        T, _, _ = m.vfinet._host_scalars()
+        cands = [torch.rand(1, 3, 64, 96, device=dev) for _ in range(6)]
+        tail = hip.synth_tail(torch.randn(1, 6, 64, 96, device=dev), cands, t, T)
+        assert torch.isnan(tail).all()
+        dec1 = hip.spk_pack(torch.rand(1, 32, 16, 24, device=dev))
+        enc1 = hip.spk_pack(torch.rand(1, 16, 32, 48, device=dev))
+        un = m.vfinet.refine_unet
+        fr = hip.dec23_synth(dec1, enc1, un.dec2.weight, un.dec2.bias, un.dec3.weight, un.dec3.bias, cands, t, T)
+        assert torch.isnan(fr).all(), "fldr_dec23_synth after a ring fault must write NaN frames"
+        d2p = hip.conv2d_spk([dec1, enc1], un.dec2.weight, un.dec2.bias, relu=True, up2=[True, False], want_f32=False, want_spk=True)
+        assert torch.isnan(hip.dec3_synth(d2p, un.dec3.weight, un.dec3.bias, cands, t, T)).all()
+        # (iii) the next forward raises on entry, and the exception resets the flags
+        with pytest.raises(hip.FldrError, match="ring"):
+            m([None] * 6, t, normInput=pyr, is_training=False, validation=False)
+        assert words[1] == 0 and words[0] == 0 and L.fldr_debug_ring_timeouts() == 0
+        # (iv) clean again
+        again = hip.conv2d_spk([hip.spk_pack(x)], c.weight, c.bias, relu=True, want_f32=True, want_spk=True)
+        assert torch.equal(again[0], clean[0]) and torch.equal(again[1].float(), clean[1].float())
+        assert torch.equal(Hn.interpolate(m, a, frames, t), clean_frame)
+        hip.check_range()
+    # the range flag takes the same road: saturated activations are visible in word [0] without a synchronising call
+    big = torch.full((1, 16, 16, 32), 1.0e5, device=dev)
+    w = torch.ones(16, 16, 3, 3, device=dev)
+    hip.check_range()
+    words = hip.status_words()
+    out = hip.conv2d_spk([hip.spk_pack(big)], w, None, want_f32=True, want_spk=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[0]).all()
+    assert words[0] == 1 and words[1] == 0
+    with pytest.raises(hip.FldrError, match="fp16 split range"):
+        m([None] * 6, t, normInput=Hn.build_pyramid(Hn.pad_frames(frames, a), a), is_training=False, validation=False)
+    assert words[0] == 0
 
 
 def test_pair_invariant_cache_multi_t(hip, oracle, weights, dev, model):

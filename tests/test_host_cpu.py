@@ -39,9 +39,10 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in texported if not n.startswith("fldr_")], sorted(n for n in texported if not n.startswith("fldr_"))[:10]
     assert declared <= texported and texported - declared <= hooks_decl, sorted(texported - declared - hooks_decl)
     assert set(fldr_hip.HOOKS) <= texported, sorted(set(fldr_hip.HOOKS) - texported)
-    assert fldr_hip.lib().fldr_version() == 104 == fldr_hip.ABI_VERSION
-    assert re.search(r"#define FLDR_VERSION 104\b", hdr)
+    assert fldr_hip.lib().fldr_version() == 105 == fldr_hip.ABI_VERSION
+    assert re.search(r"#define FLDR_VERSION 105\b", hdr)
     assert fldr_hip.lib().fldr_error_string(-2) == b"fldr: shape constraint violated"
+    assert b"status block" in fldr_hip.lib().fldr_error_string(-3)
 
 
 def test_conv_desc_layout_matches_header():
@@ -380,3 +381,31 @@ def test_dec23_softmax_exp_polynomial_is_accurate_to_1e12():
     m = ref > 1e-300
     assert np.max(np.abs(got[m] - ref[m]) / ref[m]) < 1e-12
     assert got[np.argmax(x)] == 1.0 and np.all(np.ldexp(pl[:4], np.full(4, -1200)) == 0.0)
+
+
+def test_dec23_counted_vmcnt_invariant(tmp_path):
+    """fldr_dec23_synth's consumer waves prove that their LDS-DMA pieces of tile k + 2 have landed with `s_waitcnt vmcnt(3)` in front of
+    the tile barrier — correct only if at least three vector-memory instructions (the frame stores) follow the last piece on EVERY path,
+    free only if exactly three do and the compiler adds no vmcnt(0) of its own in between (round 5's build did: the stores sat in a
+    divergent region and the candidates' loads were still pending behind the pieces).  Nothing in the source enforces the emitted code,
+    so the gfx950 listing is checked (tools/check_dma_waits.py: dataflow over the kernel's basic blocks): the two product instantiations
+    (fp64 frame, 8-bit frame) reach the counted wait with exactly three stores behind the pieces on every path, no barrier is reached with
+    an uncovered piece, no scratch memory; the fp32-output instantiation (tests only) keeps a compiler-placed vmcnt(0) — safe, not counted."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    src = os.path.join(ROOT, "fldr-vfi_amd", "csrc", "dec23_kernels.hip")
+    out = str(tmp_path / "dec23.s")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-fvisibility=hidden", "-I" + os.path.join(ROOT, "include"),
+                    "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True, timeout=600)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dma_waits as C
+    for inst in ("dec23_synth_kernelIdE", "dec23_synth_kernelIhE"):
+        problems, notes = C.check(out, inst, expect_counted=3)
+        assert not problems, (problems, notes)
+        assert "[(3, [3])]" in notes[0], notes
+    problems, notes = C.check(out, "dec23_synth_kernelIfE")
+    assert not problems, (problems, notes)
