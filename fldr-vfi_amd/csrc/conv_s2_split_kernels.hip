@@ -305,8 +305,12 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                         if (guard) {
+                            {
+                                bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                                for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
+                                fldr_note_range(bad);
+                            }
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
@@ -639,8 +643,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
                             for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                             if (guard) {
+                                {
+                                    bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                                    for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
+                                    fldr_note_range(bad);
+                                }
                             } else {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
@@ -907,8 +915,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
                             for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                             if (guard) {
+                                {
+                                    bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                                    for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
+                                    fldr_note_range(bad);
+                                }
                             } else {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);
@@ -1115,8 +1127,12 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
 #pragma unroll
                         for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                         if (guard) {
+                            {
+                                bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { bool bad = false; fldr_split_hl(xs[r], hs[r], ls[r], bad); fldr_note_range(bad); }
+                                for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
+                                fldr_note_range(bad);
+                            }
                         } else {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) fldr_split_plain(xs[r], hs[r], ls[r]);

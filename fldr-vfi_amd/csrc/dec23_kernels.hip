@@ -55,6 +55,9 @@
 #ifndef D23_EXP
 #define D23_EXP d23_exp_nonpos
 #endif
+#ifndef D23_EXP_F32
+#define D23_EXP_F32 1                         // softmax weights by the fp32 transcendental unit (see the tail of `consume`); 0: the fp64 exp below
+#endif
 #ifndef D23_NB
 #define D23_NB 3                              // pixel blocks per fetch / MFMA unit of the producer (6 blocks per wave and K-step)
 #endif
@@ -382,15 +385,30 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             // Instruction diet of the same quotient (every step changes the literal order's result by rounding only, ~1e-16 relative, against
             // a 3e-6 bound): the maximum is taken on the fp32 logits (x -> x / T is monotone), logit / T - max is one fma, and the blend below
             // is an fma chain.
+            // Round 6: the softmax weights themselves are fp32 — exp2((logit - max) * (log2 e / T)) on the transcendental unit, converted once —
+            // and everything they enter (the t weights, the normalisation, the blend, the quotient) stays fp64 as in the reference.  The
+            // logits are fp32 accumulations of split-fp16 products (error ~1e-6 of their magnitude): a weight computed from them is
+            // uncertain by ~1e-6 relative whatever the exp's precision, and the fp32 form is within 1e-7 (dominant weights) .. 1e-6 (weights
+            // below 1e-5 of the sum) of the fp64 one — a frame difference of ~1e-7, against the 3e-6 bound of the kernel's test and the
+            // reference's own fp32 convolutions in front of this tail.  It takes 12 x 18 double-precision instructions per lane out of the
+            // ~430 that paced the consumer waves (D23_EXP_F32=0: the 16-instruction fp64 exp above).
             double wo[2][6], inv_div[2];
+#if D23_EXP_F32
+            const float sc2 = (float)(inv_T * 1.4426950408889634074);
+#endif
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
                 float mx32 = acc3[rb][0];
 #pragma unroll
                 for (int kc = 1; kc < 6; ++kc) mx32 = fmaxf(mx32, acc3[rb][kc]);
+#if D23_EXP_F32
+#pragma unroll
+                for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * (double)__builtin_amdgcn_exp2f((acc3[rb][kc] - mx32) * sc2);
+#else
                 const double nmx = -((double)mx32 * inv_T);
 #pragma unroll
                 for (int kc = 0; kc < 6; ++kc) wo[rb][kc] = ((kc & 1) ? w1 : w0) * D23_EXP(__builtin_fma((double)acc3[rb][kc], inv_T, nmx));
+#endif
                 double div = ((wo[rb][0] + wo[rb][1]) + wo[rb][2]) + wo[rb][3];      // fLDRnet.py:517
                 div = div + (wo[rb][4] + wo[rb][5]);                                // :522
                 inv_div[rb] = d23_rcp(div);
