@@ -345,7 +345,9 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
                                 const int co = 4 * lg + r;
-                                if (co < 6) lg_s[co * 32 + 16 * qq + ln] = dd[r];
+                                // (columns of channels 4, 5 — lane group 1 — are stored with their 16-pixel halves swapped: lane groups 0 and 1 would
+                                // otherwise write channels c and c + 4 of the same pixel, 128 floats = the same bank apart, in one instruction)
+                                if (co < 6) lg_s[co * 32 + ((16 * qq + ln) ^ ((co >> 2) << 4))] = dd[r];
                             }
                         }
                     }
@@ -354,7 +356,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if ((lane >> 5) == rr) {
 #pragma unroll
-                        for (int co = 0; co < 6; ++co) acc3[pb][co] = lg_s[co * 32 + tx] * inv_scale3 + bias3_r[co];
+                        for (int co = 0; co < 6; ++co) acc3[pb][co] = lg_s[co * 32 + (tx ^ ((co >> 2) << 4))] * inv_scale3 + bias3_r[co];
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
@@ -493,13 +495,21 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
     } else {
     // =============================== PRODUCER (waves 8-11): dec2 of one tile ===============================
         const int pw = wv - 8;                                               // producer wave 0 .. 3
-        // Which tile pixel a lane's MFMA column is: the (8 + 2) x (32 + 2) tile splits into four parity classes (row & 1, column & 1) of
-        // 5 x 17 pixels; a lane serves ONE class (ln & 3) in all its blocks — pixel index inside the class = 4 block + (ln >> 2), 22 blocks
-        // (+ 2 of padding) over 4 waves.  With the parities fixed per lane, the nearest-x2 index of a dec1 tap (dy, dx) is
-        //     (cy + ((pyb + dy) >> 1), cx + ((pxb + dx) >> 1)) = (cy, cx) + {0, pyb, 1} rows + {0, pxb, 1} columns:
-        // one register per block (qr) + three per lane (qsel) + an immediate, instead of four registers per block.
-        const int pyb = ln & 1, pxb = (ln >> 1) & 1;
-        int pyx[6], qr[6], eoff[6], soff[6], qsel[2][2];
+        // Which tile pixel a lane's MFMA column is: the (8 + 2) x (32 + 2) tile splits by ROW parity into two sets of 5 x 17 pixel PAIRS
+        // (cy, cx) -> pixels (2 cy + pyb, 2 cx), (2 cy + pyb, 2 cx + 1); block i of a wave serves row parity pyb = i & 1 (a compile-time
+        // constant of the unrolled block loop), its 16 lanes = 8 consecutive pairs x the two columns of a pair (pxb = ln & 1): pair index
+        // 8 (block >> 1) + (ln >> 1), 11 blocks per parity = 22 blocks (+ 2 of padding) over 4 waves.  The nearest-x2 index of a dec1 tap
+        // (dy, dx) is (cy + ((pyb + dy) >> 1), cx + ((pxb + dx) >> 1)): the row part is an IMMEDIATE per block, the column part one register
+        // per lane (qx) — one register per block (qr) + one per lane + an immediate.
+        // Round 6: this replaces four parity classes per block (pyb = ln & 1, pxb = (ln >> 1) & 1, four pairs per block).  There the two
+        // rows of a block's pixels lay 16 banks apart in the enc1 window (36-record rows) and 8 banks apart in the dec1 window for the odd
+        // kernel row: a two-way conflict on three quarters of the producer's B-operand reads (22 % of the kernel's LDS-active cycles were
+        // bank conflicts, and padding the rows needs 6 KB of LDS that do not exist).  Now the 16 lanes of a block read 16 consecutive records
+        // of ONE row (256 contiguous bytes: every bank once) — except where the pair index wraps to the next row.  Same values per pixel:
+        // the bits of dec2's tile are unchanged.
+        const int pxb = ln & 1;
+        const int qx = pxb * 16;
+        int pyx[6], qr[6], eoff[6], soff[6];
         const bool etap1 = (lg >> 1) != 0;                                   // enc1 steps: this lane group's tap is 2 j + 1 (else 2 j)
         const int egrp = (lg & 1) * 2 * D23_EPLANE;
         float bias2_r[4];
@@ -507,18 +517,14 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
         {
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                const int idx = min((pw * 6 + i) * 4 + (ln >> 2), 84);
+                const int idx = min(((pw * 6 + i) >> 1) * 8 + (ln >> 1), 84);
                 const int cy = (idx * 241) >> 12, cx = idx - cy * 17;    // idx / 17, idx % 17 for idx < 128
-                const int py = 2 * cy + pyb, px = 2 * cx + pxb;
+                const int py = 2 * cy + (i & 1), px = 2 * cx + pxb;      // (pw * 6 is even: the block's row parity is i & 1)
                 pyx[i] = (py << 8) | px;
                 eoff[i] = D23_OFF_WIN + (py * D23_EW + px) * 16;
                 soff[i] = (lg >> 1) * 2 * D23_OPLANE + (py * D23_OW + px) * 16 + (lg & 1) * 8;     // this lane's piece of the pixel's record in a tile buffer
                 qr[i] = D23_OFF_WIN + 4 * D23_EPLANE + 2 * lg * D23_QPLANE + (cy * D23_QW + cx) * 16;
             }
-#pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
-#pragma unroll
-                for (int bb = 0; bb < 2; ++bb) qsel[aa][bb] = aa * pyb * D23_QW * 16 + bb * pxb * 16;
             inv_scale2 = a.w2[0];
 #pragma unroll
             for (int r = 0; r < 4; ++r) bias2_r[r] = a.bias2[4 * lg + r];
@@ -540,9 +546,10 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
                     const int i = NB * part + ib;
                     if constexpr (s < 9) {
                         constexpr int dy = s / 3, dx = s % 3;
-                        const int off = (dy == 1 || dx == 1) ? qr[i] + qsel[dy == 1][dx == 1] : qr[i];
-                        bh[set][ib] = d23_lds(smem, off + (dy >> 1) * D23_QW * 16 + (dx >> 1) * 16);
-                        bl[set][ib] = d23_lds(smem, off + (dy >> 1) * D23_QW * 16 + (dx >> 1) * 16 + D23_QPLANE);
+                        const int row = (((i & 1) + dy) >> 1) * D23_QW * 16;     // (pyb + dy) >> 1 rows with pyb = i & 1: an immediate once unrolled
+                        const int off = dx == 1 ? qr[i] + qx : qr[i];
+                        bh[set][ib] = d23_lds(smem, off + row + (dx >> 1) * 16);
+                        bl[set][ib] = d23_lds(smem, off + row + (dx >> 1) * 16 + D23_QPLANE);
                     } else {
                         constexpr int t0 = 2 * (s - 9), t1 = t0 + 1 < 9 ? t0 + 1 : 8;   // (tap 9 has zero weights: tap 8 is read again)
                         const int off = eoff[i] + egrp + (etap1 ? ((t1 / 3) * D23_EW + t1 % 3) * 16 : ((t0 / 3) * D23_EW + t0 % 3) * 16);
@@ -600,7 +607,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             fldr_note_range(bad);
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-                if ((pw * 6 + i) * 4 + (ln >> 2) < 85) {
+                if (((pw * 6 + i) >> 1) * 8 + (ln >> 1) < 85) {
                     // channels 4 lg .. 4 lg + 3: group lg >> 1, second half of the record for odd lg; planes: [g0 hi, g0 lo, g1 hi, g1 lo]
                     unsigned char* d = tb + soff[i];
                     *reinterpret_cast<d23_h4*>(d) = d23_h4{hs[4 * i], hs[4 * i + 1], hs[4 * i + 2], hs[4 * i + 3]};
