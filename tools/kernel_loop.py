@@ -12,7 +12,12 @@ model, _, args = Hn.prepare_model(dev)
 un = model.vfinet.refine_unet
 if which == "idle":
     fn = None
-elif which == "conv96":
+elif which.startswith("conv96"):
+    # conv96 | conv96:nc4 (four consumer waves) | conv96:r32 (the 32x32x16 kernel forced): the variants through the test build's hooks
+    if ":" in which:
+        L = hip.enter_test_hooks()
+        if which.endswith(":nc4"): L.fldr_debug_ring_consumers(4)
+        if which.endswith(":r32"): L.fldr_debug_ring32(2)
     xs = [hip.spk_pack(torch.rand(1, 96, 288, 480, device=dev) * 2 - 1) for _ in range(4)]
     c = model.rec_ctx_ds[0]
     fn = lambda i: hip.conv2d_spk([xs[i % 4]], c.weight, c.bias, relu=True, want_f32=False, want_spk=True)
