@@ -366,16 +366,9 @@ def main():
     for i in range(a.warmup):
         out = step(i)
     sync()
-    if gpu:
-        def one_at_a_time(fn, reps=6):                            # single-stream latency: a forward alone on the GPU, host waits for it
-            for k in range(2):
-                fn(k * len(streams)); sync()
-            tl = time.perf_counter()
-            for k in range(reps):
-                fn(k * len(streams)); sync()                     # (multiples of the stream count: always stream 0)
-            return (time.perf_counter() - tl) / reps * 1e3
-        latency_ms = one_at_a_time(step)
-        latency_eager_ms = one_at_a_time(eager_step) if graph_state["on"] else latency_ms
+    # (the single-stream latency legs run AFTER the timed region: the --warmup steps directly precede it.  An extra untimed 0.5 / 1.5 s of the
+    # same loop in front of it was tried in round 6 and changed nothing systematic: 516.9 / 510.1 / 476.3 vs 507.1 / 512.1 pairs/s on one box —
+    # the 20-step region's spread is its own fill / drain transient between two synchronisations, not the board's clock state)
     # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides -------------
     barrier()
     sync()
@@ -387,6 +380,16 @@ def main():
     dt_local = time.perf_counter() - t0
     # ---- sustained rate: the same loop for >= --sustained-s seconds (clocks settle, caches in steady state) ---
     dt = max_over_ranks(dt_local, device)
+    if gpu:
+        def one_at_a_time(fn, reps=6):                            # single-stream latency: a forward alone on the GPU, host waits for it
+            for k in range(2):
+                fn(k * len(streams)); sync()
+            tl = time.perf_counter()
+            for k in range(reps):
+                fn(k * len(streams)); sync()                     # (multiples of the stream count: always stream 0)
+            return (time.perf_counter() - tl) / reps * 1e3
+        latency_ms = one_at_a_time(step)
+        latency_eager_ms = one_at_a_time(eager_step) if graph_state["on"] else latency_ms
     if gpu and a.sustained_s > 0:
         n_s = max(a.steps, int(a.sustained_s / max(dt / a.steps, 1e-5)) + 1)      # the same step count on every rank
         barrier()
