@@ -37,6 +37,7 @@ FLDR_HOOK int fldr_debug_read_spk_stamps(unsigned long long* host) {
 #endif
 
 #include "spk_common.h"
+#include <mutex>
 
 #ifdef FLDR_TEST_HOOKS        // the barrier pipeline: round 1's kernel, kept as the bit-exact cross-check of the ring pipeline (test build only)
 template <int NMT, int TERMS, bool HAS_RES>
@@ -457,7 +458,6 @@ __global__ void spk_unpack_kernel(const unsigned char* __restrict__ src, int64_t
 FLDR_TU_STATUS(spk)
 
 // ---- status block of the current device (common.h: fldr_status_block) -------------------------------------------------------
-#include <mutex>
 namespace {
 struct DevStatus { fldr_status_block* host = nullptr; fldr_status_block* host_dev = nullptr; float* poison = nullptr; };
 std::mutex g_status_mu;

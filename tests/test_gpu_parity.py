@@ -1594,8 +1594,8 @@ def test_ring_fault_poisons_outputs_and_raises_in_the_next_forward(hip, dev, mod
     satisfied at once expires — a consumer then runs on with operands that have not landed):
       (i)   the convolution writes NaN instead of its result (fp32 and packed outputs), the event is counted (fldr_ring_status) and
             stored into the host-visible status words without any synchronisation by the caller;
-      (ii)  a whole forward started while the flag is still unseen returns a NaN frame (every frame-writing kernel adds the device's
-            poison to its blend weight), never a plausible wrong one;
+      (ii)  every frame-writing kernel (fldr_synth_tail, fldr_dec23_synth, fldr_dec3_synth_spk) launched while the flag is still unseen
+            writes a NaN frame — each adds the device's poison to its blend weight —, never a plausible wrong one;
       (iii) the NEXT model(...) call raises FldrError on entry (DCTXVFInet.forward polls the status words) — the drop-in path of
             INTEGRATION.md section 1, where nobody calls check_range();
       (iv)  after the reset that the exception performs, the same convolution and forward give their clean results again, bit for bit."""
