@@ -985,6 +985,312 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
     }
 }
 
+#ifdef FLDR_TEST_HOOKS
+// ------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 6, test build only): ring item = (32 input channels, ONE kernel row).
+// The 16x16x32 kernel above spends 5 K = 32 steps on the 9 taps x 16 channels of a chunk: the tenth half-step multiplies a zero
+// pad tap (10 % of the issued matrix instructions).  Pairing tap 8 of two chunks couples two ring slots (round 3: no gain).  Here a
+// K = 32 step is ONE tap x 32 channels (lane group lg = 8-channel group lg of the 32-channel block) and a ring item carries the
+// three taps of one kernel row dy: 3 steps per item, 9 per 32 channels, 27 per 96 — no pad tap, no coupling between items.
+//   stage = weights of (32 channels, dy): 3 taps x NMT x [hi, lo] 1-KB blocks (18 KB at 48 outputs)
+//         + 8 planes (4 groups x hi / lo) of the 8 window rows this dy needs x 34 pixels (4,352 B each): 53,248 B -> 3 slots.
+// The price: every window row is staged once per kernel row it serves (24 row-loads per 32 channels instead of 20: +66 % LDS-DMA
+// bytes per unit with the weights counted) and a unit is 9 ring items instead of 6 (hand-shakes, operand pipeline restarts).
+// Summation order: 32-channel block -> dy -> dx -> (hi hi, hi lo, lo hi): equal to the other kernels to fp32 accumulation rounding.
+// Scope: cin % 32 == 0, cout % (16 NMT) == 0 all stored, packed output only, no residual, single level.
+// ------------------------------------------------------------------------------------------------
+template <int NMT>
+struct RingRowCfg {
+    static constexpr int NBLK = 3 * NMT * 2;                              // 1-KB weight blocks per item: (dx, m, kind)
+    static constexpr int W_BYTES = NBLK * 1024;
+    static constexpr int NWL = (NBLK + RING_NLOAD - 1) / RING_NLOAD;
+    static constexpr int IW = SPK_TW + 2;
+    static constexpr int PLANE = SPK_TH * IW * 16;                        // 4,352 B: the 8 rows of one kernel row's window
+    static constexpr int NXI = (SPK_TH * IW + 63) / 64;                   // 5 pieces per plane (the last one overlaps)
+    static constexpr int K_DMA = NWL + 2 * NXI;                           // a loader wave: its quarter of the weights + the hi and lo plane of ONE group
+    static constexpr int STAGE = W_BYTES + 8 * PLANE;
+    static constexpr int SLOTS = 3;
+    static constexpr int CTR_OFF = SLOTS * STAGE;
+    static constexpr int BIAS_OFF = CTR_OFF + 64;
+    static constexpr int LDS_BYTES = BIAS_OFF + 64 * NMT;
+    static_assert(K_DMA <= 15 && LDS_BYTES <= 160 * 1024 && PLANE % 256 == 0, "ring-row shape");
+};
+
+template <int NMT>
+__global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(SpkArgs a, const float* __restrict__ wrow) {
+    using Cfg = RingRowCfg<NMT>;
+    constexpr int SLOTS = Cfg::SLOTS, NC = 8, NQ = 2;
+    extern __shared__ __attribute__((aligned(256))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n32 = a.n_chunks;                                           // (the launcher passes 32-channel blocks here)
+    const int n_items = 3 * n32;
+    const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
+    if (tid >= 64 && tid < 64 + 16 * NMT) {
+        const int u0 = (blockIdx.x & 7) * a.units_per_xcd + (blockIdx.x >> 3);
+        const int co = (u0 % a.groups) * 16 * NMT + (tid - 64);
+        reinterpret_cast<float*>(smem + Cfg::BIAS_OFF)[tid - 64] = (a.bias && co < a.cout) ? a.bias[co] : 0.0f;
+    }
+    __syncthreads();
+    const int xcd = blockIdx.x & 7, slot_id = blockIdx.x >> 3;
+    const int u_end = min((xcd + 1) * a.units_per_xcd, a.n_units);
+    const int u_first = xcd * a.units_per_xcd + slot_id;
+    if (u_first >= u_end) return;
+    const int my_units = (u_end - u_first + a.wgs_per_xcd - 1) / a.wgs_per_xcd;
+    const int total = my_units * n_items;
+    const int grp0 = u_first % a.groups;
+
+    if (wave >= NC) {
+        // =========================================== loader: group lw of every 32-channel block ===========================================
+        const int lw = wave - NC;
+        const char* zero_blk = reinterpret_cast<const char*>(a.wpack + 4);
+        int w_blk[Cfg::NWL], x_piece[Cfg::NXI];
+#pragma unroll
+        for (int i = 0; i < Cfg::NWL; ++i) w_blk[i] = min(lw * Cfg::NWL + i, Cfg::NBLK - 1);
+#pragma unroll
+        for (int i = 0; i < Cfg::NXI; ++i) x_piece[i] = min(i * 64, Cfg::PLANE / 16 - 64);
+        unsigned long long tab_ptr;
+        long long tab_bs;
+        {
+            const auto* kt = (const __attribute__((address_space(4))) unsigned long long*)__builtin_amdgcn_kernarg_segment_ptr();
+            const int l = lane < SPK_MAX_GROUPS ? lane : 0;
+            tab_ptr = kt[l];
+            tab_bs = (long long)kt[SPK_MAX_GROUPS + l];
+        }
+        int iss_u = u_first, iss_i = 0, iss_n = 0;
+        int gy0[Cfg::NXI], gx0[Cfg::NXI];                                  // window row / column of this lane's slot of piece i (row for dy = 0)
+        auto issue_geometry = [&]() {
+            const int t = spk_div(iss_u, a.m_groups, a.groups);
+            iss_n = spk_div(t, a.m_tiles, a.n_tiles);
+            const int tile = t - iss_n * a.n_tiles;
+            const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x);
+            const int oy0 = ty * SPK_TH, ox0 = (tile - ty * a.tiles_x) * SPK_TW;
+#pragma unroll
+            for (int i = 0; i < Cfg::NXI; ++i) {
+                const int e = x_piece[i] + lane;
+                const int y = e / Cfg::IW, x = e - y * Cfg::IW;
+                gy0[i] = oy0 - 1 + y; gx0[i] = ox0 - 1 + x;
+            }
+        };
+        const char* const iss_w = reinterpret_cast<const char*>(wrow) + (int64_t)grp0 * n_items * Cfg::W_BYTES;
+        issue_geometry();
+        int st = 0;
+        uint32_t free_target = 0;
+        for (int k = 0; k < total; ++k) {
+            const int c32 = iss_i / 3, dy = iss_i - 3 * c32;
+            const char* wbase = iss_w + (int64_t)iss_i * Cfg::W_BYTES + lane * 16;
+            const int gi = c32 * 4 + lw;
+            const uint32_t e_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_ptr, gi), e_hi = __builtin_amdgcn_readlane((int)(uint32_t)(tab_ptr >> 32), gi);
+            const uint32_t b_lo = __builtin_amdgcn_readlane((int)(uint32_t)tab_bs, gi), b_hi = __builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)tab_bs >> 32), gi);
+            const unsigned long long e = ((unsigned long long)e_hi << 32) | e_lo;
+            const long long bs = (long long)(((unsigned long long)b_hi << 32) | b_lo);
+            const bool nul = e == 0ull, up2 = (e & 1ull) != 0ull;
+            const char* base = reinterpret_cast<const char*>(static_cast<uintptr_t>(e & ~1ull)) + (int64_t)iss_n * bs;
+            const long long plane_b = up2 ? (long long)(a.H >> 1) * (a.W >> 1) * 16 : (long long)a.H * a.W * 16;      // hi -> lo plane of the group
+            const char* dhi[Cfg::NXI];
+            const char* dlo[Cfg::NXI];
+#pragma unroll
+            for (int i = 0; i < Cfg::NXI; ++i) {
+                const int gy = gy0[i] + dy, gx = gx0[i];
+                const bool ok = !nul && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+                const uint32_t off = up2 ? (uint32_t)((gy >> 1) * (a.W >> 1) + (gx >> 1)) * 16u : (uint32_t)(gy * a.W + gx) * 16u;
+                dhi[i] = ok ? base + off : zero_blk;
+                dlo[i] = ok ? base + plane_b + off : zero_blk;
+            }
+            if (++iss_i == n_items) { iss_i = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane, ctr + RING_POISON_OFF);
+            unsigned char* stage = smem + st * Cfg::STAGE;
+#pragma unroll
+            for (int i = 0; i < Cfg::NWL; ++i)
+                __builtin_amdgcn_global_load_lds((kgptr_t)(wbase + w_blk[i] * 1024), (klptr_t)(stage + w_blk[i] * 1024), 16, 0, 0);
+#pragma unroll
+            for (int i = 0; i < Cfg::NXI; ++i) {
+                __builtin_amdgcn_global_load_lds((kgptr_t)dhi[i], (klptr_t)(stage + Cfg::W_BYTES + lw * Cfg::PLANE + x_piece[i] * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((kgptr_t)dlo[i], (klptr_t)(stage + Cfg::W_BYTES + (4 + lw) * Cfg::PLANE + x_piece[i] * 16), 16, 0, 0);
+            }
+            if (k > 0) {
+                __builtin_amdgcn_s_waitcnt(0x0F70 | Cfg::K_DMA);
+                ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
+            }
+            if (++st == SLOTS) { st = 0; free_target += NC; }
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
+        return;
+    }
+
+    // ============================================= consumer: tile row cw =============================================
+    const int cw = wave;
+    const int lj = lane & 15, lg = lane >> 4;
+    int boff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) boff[q] = Cfg::W_BYTES + lg * Cfg::PLANE + (cw * Cfg::IW + q * 16 + lj) * 16;
+    f4 acc[NMT][NQ];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc[m][q] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+    int cur_u = u_first, cur_i = 0;
+    const float inv_scale = a.wpack[0];
+    const int64_t HW = (int64_t)a.H * a.W;
+    const uint32_t HW32 = (uint32_t)HW;
+    float bias_r[NMT][4];
+#pragma unroll
+    for (int m = 0; m < NMT; ++m) {
+        const f4 bv = *reinterpret_cast<const f4*>(smem + Cfg::BIAS_OFF + (m * 16 + lg * 4) * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias_r[m][r] = bv[r];
+    }
+    const float relu_floor = a.relu ? 0.0f : -3.402823466e+38f;
+    auto finish_store = [&]() {
+        const int t = spk_div(cur_u, a.m_groups, a.groups);
+        const int n = spk_div(t, a.m_tiles, a.n_tiles);
+        const int tile = t - n * a.n_tiles;
+        const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x), tx = tile - ty * a.tiles_x;
+        const int oy = ty * SPK_TH + cw;
+        unsigned char* spkn = a.out_spk + (int64_t)n * a.out_spk_bstride;
+        const bool poisoned = ring_peek(ctr + RING_POISON_OFF) != 0u;
+        float abs_sum = 0.0f;
+#pragma unroll
+        for (int m = 0; m < NMT; ++m)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[m][q][r] = fmaxf(acc[m][q][r] * inv_scale + bias_r[m][r], relu_floor);
+                    abs_sum += fabsf(acc[m][q][r]);
+                }
+        const bool guard = fldr_guard_trips(abs_sum);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int ox = tx * SPK_TW + q * 16 + lj;
+            const bool ok = oy < a.H && ox < a.W;
+            const uint32_t pq = ok ? (uint32_t)(oy * a.W + ox) : 0u;
+#pragma unroll
+            for (int m = 0; m < NMT; ++m) {
+                const int co0 = grp0 * 16 * NMT + m * 16 + lg * 4;
+                h4 ohi, olo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[m][q][r];
+                    acc[m][q][r] = 0.0f;
+                    _Float16 h, l;
+                    if (guard) { bool bad = false; spk_split(v, h, l, bad); fldr_note_range(bad); } else fldr_split_plain(v, h, l);
+                    ohi[r] = h; olo[r] = l;
+                }
+                if (poisoned) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ohi[r] = (_Float16)__builtin_nanf(""); olo[r] = (_Float16)__builtin_nanf(""); }
+                }
+                if (ok) {
+                    const uint32_t off = ((uint32_t)(co0 >> 3) * 2u * HW32 + pq) * 16u + (uint32_t)(lg & 1) * 8u;
+                    *reinterpret_cast<h4*>(spkn + off) = ohi;
+                    *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
+                }
+            }
+        }
+    };
+    int st_cur = 0, g = 0;
+    uint32_t full_target = RING_NLOAD;
+    while (g < total) {
+        const bool last = cur_i == n_items - 1;
+        ring_wait_ge(ctr + 4 * st_cur, full_target, lane, ctr + RING_POISON_OFF);
+        {
+            const unsigned char* sb = smem + st_cur * Cfg::STAGE;
+            const unsigned char* win = sb + lane * 16;
+            h8 bh[2][NQ], bl[2][NQ], ah[2][NMT], al[NMT];
+            auto ld = [&](int buf, int s) __attribute__((always_inline)) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bh[buf][q] = *reinterpret_cast<const h8*>(sb + boff[q] + s * 16);
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) ah[buf][m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 0) * 1024);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) bl[buf][q] = *reinterpret_cast<const h8*>(sb + 4 * Cfg::PLANE + boff[q] + s * 16);
+            };
+            auto ld_al = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+                for (int m = 0; m < NMT; ++m) al[m] = *reinterpret_cast<const h8*>(win + ((s * NMT + m) * 2 + 1) * 1024);
+            };
+            constexpr int N_MFMA = NQ * 3 * NMT, N_DS = 2 * NQ + 2 * NMT;
+            constexpr int N_TAIL = N_MFMA >= 12 ? 4 : 2;
+            ld(0, 0);
+            ld_al(0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                if (s > 0) ld_al(s);
+                if (s + 1 < 3) ld((s + 1) & 1, s + 1);
+#pragma unroll
+                for (int term = 0; term < 3; ++term)
+#pragma unroll
+                    for (int m = 0; m < NMT; ++m)
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q) {
+                            const h8 av = term == 2 ? al[m] : ah[s & 1][m];
+                            const h8 bv = term == 1 ? bl[s & 1][q] : bh[s & 1][q];
+                            acc[m][q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, bv, acc[m][q], 0, 0, 0);
+                        }
+                spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < 3);
+            }
+        }
+        ring_signal(ctr + 32 + 4 * st_cur, lane);
+        if (last) { finish_store(); cur_i = 0; cur_u += a.wgs_per_xcd; } else ++cur_i;
+        if (++st_cur == SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
+        ++g;
+    }
+}
+
+// weight section of the experiment: [group of 16 NMT outputs][32-channel block][dy][dx][m][hi, lo][lane = channel group * 16 + output][8 channels]
+__global__ void ringrow_prepack_kernel(const float* __restrict__ w, const float* __restrict__ hdr, float* __restrict__ dst, int cout, int cin, int nmt,
+                                       int n32, int64_t total_h8) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total_h8) return;
+    const float scale = hdr[1];
+    const int lane = (int)(i % 64), kind = (int)((i / 64) % 2), m = (int)((i / 128) % nmt), dx = (int)((i / (128 * nmt)) % 3);
+    const int dy = (int)((i / (128 * nmt * 3)) % 3), c32 = (int)((i / (128 * nmt * 9)) % n32), gr = (int)(i / ((int64_t)128 * nmt * 9 * n32));
+    const int co = gr * 16 * nmt + m * 16 + (lane & 15);
+    h8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = c32 * 32 + (lane >> 4) * 8 + j;
+        const float x = (co < cout && c < cin) ? w[((int64_t)co * cin + c) * 9 + dy * 3 + dx] * scale : 0.0f;
+        const _Float16 h = (_Float16)x;
+        v[j] = kind == 0 ? h : (_Float16)(x - (float)h);
+    }
+    reinterpret_cast<h8*>(dst)[i] = v;
+}
+FLDR_HOOK int64_t fldr_debug_ringrow_pack_floats(int cout, int cin) {
+    if (cin % 32 || (cout % 48 && cout % 32)) return FLDR_E_SHAPE;
+    const int nmt = cout % 48 == 0 ? 3 : 2;
+    return (int64_t)(cout / (16 * nmt)) * (cin / 32) * 9 * nmt * 2 * 256;
+}
+// wpack: the layer's ordinary pack (header: scale); wrow: fldr_debug_ringrow_pack_floats floats
+FLDR_HOOK int fldr_debug_ringrow_prepack(const float* weight, const float* wpack, float* wrow, int cout, int cin, fldr_stream_t stream) {
+    const int64_t nf = fldr_debug_ringrow_pack_floats(cout, cin);
+    if (nf < 0) return (int)nf;
+    const int nmt = cout % 48 == 0 ? 3 : 2;
+    hipLaunchKernelGGL(ringrow_prepack_kernel, dim3(fldr_cdiv(nf / 4, 256)), dim3(256), 0, fldr_s(stream), weight, wpack, wrow, cout, cin, nmt, cin / 32, nf / 4);
+    FLDR_LAUNCH_RET();
+}
+template <int NMT>
+static int ringrow_launch(SpkArgs& a, const float* wrow, int N, int wgs_per_xcd_max, hipStream_t s) {
+    using Cfg = RingRowCfg<NMT>;
+    static std::atomic<uint64_t> attr_done{0};
+    if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ringrow_kernel<NMT>), Cfg::LDS_BYTES, attr_done)) return e;
+    a.groups = a.cout / (16 * NMT);
+    if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, SPK_TW)) return e;
+    hipLaunchKernelGGL(conv3x3_ringrow_kernel<NMT>, dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a, wrow);
+    FLDR_LAUNCH_RET();
+}
+// a: filled by fldr_conv2d_spk's front end (fldr_debug_conv2d_ringrow in conv_spk_kernels.hip)
+int fldr_spk_ringrow_dispatch(SpkArgs& a, const float* wrow, int N, int wgs_per_xcd_max, hipStream_t s) {
+    if (a.cout % 48 == 0) { a.n_chunks = a.n_chunks / 2; return ringrow_launch<3>(a, wrow, N, wgs_per_xcd_max, s); }
+    a.n_chunks = a.n_chunks / 2;
+    return ringrow_launch<2>(a, wrow, N, wgs_per_xcd_max, s);
+}
+#endif  // FLDR_TEST_HOOKS
+
 static int g_ring_consumers = 8;
 FLDR_HOOK int fldr_debug_ring_consumers(int v) { if (v == 4 || v == 8) g_ring_consumers = v; return g_ring_consumers; }
 

@@ -746,6 +746,43 @@ extern "C" int fldr_conv2d_spk(const fldr_spk_conv_desc* d, fldr_stream_t stream
 #endif
 }
 
+#ifdef FLDR_TEST_HOOKS
+// EXPERIMENT (round 6): the convolution of `d` on conv3x3_ringrow_kernel (conv_ring_kernels.hip: ring item = 32 channels x one kernel row).
+// wrow: fldr_debug_ringrow_prepack's section.  cin % 32 == 0, cout % 48 == 0 or % 32 == 0, every channel stored, packed output only,
+// no residual, full-resolution or nearest-x2 sources as fldr_conv2d_spk.
+int fldr_spk_ringrow_dispatch(SpkArgs& a, const float* wrow, int N, int wgs_per_xcd_max, hipStream_t s);
+FLDR_HOOK int fldr_debug_conv2d_ringrow(const fldr_spk_conv_desc* d, const float* wrow, fldr_stream_t stream) {
+    FLDR_CHECK_ARG(d && wrow && d->wpack && d->out_spk && !d->out_f32 && !d->residual && d->n_src >= 1 && d->n_src <= FLDR_CONV_MAX_SRC);
+    FLDR_CHECK_ARG(d->N > 0 && d->cin > 0 && d->cin % 32 == 0 && d->cin <= SPK_MAX_GROUPS * 8 && d->cout > 0 && d->cout <= 96 && d->cout_store == d->cout);
+    FLDR_CHECK_ARG((d->cout % 48 == 0 || d->cout % 32 == 0) && d->precision == 0 && d->H > 0 && d->W > 0);
+    if (fldr_spk_bytes(96, d->H, d->W) >= (1ll << 32)) return FLDR_E_SHAPE;
+    SpkArgs a;
+    a.res_spk = 0;
+    int gsum = 0;
+    for (int s = 0; s < d->n_src; ++s) {
+        FLDR_CHECK_ARG(d->src[s] && d->src_c[s] > 0 && !(d->src_c[s] & 7));
+        if (d->src_up2[s] && ((d->H | d->W) & 1)) return FLDR_E_SHAPE;
+        const int ng = d->src_c[s] / 8;
+        if (gsum + ng > SPK_MAX_GROUPS) return FLDR_E_ARG;
+        const int64_t plane = d->src_up2[s] ? (int64_t)(d->H >> 1) * (d->W >> 1) * 16 : (int64_t)d->H * d->W * 16;
+        for (int g = 0; g < ng; ++g) {
+            a.grp_ptr[gsum + g] = (unsigned long long)(reinterpret_cast<uintptr_t>(d->src[s]) + (uint64_t)g * 2 * plane) | (d->src_up2[s] ? 1ull : 0ull);
+            a.grp_bstride[gsum + g] = d->src_bstride[s];
+        }
+        gsum += ng;
+    }
+    if (gsum * 8 != d->cin) return FLDR_E_SHAPE;
+    for (int g = gsum; g < SPK_MAX_GROUPS; ++g) { a.grp_ptr[g] = 0ull; a.grp_bstride[g] = 0; }
+    a.n_levels = 0;
+    a.wpack = d->wpack; a.bias = d->bias; a.residual = nullptr; a.out_f32 = nullptr;
+    a.out_spk = reinterpret_cast<unsigned char*>(d->out_spk);
+    a.out_spk_bstride = fldr_spk_bytes(d->cout_store, d->H, d->W);
+    a.n_chunks = d->cin / 16; a.cout = d->cout; a.cout_store = d->cout_store;
+    a.H = d->H; a.W = d->W; a.relu = d->relu; a.pack_nmt = 0; a.w32_off = 0;
+    return fldr_spk_ringrow_dispatch(a, wrow, d->N, g_spk_wgs_per_xcd, fldr_s(stream));
+}
+#endif
+
 // The same convolution (same weights, bias, ReLU) over SEVERAL inputs of different sizes in ONE launch of the ring pipeline:
 // rec_ctx_ds.0 / .2 over the six pyramid levels (fLDRnet.py:148-162 runs them level by level: 12 launches, ten of them too
 // small to fill the chip).  descs[l]: one sample (N = 1), one packed source of cin channels, the same wpack / bias / relu /

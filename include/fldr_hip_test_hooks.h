@@ -28,6 +28,9 @@ FLDR_API int fldr_debug_corr_xcd(int v);                                    /* t
 FLDR_API int fldr_debug_corr_chunk(int v);                                  /* channels per staged chunk of the LDS-DMA cost-volume kernel: 8 (default) or 16; other: query */
 FLDR_API int fldr_debug_ring_tile_width(int v);                             /* tuning hook of the ring pipeline: 0 (default) automatic per launch, 16 / 32 forced; other: query.  Bit-identical results */
 FLDR_API int fldr_debug_ring_spin_limit(int v);                             /* polls a bounded ring wait makes before it expires (default 2^21; < 0: restore the default); 0 makes every wait that is not satisfied at once expire: exercises the fault path */
+FLDR_API int64_t fldr_debug_ringrow_pack_floats(int cout, int cin);         /* round-6 experiment (ring item = 32 channels x one kernel row, no pad tap): floats of its weight section, < 0: shape not covered */
+FLDR_API int fldr_debug_ringrow_prepack(const float* weight, const float* wpack, float* wrow, int cout, int cin, fldr_stream_t stream);
+FLDR_API int fldr_debug_conv2d_ringrow(const fldr_spk_conv_desc* desc, const float* wrow, fldr_stream_t stream);
 FLDR_API int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */
 FLDR_API int fldr_debug_splat_tile_variant(int v);                          /* fldr_softsplat_tile: 1 (default) claim-and-add bands, 0 the LDS-f32-atomic tiles; other: query */
 FLDR_API int fldr_debug_pca_variant(int v);                                 /* fldr_pca_project_pyramid: 0 (default) vector fp64 kernel, 1 fp64 matrix-core kernel; other: query */
