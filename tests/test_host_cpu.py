@@ -409,3 +409,59 @@ def test_dec23_counted_vmcnt_invariant(tmp_path):
         assert "[(3, [3])]" in notes[0], notes
     problems, notes = C.check(out, "dec23_synth_kernelIfE")
     assert not problems, (problems, notes)
+
+
+def test_dma_wait_checker_detects_violations(tmp_path):
+    """tools/check_dma_waits.py on hand-written listings: the analyser that guards the synthesis kernel's counted wait must itself flag
+    (a) a counted wait with too few vector-memory instructions behind the last LDS-DMA piece on ONE of two paths, (b) a barrier reached
+    with an uncovered piece, (c) scratch memory — and pass the sound form (three stores on every path, or a vmcnt(0))."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_dma_waits as C
+
+    def listing(name, body, scratch=0):
+        return ("\t.amdhsa_kernel %s\n\t\t.amdhsa_private_segment_fixed_size %d\n\t.end_amdhsa_kernel\n%s:                ; @%s\n%s\ts_endpgm\n"
+                % (name, scratch, name, name, body))
+    good = listing("_Z4goodv", """\tglobal_load_lds_dwordx4 v[0:1], off
+\tv_add_f32_e32 v2, v3, v4
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\ts_waitcnt vmcnt(3) lgkmcnt(0)
+\ts_barrier
+""")
+    two_paths = listing("_Z3badv", """\tglobal_load_lds_dwordx4 v[0:1], off
+\ts_cbranch_execz .LBB0_2
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+.LBB0_2:
+\ts_waitcnt vmcnt(3) lgkmcnt(0)
+\ts_barrier
+""")
+    covered = listing("_Z7coveredv", """\tglobal_load_lds_dwordx4 v[0:1], off
+\ts_cbranch_execz .LBB1_2
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\tglobal_store_dwordx4 v[0:1], v[4:7], off
+\ts_branch .LBB1_3
+.LBB1_2:
+\ts_waitcnt vmcnt(0)
+.LBB1_3:
+\ts_waitcnt vmcnt(3) lgkmcnt(0)
+\ts_barrier
+""")
+    spilled = listing("_Z7spilledv", """\tglobal_load_lds_dwordx4 v[0:1], off
+\ts_waitcnt vmcnt(0)
+\ts_barrier
+""", scratch=24)
+    p = str(tmp_path / "k.s")
+    open(p, "w").write(good + two_paths + covered + spilled)
+    ok, notes = C.check(p, "_Z4goodv", expect_counted=3)
+    assert not ok and "[(3, [3])]" in notes[0], (ok, notes)
+    bad, _ = C.check(p, "_Z3badv", expect_counted=3)
+    assert any("vmcnt(3) with only [0]" in x for x in bad) and any("s_barrier reached with an LDS-DMA piece pending" in x for x in bad), bad
+    ok2, _ = C.check(p, "_Z7coveredv", expect_counted=3)
+    assert not ok2, ok2
+    sp, _ = C.check(p, "_Z7spilledv")
+    assert any("scratch" in x for x in sp), sp

@@ -51,21 +51,14 @@ def analyse(lines, start, end):
         cur.append(i)
     blocks[name] = cur
     order.append(name)
-    succ = {}
+    # fall-through successor of every block (none behind an unconditional branch or the end of the program); a conditional or
+    # unconditional branch INSIDE a block hands the state AT THE BRANCH to its target (blocks are only split at labels)
+    fall = {}
     for k, name in enumerate(order):
-        s = []
-        fall = True
-        for i in blocks[name]:
-            m = BRANCH.match(lines[i])
-            if m:
-                s.append(m.group(2))
-                if m.group(1) == "s_branch":
-                    fall = False
-            if re.match(r"^\s+s_endpgm", lines[i]):
-                fall = False
-        if fall and k + 1 < len(order):
-            s.append(order[k + 1])
-        succ[name] = s
+        last = blocks[name][-1] if blocks[name] else None                # (the last instruction decides)
+        lm = BRANCH.match(lines[last]) if last is not None else None
+        ends = bool(lm and lm.group(1) == "s_branch") or bool(last is not None and re.match(r"^\s+s_endpgm", lines[last]))
+        fall[name] = order[k + 1] if (not ends and k + 1 < len(order)) else None
 
     def step(state, i, report):
         l = lines[i]
@@ -87,18 +80,35 @@ def analyse(lines, start, end):
                     return frozenset("S" if isinstance(c, int) else c for c in state)
         return state
 
+    def flow(b, st, out):
+        """Run block b from state st; out(target, state) for every edge leaving it."""
+        dead = False
+        for i in blocks[b]:
+            m = BRANCH.match(lines[i])
+            if m:
+                out(m.group(2), st)
+                if m.group(1) == "s_branch":
+                    dead = True
+                    break
+                continue
+            if re.match(r"^\s+s_endpgm", lines[i]):
+                dead = True
+                break
+            st = step(st, i, None)
+        if not dead and fall[b] is not None:
+            out(fall[b], st)
+
     inb = {name: frozenset() for name in order}
     inb["entry"] = frozenset(["N"])
     work = ["entry"]
     while work:
         b = work.pop()
-        st = inb[b]
-        for i in blocks[b]:
-            st = step(st, i, None)
-        for s in succ[b]:
-            if s in inb and not st <= inb[s]:
-                inb[s] = inb[s] | st
-                work.append(s)
+
+        def out(target, st):
+            if target in inb and not st <= inb[target]:
+                inb[target] = inb[target] | st
+                work.append(target)
+        flow(b, inb[b], out)
     violations, counted, barriers = [], {}, 0
     for b in order:
         st = inb[b]
