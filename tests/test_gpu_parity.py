@@ -1362,6 +1362,52 @@ def test_model_matches_oracle_odd_sizes(hip, oracle, weights, dev, model, case):
     assert (out.cpu() - ref).abs().mean().item() <= 1e-6
 
 
+@pytest.mark.parametrize("case", [("t0", 0.0, False), ("t1", 1.0, False), ("still", 0.5, True), ("t_eps", 1.0e-3, False)])
+def test_model_edge_cases_of_t_and_motion(hip, oracle, weights, dev, model, case):
+    """Edge cases of the blend (fLDRnet.py:511-524): t = 0 and t = 1 (half of the six weights are exactly zero: the normalisation rests on
+    the other three), t = 1e-3, and two IDENTICAL frames (zero motion: every splat lands on its own cell, every backward-warp mask sits at
+    exactly 1) — whole forward against the oracle."""
+    import fldr_harness as Hn
+    name, tv, still = case
+    m, a = model
+    u8 = Hn.synthetic_pair(192, 320, seed=9, quadrant=True)
+    if still:
+        u8 = torch.stack([u8[0], u8[0]], 0)
+    frames = Hn.frames_from_uint8(u8)
+    t = torch.tensor([[tv]])
+    out = Hn.interpolate(m, a, frames.to(dev), t.to(dev))
+    with torch.no_grad():
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t)[..., :192, :320]
+    err = _cmp(out, ref, atol=1e-4, what="forward, " + name)
+    assert (out.cpu() - ref).abs().mean().item() <= 1e-6
+    if still:                                                            # zero motion: the interpolated frame is the frame itself, to the network's noise
+        assert (out.cpu() - frames[:, :, 0].double()).abs().mean().item() < 2e-2
+    print("%s: max|err| %.2e" % (name, err))
+    hip.check_range()
+
+
+def test_model_smallest_frame_and_flow_output(hip, oracle, weights, dev):
+    """The smallest frame the reference's reflect padding accepts for the 5-scale path (129 x 131: 127 / 125 padded pixels < the frame),
+    and --testgetflowout (fLDRnet.py:407,535: the forward also returns the t-scaled level-0 flows) against the oracle's level-0 flow."""
+    import fldr_harness as Hn
+    args = Hn.args_config()
+    args.testgetflowout = True
+    m, _, a = Hn.prepare_model(dev, args=args)
+    frames = Hn.frames_from_uint8(Hn.synthetic_pair(129, 131, seed=12))
+    t = torch.tensor([[0.25]])
+    with torch.no_grad():
+        pyr = Hn.build_pyramid(Hn.pad_frames(frames.to(dev), a), a)
+        out, flow_out = m([None] * 6, t.to(dev), normInput=pyr, is_training=False, validation=False)
+        keep = {}
+        ref = oracle.forward(weights, oracle.pad_and_pyramid(frames), t, keep=keep)
+    _cmp(out[..., :129, :131], ref[..., :129, :131], atol=1e-4, what="129x131 forward")
+    f0 = keep["flows"][0]
+    want = torch.cat([0.25 * f0[:, 2:], (1 - 0.25) * f0[:, :2]], 1)
+    assert flow_out is not None and flow_out.shape == want.shape
+    _cmp(flow_out, want, atol=2e-4, rtol=1e-4, what="testgetflowout")
+    hip.check_range()
+
+
 @pytest.mark.parametrize("case", ["depth_S3_100x150", "depth_S4_128x200", "depth_S6_300x400", "depth_S7_520x530"])
 def test_model_pyramid_depths(hip, oracle, weights, golden, dev, case):
     """--test3scales / --test4scales / --test6scales / --test7scales (main.py:243-268): the whole forward with S_tst + 1 pyramid
