@@ -75,6 +75,10 @@ typedef __attribute__((address_space(3))) void* d23_lptr_t;
 #define FLDR_STAMP_BLOCK 100
 #endif
 __device__ unsigned long long fldr_d23_stamp_buf[2 * 8];
+__device__ unsigned long long fldr_d23_wave_buf[12 * 2];            // per wave of the stamped workgroup: {cycles waiting at the tile barrier, cycles of the tile loop}
+FLDR_HOOK int fldr_debug_read_d23_wave_stamps(unsigned long long* host) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_d23_wave_buf), sizeof(unsigned long long) * 24);
+}
 #define D23_STAMP(var) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 FLDR_HOOK int fldr_debug_read_d23_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(fldr_d23_stamp_buf), sizeof(unsigned long long) * 16);
@@ -490,6 +494,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             sf += st6 - st0; sa += st1 - st0; se += st4 - st1; sd += st5 - st4; sb += st2 - st5; sc += st3 - st2;
         }
 #ifdef FLDR_STAMPS
+        if (blockIdx.x == FLDR_STAMP_BLOCK && lane == 0) { fldr_d23_wave_buf[wv * 2] = sc; fldr_d23_wave_buf[wv * 2 + 1] = sa + se + sd + sb + sc; }
         if (blockIdx.x == FLDR_STAMP_BLOCK && tid == 0) { fldr_d23_stamp_buf[0] = sa; fldr_d23_stamp_buf[1] = sb; fldr_d23_stamp_buf[2] = sc; fldr_d23_stamp_buf[3] = my_tiles; fldr_d23_stamp_buf[4] = sd; fldr_d23_stamp_buf[5] = se; fldr_d23_stamp_buf[6] = sf; }
 #endif
     } else {
@@ -641,6 +646,7 @@ __global__ __launch_bounds__(D23_THREADS) void dec23_synth_kernel(D23Args a) {
             sa += st1 - st0; sb += st2 - st1; sc += st3 - st2; sd += st4 - st3; se += st5 - st4;
         }
 #ifdef FLDR_STAMPS
+        if (blockIdx.x == FLDR_STAMP_BLOCK && lane == 0) { fldr_d23_wave_buf[wv * 2] = se; fldr_d23_wave_buf[wv * 2 + 1] = sa + sb + sc + sd + se; }
         if (blockIdx.x == FLDR_STAMP_BLOCK && tid == 512) { unsigned long long* o = fldr_d23_stamp_buf + 8; o[0] = sa; o[1] = sb; o[2] = sc; o[3] = sd; o[4] = se; o[5] = my_tiles; }
 #endif
     }

@@ -47,3 +47,9 @@ if hasattr(hip.lib(), "fldr_debug_read_d23_stamps"):
     print("consumer wave 0: tiles %d | per tile (s_memtime ticks): cands+matrix+exchange %d (cands issue %d)  softmax %d  dma-issue %d  blend+store %d  barrier %d" % (buf[3], buf[0] / n, buf[6] / n, buf[5] / n, buf[4] / n, buf[1] / n, buf[2] / n))
     n = max(1, buf[13])
     print("producer wave 8: tiles %d | per tile: stage-issue %d  mfma-loop %d  epilogue %d  dma-wait %d  barrier %d" % (buf[13], buf[8] / n, buf[9] / n, buf[10] / n, buf[11] / n, buf[12] / n))
+if hasattr(hip.lib(), "fldr_debug_read_d23_wave_stamps"):
+    wb = (ctypes.c_uint64 * 24)()
+    hip.lib().fldr_debug_read_d23_wave_stamps.argtypes = [ctypes.c_void_p]
+    hip.lib().fldr_debug_read_d23_wave_stamps(wb)
+    nt = max(1, buf[3])
+    print("per wave and tile: barrier wait / loop cycles  " + "  ".join("w%d %d/%d" % (w, wb[2 * w] / nt, wb[2 * w + 1] / nt) for w in range(12)))
