@@ -110,15 +110,21 @@ __device__ __forceinline__ void fldr_split_hl_group(const float (&x)[N], _Float1
 struct fldr_status_block { int range; int ring; int pad[14]; };
 struct fldr_tu_status_t { fldr_status_block* host; float* poison; };
 static __device__ fldr_tu_status_t fldr_tu_status;        // one per translation unit, bound by fldr_status_word() (null before)
+// (explicit global-address-space pointers: through generic pointers these stores became flat_store instructions)
+typedef __attribute__((address_space(1))) int* fldr_gint_t;
+typedef __attribute__((address_space(1))) float* fldr_gfloat_t;
 __device__ __forceinline__ void fldr_status_raise_range() {
+#ifdef FLDR_NO_HOST_STATUS                               // A/B builds only: the range flag stays in device memory (what its cold path costs the kernels around it)
+    return;
+#endif
     fldr_status_block* h = fldr_tu_status.host;
-    if (h) __hip_atomic_store(&h->range, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (h) __hip_atomic_store((fldr_gint_t)&h->range, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __device__ __forceinline__ void fldr_status_raise_ring() {
     fldr_status_block* h = fldr_tu_status.host;
-    if (h) __hip_atomic_store(&h->ring, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (h) __hip_atomic_store((fldr_gint_t)&h->ring, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     float* p = fldr_tu_status.poison;
-    if (p) *p = __builtin_nanf("");
+    if (p) *(fldr_gfloat_t)p = __builtin_nanf("");
 }
 __device__ __forceinline__ void fldr_note_range(bool bad) { if (bad) { fldr_tu_range_flag = 1; fldr_status_raise_range(); } }
 static inline int fldr_tu_range_read(int reset) {

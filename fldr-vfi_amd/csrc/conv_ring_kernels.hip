@@ -68,12 +68,15 @@ FLDR_HOOK int fldr_debug_read_ring_stamps(unsigned long long* host) {
 #endif
 
 __device__ int fldr_ring_timeouts;
-// Polls a bounded wait makes before it gives up (read on the slow path only).  Test build: fldr_debug_ring_spin_limit(0) makes every wait
-// that is not satisfied at once expire — the way the fault path (counter, status block, poisoned outputs) is exercised.
-__device__ int fldr_ring_spin_limit = RING_SPIN_LIMIT;
+// Polls a bounded wait makes before it gives up: a KERNEL ARGUMENT (SpkArgs::spin_limit, set by the launchers from g_ring_spin_limit) —
+// as a __device__ variable it cost every launch a global-memory round trip in its prologue or in front of the second poll of its first
+// wait: +0.7 us on each of the 39 ring launches of a forward (tools/small_conv_probe.py, round 6).  Test build:
+// fldr_debug_ring_spin_limit(0) makes every wait that is not satisfied at once expire — the way the fault path (counter, status block,
+// poisoned outputs) is exercised.
+static int g_ring_spin_limit = RING_SPIN_LIMIT;
 FLDR_HOOK int fldr_debug_ring_spin_limit(int v) {
-    if (v < 0) v = RING_SPIN_LIMIT;
-    return hipMemcpyToSymbol(HIP_SYMBOL(fldr_ring_spin_limit), &v, sizeof(int)) == hipSuccess ? v : -1;
+    g_ring_spin_limit = v < 0 ? RING_SPIN_LIMIT : v;
+    return g_ring_spin_limit;
 }
 FLDR_HOOK int fldr_debug_ring_timeouts(void) {
     int v = -1;
@@ -111,7 +114,7 @@ struct RingCfg {
     static constexpr int CTR_OFF = WRES_OFF + (RW ? RING_RW_MAX_CHUNKS * W_BYTES : 0);   // FULL[8] at +0, FREE[8] at +32
     static constexpr int BIAS_OFF = CTR_OFF + 64;                       // bias of the workgroup's 16 * NMT output channels (fp32)
     static constexpr int LDS_BYTES = BIAS_OFF + 64 * NMT;
-    static_assert(SLOTS <= 7 && INFLIGHT + 2 <= SLOTS && INFLIGHT * K_DMA <= 15, "ring shape (FREE[7] is the POISON word)");
+    static_assert(SLOTS <= 8 && INFLIGHT + 2 <= SLOTS && INFLIGHT * K_DMA <= 15, "ring shape");
     static_assert(TW == 16 || TW == 32, "tile width");
     static_assert(TW != SPK_TW || PLANE == SPK_PLANE, "the 32-pixel plane is the barrier pipeline's");
     static_assert(PLANE / 16 >= 64 && NXI * 64 >= SPK_IH * IW, "DMA pieces cover the plane");
@@ -126,25 +129,42 @@ __device__ __forceinline__ uint32_t ring_peek(uint32_t lds_addr) {
 }
 
 // Spin until the counter at lds_addr reaches `target` (counters only grow).  Bounded: see the file header.  An expired wait is a library
-// fault and is never silent: it is counted (fldr_ring_status), stored into the host-visible status block and the device's frame poison
-// (common.h: fldr_status_raise_ring), and it sets the workgroup's POISON word in LDS (`poison_addr`), which every consumer reads in its
-// epilogue: the units this workgroup still finishes are written as NaN instead of values computed from operands that had not landed.
-#define RING_POISON_OFF 60                      // byte offset of the POISON word from FULL[0] (the slot of FREE[7]: rings have <= 7 slots)
-__device__ __forceinline__ void ring_wait_ge(uint32_t lds_addr, uint32_t target, int lane, uint32_t poison_addr) {
+// fault and is never silent.  The WAVE is faulted from then on: `limit` (wave-uniform, an SGPR the wave holds anyway) becomes negative.
+// A faulted wave never waits again (every later wait returns after one look: the launch stays bounded), and
+//   * a faulted CONSUMER writes NaN for every unit it still finishes (its accumulators may hold products of operands that had not landed)
+//     and stops releasing slots, so the loaders cannot overwrite a slot on its behalf: they expire on FREE in turn;
+//   * a faulted LOADER retires at once (it never fills a slot that has not been released), so every consumer expires on FULL in turn;
+//   * where it leaves its loop, a faulted wave REPORTS (ring_report_fault): the event is counted (fldr_ring_status) and stored into the
+//     host-visible status block and the device's frame poison (common.h: fldr_status_raise_ring) — before the kernel ends, so every frame
+//     synthesised behind this launch is NaN.
+// A unit is therefore stored as values only by a consumer all of whose waits were satisfied: its operands had landed and were not
+// overwritten.  What this costs a launch that does not fault was measured on the same box against the round-5 kernels
+// (profiles/r06_ring_wait_ab.txt) and shaped the code:
+//   * no shared poison word: the epilogue's test is one scalar compare (a word in LDS, read in every epilogue, cost the residual kernels 14
+//     spilled registers: +18 % on the 48-channel residual launches of the 4K forward);
+//   * the report is NOT inlined behind the wait: ~40 instructions of cold code between every wait and the code that follows it cost each
+//     of the ~35 small launches of a forward 0.35 us (one more instruction-cache miss per wait site in a launch whose every fetch is cold);
+//   * eight polls per trip of the loop, each with its own exit, as the compiler unrolled it by itself while the limit was a constant
+//     (rolled — counter, compare and two more branches between polls — every ring launch took 0.3 us longer);
+//   * every value of the loop is wave-uniform: scalar loop control.
+__device__ __forceinline__ void ring_wait_ge(uint32_t lds_addr, uint32_t target, int& limit) {
     if (ring_peek(lds_addr) >= target) return;
-    const int limit = *(volatile const int*)&fldr_ring_spin_limit;
-    int spins = 0;
-    while (true) {
-        if (++spins > limit) {
-            if (lane == 0) {
-                atomicAdd(&fldr_ring_timeouts, 1);
-                fldr_status_raise_ring();
-                asm volatile("ds_write_b32 %0, %1" :: "v"(poison_addr), "v"(1u) : "memory");
-            }
-            return;
+    bool landed = false;
+    for (int spins = 0; spins < limit && !landed; spins += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            __builtin_amdgcn_s_sleep(1);
+            if (ring_peek(lds_addr) >= target) { landed = true; break; }
         }
-        __builtin_amdgcn_s_sleep(1);
-        if (ring_peek(lds_addr) >= target) return;
+    }
+#ifndef RING_AB_NOFAULT                                                  // (A/B builds only: what the fault bookkeeping costs a launch)
+    if (!landed) limit = -1;
+#endif
+}
+__device__ __forceinline__ void ring_report_fault(int lane) {
+    if (lane == 0) {
+        atomicAdd(&fldr_ring_timeouts, 1);
+        fldr_status_raise_ring();
     }
 }
 
@@ -172,6 +192,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_chunks = a.n_chunks;
     const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);   // LDS byte address of FULL[0]; FREE[s] at +32 + 4 s
+#ifdef RING_AB_CONSTLIMIT                                               // A/B builds only: the limit as a constant instead of a kernel argument
+    int spin_limit = RING_SPIN_LIMIT;
+#else
+    int spin_limit = a.spin_limit;                                        // negative once a wait of this wave has expired (ring_wait_ge)
+#endif
 
     if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
     if (tid >= 64 && tid < 64 + 16 * NMT) {                               // (unit -> output group as below: constant over the workgroup)
@@ -297,7 +322,8 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             }
             if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
             RSTAMP(l1)
-            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane, ctr + RING_POISON_OFF);
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, spin_limit);
+            if (spin_limit < 0) break;                                    // expired: this loader retires (below), nothing is filled over a slot in use
             RSTAMP(l2)
             unsigned char* stage = smem + st * Cfg::STAGE;
 #if defined(RING_ABLATE) && RING_ABLATE == 3                          // diagnostic: no DMA traffic after the prologue fills
@@ -326,6 +352,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #endif
             if (++st == SLOTS) { st = 0; free_target += RING_NCONS; }
         }
+        if (spin_limit < 0) { ring_report_fault(lane); __builtin_amdgcn_s_waitcnt(0x0F70); return; }   // retired on an expired wait: report; its last fills are never announced
         // the last INFLIGHT fills (st = slot after the last fill), oldest first
         if constexpr (Cfg::INFLIGHT == 2) {
             if (total >= 2) {
@@ -466,11 +493,11 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
         char* outn = a.out_f32 ? reinterpret_cast<char*>(a.out_f32 + (int64_t)n * a.cout_store * HW) + u_f32_off : nullptr;
         char* spkn = a.out_spk ? reinterpret_cast<char*>(a.out_spk) + (int64_t)n * a.out_spk_bstride + u_spk_off : nullptr;
         const bool inside = oy0 + ROWS <= uH && ox0 + TW <= uW;      // wave-uniform
-        // POISON: a bounded wait of this workgroup's ring expired (ring_wait_ge) — the accumulators may hold products of operands that
-        // had not landed; the unit is written as NaN (general path below) instead
-        const bool poisoned = ring_peek(ctr + RING_POISON_OFF) != 0u; // wave-uniform
+        // a wait of this wave expired (ring_wait_ge): its accumulators may hold products of operands that had not landed — the unit is
+        // written as NaN (general path below) instead
+        const bool poisoned = spin_limit < 0;                            // wave-uniform, scalar
         RSTAMP(f1)
-        if (grp_full && inside && !poisoned) {
+        if (grp_full && inside) {
             const uint32_t p0 = (uint32_t)(oy0 * uW + ox0 + lj);
             // pass 1: the finished values in place of the accumulators, and per lane the sum of their magnitudes — the range guard of the
             // split is decided ONCE per unit and wave (common.h: fldr_guard_trips) instead of a compare and two clamps per value
@@ -534,11 +561,14 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 }
                 if constexpr (GUARDED) { if (a.out_spk) fldr_note_range(range_bad); }
             };
-            if (fldr_guard_trips(abs_sum)) emit(std::true_type{}); else emit(std::false_type{});
+            if (!poisoned) {
+                if (fldr_guard_trips(abs_sum)) emit(std::true_type{}); else emit(std::false_type{});
 #ifdef RING_STAMPS
-            { RSTAMP(f2) cs_f_dec += f1 - f0; cs_f_fast += f2 - f1; cs_f_b0 += fq0 - f1; }
+                { RSTAMP(f2) cs_f_dec += f1 - f0; cs_f_fast += f2 - f1; cs_f_b0 += fq0 - f1; }
 #endif
-            return;
+                return;
+            }
+            // (poisoned: the general path below writes NaN for every value of the unit and clears the accumulators)
         }
         uint32_t po[NQ];
 #pragma unroll
@@ -547,6 +577,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             po[q] = (oy < uH && ox < uW) ? (uint32_t)(oy * uW + ox) : ~0u;
         }
         const bool quads = !(a.cout_store & 3);                          // whole quads of channels: one predicate per 4 stores
+        bool range_bad = false;                                          // (one flag raise per unit: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
         for (int q = 0; q < NQ; ++q)
 #pragma unroll
@@ -566,9 +597,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                 }
                 {
                     _Float16 h[4], l[4];
-                    bool bad = false;
-                    fldr_split_hl_group(xs, h, l, bad);
-                    if (a.out_spk) fldr_note_range(bad);
+                    fldr_split_hl_group(xs, h, l, range_bad);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { ohi[r] = h[r]; olo[r] = l[r]; }
                 }
@@ -598,6 +627,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     }
                 }
             }
+        if (a.out_spk && !poisoned) fldr_note_range(range_bad);          // (a poisoned unit's accumulators are garbage: not a range event)
     };
 
     int st_cur = 0;
@@ -703,13 +733,13 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
 #if defined(RING_ABLATE) && RING_ABLATE == 5                          // diagnostic: consumers never look at FULL after the first fills (timing only: stale operands)
         if (g < SLOTS)
 #endif
-        ring_wait_ge(ctr + 4 * st_cur, full_target, lane, ctr + RING_POISON_OFF);
+        ring_wait_ge(ctr + 4 * st_cur, full_target, spin_limit);
 #ifdef RING_STAMPS
         { RSTAMP(t) c1 = t; }
 #endif
     };
     auto iter_end = [&]() __attribute__((always_inline)) {
-        ring_signal(ctr + 32 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
+        if (spin_limit >= 0) ring_signal(ctr + 32 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
 #ifdef RING_STAMPS
         { RSTAMP(t) c2 = t; }
 #endif
@@ -750,6 +780,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
             iter_close();
         }
     }
+    if (spin_limit < 0) ring_report_fault(lane);                          // a wait of this consumer expired: its units were written as NaN; report
 #ifdef RING_STAMPS
     RSTAMP(c_end)
     if ((blockIdx.x == 0 || blockIdx.x == 101) && wave == 0 && lane == 0) {
@@ -797,6 +828,11 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n_chunks = a.n_chunks;
     const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);
+#ifdef RING_AB_CONSTLIMIT                                               // A/B builds only: the limit as a constant instead of a kernel argument
+    int spin_limit = RING_SPIN_LIMIT;
+#else
+    int spin_limit = a.spin_limit;                                        // negative once a wait of this wave has expired (ring_wait_ge)
+#endif
     if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
     if (tid >= 64 && tid < 96) {
         const int u0 = (blockIdx.x & 7) * a.units_per_xcd + (blockIdx.x >> 3);
@@ -873,7 +909,8 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
                 dptr[i] = (off != ~0u && !nul) ? base + off : zero_blk;
             }
             if (++iss_c == n_chunks) { iss_c = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
-            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane, ctr + RING_POISON_OFF);
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, spin_limit);
+            if (spin_limit < 0) break;                                    // expired: this loader retires (below), nothing is filled over a slot in use
             unsigned char* stage = smem + st * Cfg::STAGE;
 #pragma unroll
             for (int i = 0; i < Cfg::NWL; ++i)
@@ -887,6 +924,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
             }
             if (++st == SLOTS) { st = 0; free_target += NC; }
         }
+        if (spin_limit < 0) { ring_report_fault(lane); __builtin_amdgcn_s_waitcnt(0x0F70); return; }   // retired on an expired wait: report; its last fills are never announced
         __builtin_amdgcn_s_waitcnt(0x0F70);
         ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
         return;
@@ -917,14 +955,15 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
         const bool ok = oy < a.H && ox < a.W;
         unsigned char* spkn = a.out_spk + (int64_t)n * a.out_spk_bstride;
         const uint32_t pq = ok ? (uint32_t)(oy * a.W + ox) : 0u;
-        const bool poisoned = ring_peek(ctr + RING_POISON_OFF) != 0u;     // a wait of this workgroup's ring expired: the unit is written as NaN
         float abs_sum = 0.0f;                                             // (the range guard of the split: once per unit and wave)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             acc[r] = fmaxf(acc[r] * inv_scale + bias_r[r], relu_floor);
             abs_sum += fabsf(acc[r]);
         }
+        const bool poisoned = spin_limit < 0;                             // a wait of this wave expired (ring_wait_ge): the unit is written as NaN
         const bool guard = fldr_guard_trips(abs_sum);
+        bool bad = false;
 #pragma unroll
         for (int r0 = 0; r0 < 16; r0 += 4) {
             const int co0 = grp0 * 32 + 8 * (r0 >> 2) + 4 * lh;
@@ -934,7 +973,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
                 const float v = acc[r0 + r];
                 acc[r0 + r] = 0.0f;
                 _Float16 h, l;
-                if (guard) { bool bad = false; spk_split(v, h, l, bad); fldr_note_range(bad); } else fldr_split_plain(v, h, l);
+                if (guard) spk_split(v, h, l, bad); else fldr_split_plain(v, h, l);
                 ohi[r] = h; olo[r] = l;
             }
             if (poisoned) {
@@ -947,12 +986,13 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
                 *reinterpret_cast<h4*>(spkn + (off + HW32 * 16u)) = olo;
             }
         }
+        if (guard && !poisoned) fldr_note_range(bad);
     };
     int st_cur = 0, g = 0;
     uint32_t full_target = RING_NLOAD;
     while (g < total) {
         const bool last = cur_c == n_chunks - 1;
-        ring_wait_ge(ctr + 4 * st_cur, full_target, lane, ctr + RING_POISON_OFF);
+        ring_wait_ge(ctr + 4 * st_cur, full_target, spin_limit);
         {
             const unsigned char* sb = smem + st_cur * Cfg::STAGE;
             const unsigned char* wb = sb + lane * 16;
@@ -978,11 +1018,12 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ring32_kernel(S
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        ring_signal(ctr + 32 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
+        if (spin_limit >= 0) ring_signal(ctr + 32 + 4 * st_cur, lane);                        // all my operand reads of the slot are issued: FREE
         if (last) { finish_store(); cur_c = 0; cur_u += a.wgs_per_xcd; } else ++cur_c;
         if (++st_cur == SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
         ++g;
     }
+    if (spin_limit < 0) ring_report_fault(lane);                          // a wait of this consumer expired: its units were written as NaN; report
 }
 
 #ifdef FLDR_TEST_HOOKS
@@ -1026,6 +1067,11 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
     const int n32 = a.n_chunks;                                           // (the launcher passes 32-channel blocks here)
     const int n_items = 3 * n32;
     const uint32_t ctr = (uint32_t)(uintptr_t)(klptr_t)(smem + Cfg::CTR_OFF);
+#ifdef RING_AB_CONSTLIMIT                                               // A/B builds only: the limit as a constant instead of a kernel argument
+    int spin_limit = RING_SPIN_LIMIT;
+#else
+    int spin_limit = a.spin_limit;                                        // negative once a wait of this wave has expired (ring_wait_ge)
+#endif
     if (tid < 16) reinterpret_cast<uint32_t*>(smem + Cfg::CTR_OFF)[tid] = 0u;
     if (tid >= 64 && tid < 64 + 16 * NMT) {
         const int u0 = (blockIdx.x & 7) * a.units_per_xcd + (blockIdx.x >> 3);
@@ -1099,7 +1145,8 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
                 dlo[i] = ok ? base + plane_b + off : zero_blk;
             }
             if (++iss_i == n_items) { iss_i = 0; iss_u += a.wgs_per_xcd; if (iss_u < u_end) issue_geometry(); }
-            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, lane, ctr + RING_POISON_OFF);
+            if (free_target) ring_wait_ge(ctr + 32 + 4 * st, free_target, spin_limit);
+            if (spin_limit < 0) break;                                    // expired: this loader retires (below), nothing is filled over a slot in use
             unsigned char* stage = smem + st * Cfg::STAGE;
 #pragma unroll
             for (int i = 0; i < Cfg::NWL; ++i)
@@ -1115,6 +1162,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
             }
             if (++st == SLOTS) { st = 0; free_target += NC; }
         }
+        if (spin_limit < 0) { ring_report_fault(lane); __builtin_amdgcn_s_waitcnt(0x0F70); return; }   // retired on an expired wait: report; its last fills are never announced
         __builtin_amdgcn_s_waitcnt(0x0F70);
         ring_signal(ctr + 4 * ((st + SLOTS - 1) % SLOTS), lane);
         return;
@@ -1150,7 +1198,6 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
         const int ty = spk_div(tile, a.m_tiles_x, a.tiles_x), tx = tile - ty * a.tiles_x;
         const int oy = ty * SPK_TH + cw;
         unsigned char* spkn = a.out_spk + (int64_t)n * a.out_spk_bstride;
-        const bool poisoned = ring_peek(ctr + RING_POISON_OFF) != 0u;
         float abs_sum = 0.0f;
 #pragma unroll
         for (int m = 0; m < NMT; ++m)
@@ -1162,6 +1209,8 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
                     abs_sum += fabsf(acc[m][q][r]);
                 }
         const bool guard = fldr_guard_trips(abs_sum);
+        const bool poisoned = spin_limit < 0;
+        bool bad = false;
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const int ox = tx * SPK_TW + q * 16 + lj;
@@ -1176,7 +1225,7 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
                     const float v = acc[m][q][r];
                     acc[m][q][r] = 0.0f;
                     _Float16 h, l;
-                    if (guard) { bool bad = false; spk_split(v, h, l, bad); fldr_note_range(bad); } else fldr_split_plain(v, h, l);
+                    if (guard) spk_split(v, h, l, bad); else fldr_split_plain(v, h, l);
                     ohi[r] = h; olo[r] = l;
                 }
                 if (poisoned) {
@@ -1190,12 +1239,13 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
                 }
             }
         }
+        if (guard && !poisoned) fldr_note_range(bad);
     };
     int st_cur = 0, g = 0;
     uint32_t full_target = RING_NLOAD;
     while (g < total) {
         const bool last = cur_i == n_items - 1;
-        ring_wait_ge(ctr + 4 * st_cur, full_target, lane, ctr + RING_POISON_OFF);
+        ring_wait_ge(ctr + 4 * st_cur, full_target, spin_limit);
         {
             const unsigned char* sb = smem + st_cur * Cfg::STAGE;
             const unsigned char* win = sb + lane * 16;
@@ -1234,11 +1284,12 @@ __global__ __launch_bounds__((8 + RING_NLOAD) * 64) void conv3x3_ringrow_kernel(
                 spk_step_pattern_n<N_MFMA, N_DS, N_TAIL, 0>(s + 1 < 3);
             }
         }
-        ring_signal(ctr + 32 + 4 * st_cur, lane);
+        if (spin_limit >= 0) ring_signal(ctr + 32 + 4 * st_cur, lane);
         if (last) { finish_store(); cur_i = 0; cur_u += a.wgs_per_xcd; } else ++cur_i;
         if (++st_cur == SLOTS) { st_cur = 0; full_target += RING_NLOAD; }
         ++g;
     }
+    if (spin_limit < 0) ring_report_fault(lane);                          // a wait of this consumer expired: its units were written as NaN; report
 }
 
 // weight section of the experiment: [group of 16 NMT outputs][32-channel block][dy][dx][m][hi, lo][lane = channel group * 16 + output][8 channels]
@@ -1280,6 +1331,7 @@ static int ringrow_launch(SpkArgs& a, const float* wrow, int N, int wgs_per_xcd_
     if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ringrow_kernel<NMT>), Cfg::LDS_BYTES, attr_done)) return e;
     a.groups = a.cout / (16 * NMT);
     if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, SPK_TW)) return e;
+    a.spin_limit = g_ring_spin_limit;
     hipLaunchKernelGGL(conv3x3_ringrow_kernel<NMT>, dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a, wrow);
     FLDR_LAUNCH_RET();
 }
@@ -1300,6 +1352,7 @@ static int ring_launch3(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) {
     static std::atomic<uint64_t> attr_done{0};
     if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW, false, RW>), Cfg::LDS_BYTES, attr_done)) return e;
     if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, TW)) return e;
+    a.spin_limit = g_ring_spin_limit;
     hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, NC, TW, false, RW>), dim3(8 * a.wgs_per_xcd), dim3((NC + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }
@@ -1378,6 +1431,7 @@ static int ring32_launch(SpkArgs& a, int N, int wgs_per_xcd_max, hipStream_t s) 
     if (int e = fldr_set_max_lds(reinterpret_cast<const void*>(&conv3x3_ring32_kernel), Ring32Cfg::LDS_BYTES, attr_done)) return e;
     a.groups = a.cout / 32;
     if (int e = spk_fill_geometry(a, N, wgs_per_xcd_max, SPK_TW)) return e;
+    a.spin_limit = g_ring_spin_limit;
     hipLaunchKernelGGL(conv3x3_ring32_kernel, dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Ring32Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }
@@ -1427,6 +1481,7 @@ static int ring_launch_levels(SpkArgs& a, int n_units, int wgs_per_xcd_max, hipS
     a.wgs_per_xcd = spk_right_size(a.units_per_xcd, wgs_per_xcd_max, a.groups);
     if (((int64_t)a.n_units + 8 * a.units_per_xcd) * a.groups >= (1ll << 32)) return FLDR_E_SHAPE;
     a.m_groups = (uint32_t)((1ull << 32) / (uint32_t)a.groups) + 1u;
+    a.spin_limit = g_ring_spin_limit;
     hipLaunchKernelGGL((conv3x3_ring_kernel<NMT, TERMS, HAS_RES, 8, 32, true>), dim3(8 * a.wgs_per_xcd), dim3((8 + RING_NLOAD) * 64), Cfg::LDS_BYTES, s, a);
     FLDR_LAUNCH_RET();
 }

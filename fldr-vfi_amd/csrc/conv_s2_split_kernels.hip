@@ -192,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         h2* hi = reinterpret_cast<h2*>(stage + Cfg::W_BYTES) + wave * CHS;
         h2* lo = hi + KIND;
+        bool bad = false;                                                          // (one flag raise per call: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
         for (int i = 0; i < S2_NI; ++i) {
             if (l_dw[i] < 0) continue;
@@ -200,14 +201,13 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
             {
                 const float xs[2] = {x0, x1};
                 _Float16 hs[2], ls[2];
-                bool bad = false;
                 fldr_split_hl_group(xs, hs, ls, bad);
-                fldr_note_range(bad);
                 h[0] = hs[0]; h[1] = hs[1]; l[0] = ls[0]; l[1] = ls[1];
             }
             hi[l_dw[i]] = h;                                                       // half 0 = the even row of the pair
             lo[l_dw[i]] = l;
         }
+        fldr_note_range(bad);
     };
 
     issue_weights(0, smem);
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
 #pragma unroll
                 for (int r = 0; r < NR; ++r) abs_sum += fabsf(vv[r]);
                 const bool guard = fldr_guard_trips(abs_sum);
+                bool bad = false;                                                   // (one flag raise per tile of outputs: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
                 for (int r0 = 0; r0 < NR; r0 += 4) {
                     const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
@@ -306,10 +307,8 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
                         for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                         if (guard) {
                             {
-                                bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
-                                fldr_note_range(bad);
                             }
                         } else {
 #pragma unroll
@@ -324,6 +323,7 @@ __global__ __launch_bounds__(256, 2) void conv4x4s2_split_kernel(S2Args a) {
                         *reinterpret_cast<h4*>(q + HWo * 16) = lo;
                     }
                 }
+                if (guard) fldr_note_range(bad);
             }
         }
     }
@@ -501,13 +501,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         }
         auto emit = [&](auto guardedc) __attribute__((always_inline)) {
             constexpr bool GUARDED = decltype(guardedc)::value;
+            bool bad = false;                                                      // (one flag raise per emit: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
             for (int i = 0; i < NIT; ++i) {
                 if (l_dw[i] < 0) continue;
                 _Float16 hs[PER], ls[PER];
 #pragma unroll
                 for (int k = 0; k < PER; ++k) {
-                    if constexpr (GUARDED) { bool bad = false; fldr_split_hl(xs[i][k], hs[k], ls[k], bad); fldr_note_range(bad); } else fldr_split_plain(xs[i][k], hs[k], ls[k]);
+                    if constexpr (GUARDED) fldr_split_hl(xs[i][k], hs[k], ls[k], bad); else fldr_split_plain(xs[i][k], hs[k], ls[k]);
                 }
                 if constexpr (V4) {
                     // columns x = 4 q - 1 .. 4 q + 2 of the window: odd plane index 2 q - 1 (x = -1: the padding in front of the line),
@@ -525,6 +526,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                     lo[l_dw[i]] = l;
                 }
             }
+            if constexpr (GUARDED) fldr_note_range(bad);
         };
         if (fldr_guard_trips(abs_sum)) emit(std::true_type{}); else emit(std::false_type{});
     };
@@ -633,6 +635,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
                     for (int r = 0; r < NR; ++r) abs_sum += fabsf(vv[r]);
                     const bool guard = fldr_guard_trips(abs_sum);
+                    bool bad = false;                                                   // (one flag raise per tile of outputs: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
                     for (int r0 = 0; r0 < NR; r0 += 4) {
                         const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
@@ -644,10 +647,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                             for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                             if (guard) {
                                 {
-                                    bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
-                                    fldr_note_range(bad);
                                 }
                             } else {
 #pragma unroll
@@ -662,6 +663,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                             *reinterpret_cast<h4*>(q + HWo * 16) = lo;
                         }
                     }
+                    if (guard) fldr_note_range(bad);
                 }
             }
         }
@@ -905,6 +907,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
                     for (int r = 0; r < NR; ++r) abs_sum += fabsf(vv[r]);
                     const bool guard = fldr_guard_trips(abs_sum);
+                    bool bad = false;                                                   // (one flag raise per tile of outputs: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
                     for (int r0 = 0; r0 < NR; r0 += 4) {
                         const int co0 = MT == 32 ? m * 32 + 8 * (r0 >> 2) + 4 * lk : m * 16 + lk * 4;
@@ -916,10 +919,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                             for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                             if (guard) {
                                 {
-                                    bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
                                     for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
-                                    fldr_note_range(bad);
                                 }
                             } else {
 #pragma unroll
@@ -934,6 +935,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
                             *reinterpret_cast<h4*>(q + HWo * 16) = lo;
                         }
                     }
+                    if (guard) fldr_note_range(bad);
                 }
             }
         }
@@ -1117,6 +1119,7 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
 #pragma unroll
                 for (int r = 0; r < 16; ++r) abs_sum += fabsf(vv[r]);
                 const bool guard = fldr_guard_trips(abs_sum);
+                bool bad = false;                                                   // (one flag raise per tile of outputs: the raise is cold code, kept out of the unrolled body)
 #pragma unroll
                 for (int r0 = 0; r0 < 16; r0 += 4) {
                     const int co0 = 8 * (r0 >> 2) + 4 * lg;
@@ -1128,10 +1131,8 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
                         for (int r = 0; r < 4; ++r) xs[r] = co0 + r < a.cout_store ? vv[r0 + r] : 0.0f;
                         if (guard) {
                             {
-                                bool bad = false;                                   // (one flag test per four values)
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) fldr_split_hl(xs[r], hs[r], ls[r], bad);
-                                fldr_note_range(bad);
                             }
                         } else {
 #pragma unroll
@@ -1150,6 +1151,7 @@ __global__ __launch_bounds__((4 + S2D_NLOAD) * 64) void conv4x4s2_dma_spk_kernel
 #endif
                     }
                 }
+                if (guard) fldr_note_range(bad);
             }
         }
     };

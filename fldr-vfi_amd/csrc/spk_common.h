@@ -43,6 +43,9 @@ struct SpkArgs {
     // tensors lie at byte offsets from level 0's (grp_ptr[0] / out_spk / out_f32 / residual).  H, W, tiles_x, n_tiles, m_tiles,
     // m_tiles_x above are unused then.
     int32_t n_levels;
+    int32_t spin_limit;                           // ring kernels: polls a bounded wait makes before it expires (conv_ring_kernels.hip sets it at launch).
+                                                  // HERE (the padding in front of lv[], next to the scalars every prologue reads): at the end of the
+                                                  // struct it was one more kernel-argument cache line, fetched when the first wait needed it
     struct SpkLevel {
         int32_t H, W, tiles_x, n_tiles, unit0, pad;
         uint32_t m_tiles_x, pad2;
