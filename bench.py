@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--width", type=int, default=W4K)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
     ap.add_argument("--dry", action="store_true", help="no GPU work: a step is a 1 ms sleep (CPU test of the launcher / reductions)")
+    ap.add_argument("--share-gpu", action="store_true", help="REHEARSAL on a 1-GPU box: all N ranks run their GPU work on device 0 (process group: gloo); exercises the "
+                                                             "multi-process launch, per-rank sharding, barriers and reductions around real HIP work - the line says so and its value is no measurement")
     return ap.parse_args()
 
 
@@ -275,13 +277,14 @@ def main():
         os.environ.setdefault("WORLD_SIZE", "1")
     gpu = not a.dry
     if gpu:
-        torch.cuda.set_device(local_rank)
-        device = torch.device("cuda", local_rank)
+        dev_index = 0 if a.share_gpu else local_rank
+        torch.cuda.set_device(dev_index)
+        device = torch.device("cuda", dev_index)
     else:
         device = torch.device("cpu")
     pg_backend = None
     if use_pg:
-        pg_backend = "nccl" if (a.backend == "nccl" and gpu) else "gloo"
+        pg_backend = "nccl" if (a.backend == "nccl" and gpu and not a.share_gpu) else "gloo"       # (RCCL refuses two ranks on one device)
         if pg_backend == "nccl":
             dist.init_process_group("nccl", device_id=device)              # RCCL on ROCm
         else:
@@ -619,6 +622,9 @@ def main():
         if use_pg:
             res["config"]["process_group"] = {"backend": pg_backend + (" (RCCL)" if pg_backend == "nccl" else ""), "world_size": pg_world,
                                               "forced_at_world_size_1": world == 1}
+        if a.share_gpu and world > 1:
+            res["rehearsal"] = ("%d ranks SHARE device 0 (--share-gpu): the multi-process launch, sharding, barriers and reductions around real HIP work on a "
+                                "1-GPU box; `value` is NOT a measurement of %d GPUs" % (world, world))
         if a.dry:
             res["dry"] = True
             res["data"] = "none (dry run: 1 ms sleep per step)"

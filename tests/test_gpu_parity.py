@@ -2051,6 +2051,33 @@ def test_bench_rccl_process_group_world_size_one(dev, clean_launcher):
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and len(j["config"]["per_rank_pairs_per_s"]) == 1
 
 
+def test_bench_two_ranks_share_the_gpu_rehearsal(dev, clean_launcher):
+    """The N > 1 path of bench.py with REAL device work in every rank, as far as a 1-GPU lease allows: `bench.py --gpus 2 --share-gpu`
+    starts two ranks through its own launcher (python -m torch.distributed.run), both run their forwards on device 0 (RCCL refuses two
+    ranks on one device: the process group is gloo), each on its own disjoint pairs (shard_pairs), and rank 0 prints one line with the
+    MAX-over-ranks time, two per-rank rates, cpu_baseline absent only because the test asks so.  Small frames: two processes with 4K
+    pyramids would only make the test slow.  What this proves: two GPU processes of this package start, load the library, bind their
+    status blocks, run and meet at the barriers; NOT a scaling number (the line says `rehearsal`)."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--backend", "gloo", "--steps", "4", "--warmup", "1",
+           "--height", "540", "--width", "960", "--sustained-s", "0", "--no-cpu-baseline", "--varying-motion-steps", "0", "--incl-ingest-steps", "0",
+           "--multi-t-pairs", "0", "--fp16-mode-steps", "0", "--config5-steps", "0"]
+    r = clean_launcher(cmd, env=env, timeout=540)
+    assert r["rc"] == 0, (r["stdout"][-2000:], r["stderr"][-4000:])
+    js = [json.loads(l) for l in r["stdout"].splitlines() if l.startswith("{")]
+    assert len(js) == 1, r["stdout"][-2000:]
+    j = js[0]
+    assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0 and "rehearsal" in j
+    assert len(j["config"]["per_rank_pairs_per_s"]) == 2 and all(x > 0 for x in j["config"]["per_rank_pairs_per_s"])
+    assert j["config"]["process_group"]["backend"] == "gloo" and j["config"]["process_group"]["world_size"] == 2
+    assert j["config"]["parallelism"].startswith("dp2")
+
+
 def test_evaluate_dir_matches_per_frame_pipeline(hip, dev, model, tmp_path):
     """fldr_harness.evaluate_dir (the dataset-shaped entry: main.py:815-911) on a folder of PNG frames written here — one scene of
     5 frames, multiple = 4: the pair (0, 4) and its three intermediate targets — against the per-frame pipeline the other tests
