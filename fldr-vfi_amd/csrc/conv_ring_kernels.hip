@@ -627,7 +627,7 @@ __global__ __launch_bounds__((NC + RING_NLOAD) * 64) void conv3x3_ring_kernel(Sp
                     }
                 }
             }
-        if (a.out_spk && !poisoned) fldr_note_range(range_bad);          // (a poisoned unit's accumulators are garbage: not a range event)
+        if (a.out_spk && spin_limit >= 0) fldr_note_range(range_bad);    // (a poisoned unit's accumulators are garbage: not a range event)
     };
 
     int st_cur = 0;
