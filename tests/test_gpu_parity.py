@@ -1163,6 +1163,32 @@ def test_model_matches_reference_golden(hip, oracle, golden, dev, model, case):
     assert p > 90.0
 
 
+def test_flow_levels_with_identity_splat_match_reference_golden(hip, golden, dev, model, monkeypatch):
+    """The one whole-pyramid vector of the reference that has NO restated splat inside (tests/golden/flows_identity_splat_256x256.npz,
+    tools/make_golden.py: identity_splat_case — the reference's own model run with its CUDA-only splat replaced by the identity): flow
+    levels 5..1 from the reference's features through the HIP path — resize kernels, conv_flow_bottom, the paired conv_flow1 launch,
+    conv_flow2 with its flow residual, shipped weights — with the feature splat of this package replaced by the same identity.
+    Pins everything around the splat against reference-executed numbers only (the other model goldens carry the ORACLE's splat)."""
+    m, _ = model
+    g, gi = golden("model_256x256_t0500"), golden("flows_identity_splat_256x256")
+    calls = []
+
+    def identity_splat(xs, flows, zs, mode, want_f32=True, want_spk=False, spk_batch=False, bounds_ws=None):
+        assert want_spk and not want_f32 and zs is None and mode == "softmax" and len(xs) == 2
+        calls.append(tuple(xs[0].shape))
+        if spk_batch:
+            return hip.spk_pack(torch.cat([x.contiguous() for x in xs], 0))
+        return tuple(hip.spk_pack(x.contiguous()) for x in xs)
+    monkeypatch.setattr(hip, "softsplat_acc64", identity_splat)
+    flow = None
+    with torch.no_grad():
+        for level in range(5, 0, -1):
+            feat = torch.from_numpy(g["feat%d" % level]).to(dev)
+            flow = m.vfinet.estimate_flow(feat, flow)
+            _cmp(flow, torch.from_numpy(gi["flow%d" % level]), atol=2e-4, rtol=1e-4, what="identity-splat flow L%d" % level)
+    assert len(calls) == 4                                                  # levels 4..1 splat; level 5 is conv_flow_bottom
+
+
 # ---------------------------------------------------------------------------------------------------
 # the REFERENCE's stand-alone stage vectors (tests/golden/ops.npz, tools/make_golden.py op_cases) on the HIP stacks with the SHIPPED
 # weights — the magnitudes the fp16 split's pre-scaling and range guard actually see (the per-layer tests above use random weights)
