@@ -1349,6 +1349,14 @@ def test_level0_stages_match_reference_golden(hip, oracle, golden, dev, model, c
         for name, rf in (("refine_out", refine), ("refine_out (phase-convolution dec3)", refine2)):
             worst[name] = max(worst.get(name, 0.0), _cmp(rf[sl], torch.from_numpy(g["refine_out_crops"][ci]), atol=2e-4, rtol=1e-5, what="%s crop %d" % (name, ci)))
     np.testing.assert_allclose(refine.double().sum((0, 2, 3)).cpu().numpy(), g["refine_out_sum"], rtol=1e-5, atol=0.5)
+    # the WHOLE 26-plane input, not only its crops: per-plane sum and sum of magnitudes against the reference's (a checksum per plane;
+    # allowance: 1e-5 of the plane's magnitude + what its ill-conditioned mask pixels can move: at most |value| <= 16 each)
+    cs, ca = cat.double().sum((0, 2, 3)).cpu().numpy(), cat.double().abs().sum((0, 2, 3)).cpu().numpy()
+    n_ill = ill26.sum((0, 2, 3)).numpy().astype(np.float64)
+    slack = 1e-5 * g["cat26_abssum"] + 0.05 + 16.0 * n_ill
+    assert (np.abs(cs - g["cat26_sum"]) <= slack).all(), (np.abs(cs - g["cat26_sum"]), slack)
+    assert (np.abs(ca - g["cat26_abssum"]) <= slack).all(), (np.abs(ca - g["cat26_abssum"]), slack)
+    worst["cat26 plane sums (rel. to magnitude)"] = float((np.abs(cs - g["cat26_sum"]) / g["cat26_abssum"]).max())
     ref = torch.from_numpy(g["out"]).double()[:, :, :H, :W]
     worst["frame (two-kernel tail)"] = _cmp(out2, ref, atol=2e-5, what="frame from dec3_synth")
     print("%s level 0 vs reference: %s; ill-conditioned mask pixels %d" % (case, ", ".join("%s %.2e" % kv for kv in worst.items()), int(ill26.any(1).sum())))
