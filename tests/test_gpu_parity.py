@@ -1457,6 +1457,12 @@ def test_model_pyramid_depths(hip, oracle, weights, golden, dev, case):
     assert out.shape[-2:] == (H, W) and out.dtype == torch.float64
     y0, x0, h, w = (int(v) for v in g["window"])
     err = _cmp(out[..., y0:y0 + h, x0:x0 + w], torch.from_numpy(g["out"]), atol=1e-4, what="S_tst=%d vs reference" % S)
+    # the WHOLE frame against the reference through its per-channel checksums (the deep cases store only a window of the frame):
+    # mean error per value <= 1e-6 like the oracle bound below; and the padded size the reference worked on
+    assert list(Hn.pad_frames(frames, a).shape[-2:]) == list(g["padded"])
+    npx = float(H * W)
+    assert (np.abs(out.sum((0, 2, 3)).cpu().numpy() - g["out_sum"]) <= 1e-6 * npx).all()
+    assert (np.abs(out.abs().sum((0, 2, 3)).cpu().numpy() - g["out_abssum"]) <= 1e-6 * npx).all()
     with torch.no_grad():
         ref = oracle.forward(weights, oracle.pad_and_pyramid(frames, n_levels=S + 1), t)[..., :H, :W]
     _cmp(out, ref, atol=1e-4, what="S_tst=%d vs oracle" % S)
