@@ -2091,6 +2091,27 @@ def test_bench_rccl_process_group_world_size_one(dev, clean_launcher):
     assert j["n_gpus"] == 1 and j["steps"] == 2 and j["value"] > 0 and len(j["config"]["per_rank_pairs_per_s"]) == 1
 
 
+def test_every_entry_point_rejects_null_arguments(dev, clean_launcher):
+    """Error behaviour of the C ABI (include/fldr_hip.h: every compute entry returns a negative FLDR_E_* code for arguments it cannot run
+    on, before any launch): tools/abi_null_probe.py calls every exported non-debug entry point with null pointers / zero sizes and, where
+    it takes a descriptor, with a zero-initialised one — in a process of its own, so that a missing check is a failed test (the child's
+    segmentation fault), not a dead session.  Size queries of a shape answer FLDR_E_ARG for the zero shape as well."""
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = clean_launcher([sys.executable, os.path.join(root, "tools", "abi_null_probe.py")], env=dict(os.environ), timeout=300)
+    assert r["rc"] == 0, (r["rc"], r["stdout"][-1500:], r["stderr"][-3000:])
+    codes = json.loads([l for l in r["stdout"].splitlines() if l.startswith("{")][-1])
+    assert len(codes) >= 50, len(codes)
+    constants = ("fldr_dec23_prepack_size", "fldr_dec3_prepack_spk_size", "fldr_sizeof_desc")      # sizes that do not depend on a pointer or a shape
+    bad = {k: v for k, v in codes.items() if not all(c is not None and (c < 0 or k in constants) for c in v)}
+    assert not bad, bad
+    for k in ("fldr_conv2d_spk", "fldr_dec23_synth", "fldr_level0_prep", "fldr_softsplat_acc64", "fldr_pca_project_pyramid", "fldr_conv2d_s2_spk",
+              "fldr_correlation_fwd", "fldr_ingest_pyramid_u8", "fldr_status_word"):
+        assert codes[k] == [-1, -1], (k, codes[k])                        # FLDR_E_ARG, with and without a (zeroed) descriptor
+
+
 def test_bench_two_ranks_share_the_gpu_rehearsal(dev, clean_launcher):
     """The N > 1 path of bench.py with REAL device work in every rank, as far as a 1-GPU lease allows: `bench.py --gpus 2 --share-gpu`
     starts two ranks through its own launcher (python -m torch.distributed.run), both run their forwards on device 0 (RCCL refuses two
