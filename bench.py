@@ -333,21 +333,48 @@ def main():
 
         def capture_graphs():
             # fldr_harness.GraphedInterpolator (the opt-in replay API of the harness): one instance per (stream, pair), the instances of
-            # a stream share a memory pool; each checks its first replay against an eager forward of its pair on its stream (the same
-            # bits, or no graphs at all: a capture that baked in another stream's workspace would otherwise be timed unnoticed)
+            # a stream share a memory pool; the first replay of each is checked against an eager forward of its pair on its stream (the same
+            # bits, or no graphs at all: a capture that baked in another stream's workspace would otherwise be timed unnoticed).
+            # Those validation replays run BACK TO BACK right in front of the warm-up (validate_graphs below), their frames are kept and
+            # compared after the timed region: done one by one with a synchronisation each (as until round 6) they left the board idle for
+            # seconds, and the --warmup steps (10 ms at W = 5) do not bring it back to its steady state — tools/region_warm_probe.py on one
+            # box: the 20-step region 1.962-1.972 ms per step after 1 s of idle + 5 steps, 1.910-1.940 with 12 more steps in front.
             try:
                 pools = [torch.cuda.graph_pool_handle() for _ in streams]
                 for s_i, st in enumerate(streams):
                     for k in range(npairs):
-                        gi = Hn.GraphedInterpolator(model, args, frames[k], t, pyramid=pyrs[k], stream=st, pool=pools[s_i], check=True)
+                        gi = Hn.GraphedInterpolator(model, args, frames[k], t, pyramid=pyrs[k], stream=st, pool=pools[s_i], check="defer")
                         graphs[(s_i, k)] = gi
                         graph_outs[(s_i, k)] = gi.out
                 torch.cuda.synchronize()
-                graph_state.update(on=True, why="%d graphs (streams x pairs; fldr_harness.GraphedInterpolator), every one replayed once and == its eager frame bit for bit" % len(graphs))
+                graph_state.update(on=True, why="%d graphs (streams x pairs; fldr_harness.GraphedInterpolator) captured" % len(graphs))
             except Exception as e:                                   # eager steps still work
                 graphs.clear(); graph_outs.clear()
                 graph_state.update(on=False, why="capture failed: %r" % (e,))
                 torch.cuda.synchronize()
+
+        def validate_graphs():
+            """Every graph replayed once, in the order the loop uses them, no synchronisation; frames kept for verify_graphs()."""
+            order = []
+            for i in range(len(streams) * npairs):                    # the loop's own order (consecutive replays on different streams) ...
+                sk = (i % len(streams), i % npairs)
+                if sk not in order:
+                    order.append(sk)
+            order += [sk for sk in graphs if sk not in order]         # ... then the combinations the loop never reaches
+            for sk in order:
+                graphs[sk].first_replay()
+
+        def verify_graphs():
+            try:
+                for gi in graphs.values():
+                    gi.verify()
+                graph_state["why"] = ("%d graphs (streams x pairs; fldr_harness.GraphedInterpolator), every one replayed once right in front of the warm-up "
+                                      "and == its eager frame bit for bit (compared after the timed region)" % len(graphs))
+                return True
+            except Exception as e:
+                graphs.clear(); graph_outs.clear()
+                graph_state.update(on=False, why="replay check failed: %r; the timed region was repeated with eager steps" % (e,))
+                return False
 
         def step(i):
             if graph_state["on"]:
@@ -366,21 +393,27 @@ def main():
     sync()
     if gpu and not a.no_graphs:
         capture_graphs()
-    for i in range(a.warmup):
-        out = step(i)
-    sync()
-    # (the single-stream latency legs run AFTER the timed region: the --warmup steps directly precede it.  An extra untimed 0.5 / 1.5 s of the
-    # same loop in front of it was tried in round 6 and changed nothing systematic: 516.9 / 510.1 / 476.3 vs 507.1 / 512.1 pairs/s on one box —
-    # the 20-step region's spread is its own fill / drain transient between two synchronisations, not the board's clock state)
-    # ---- the timed region: EXACTLY --steps steps between barrier + synchronize on both sides -------------
-    barrier()
-    sync()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        out = step(i)
-    sync()
-    barrier()
-    dt_local = time.perf_counter() - t0
+        if graph_state["on"]:
+            validate_graphs()
+
+    def timed_region():
+        """--warmup untimed steps, then EXACTLY --steps steps between barrier + synchronize on both sides."""
+        o = None
+        for i in range(a.warmup):
+            o = step(i)
+        sync()
+        barrier()
+        sync()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            o = step(i)
+        sync()
+        barrier()
+        return time.perf_counter() - t0, o
+    # (the single-stream latency legs run AFTER the timed region: the --warmup steps directly precede it)
+    dt_local, out = timed_region()
+    if gpu and graph_state["on"] and not verify_graphs():          # a replay that differs from its eager frame: nothing of it is reported
+        dt_local, out = timed_region()
     # ---- sustained rate: the same loop for >= --sustained-s seconds (clocks settle, caches in steady state) ---
     dt = max_over_ranks(dt_local, device)
     if gpu:

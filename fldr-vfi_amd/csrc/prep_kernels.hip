@@ -69,15 +69,27 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 // P2: both scales are exact powers of two (the model's x8 upsampling): integer source-index arithmetic (prep_lin_in).
 // A wave covers 64 pixels of ONE row: everything that depends on the row only (its source rows and weight, its byte offset) is
 // wave-uniform and lives in scalar registers.
+// PREP_TAP_WINDOWS (default 0 since the end of round 6): the 3 x 3 low-resolution neighbourhoods of the two backward-flow taps through the
+// wave's tap windows (round 5: -15 us).  WITH them the kernel wrote wrong im1_tot values — 16-pixel runs, lanes 48-63 of a wave, mostly
+// 0.0 — whenever a kernel of ANOTHER stream had workgroups on the same CUs (enc1: 24 of 24 runs, dec1 23 / 24, dec0 14 / 24; alone or
+// beside kernels that fill the LDS — the 96-channel convolutions, the synthesis kernel — never): 1-6 wrong frames in 12 with three pairs in
+// flight (bench.py's loop), none with one forward at a time, which is all the tests ran.  Found by bench.py's deferred replay check and
+// taken apart in tools/concurrency_check.py / profiles/r06_prep_concurrency.txt: not the stores, not the gathers' queue depth, not the
+// scalar lane masks (each ruled out by a build), not the pixel's own neighbour window (phase 1 keeps it); with the tap windows compiled
+// out 0 of 288 frames differ.  The mechanism inside the tap-window path is NOT established; the path stays in the source for that work.
+#ifndef PREP_TAP_WINDOWS
+#define PREP_TAP_WINDOWS 0
+#endif
 #ifndef PREP_WPE
 #define PREP_WPE 7                 // <= 72 registers: seven waves per SIMD (8 spills; 6 measured 2 % slower)
 #endif
 template <int PH, bool P2>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREP_WPE))) void level0_prep_kernel(PrepArgs a) {
 #pragma clang fp contract(off)
-    __shared__ __attribute__((aligned(16))) unsigned char prep_lds[4 * PREP_WAVE_LDS];
+    constexpr int WAVE_LDS = PREP_TAP_WINDOWS ? PREP_WAVE_LDS : 2 * PREP_QW * 16;      // (without the tap windows: the quad window alone, 640 B per wave)
+    __shared__ __attribute__((aligned(16))) unsigned char prep_lds[4 * WAVE_LDS];
     const int tx = threadIdx.x & 63, ty = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const prep_lds_t wq = (prep_lds_t)prep_lds + ty * PREP_WAVE_LDS;     // this wave's windows (prep_device.h): quad, tap 0, tap 1
+    const prep_lds_t wq = (prep_lds_t)prep_lds + ty * WAVE_LDS;          // this wave's windows (prep_device.h): quad, tap 0, tap 1
     const prep_lds_t wu0 = wq + 2 * PREP_QW * 16;
     const prep_lds_t wu1 = wu0 + PREP_UW * PREP_UH * 8;
     const int px_raw = blockIdx.x * 64 + tx;
@@ -155,8 +167,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREP_WPE)))
             // (the taps' low-resolution neighbourhoods through the wave's windows; a wave whose flows are too incoherent for them redoes
             // its pixels on the global path)
             bool fail = false;
+#if PREP_TAP_WINDOWS
             PrepP2 r = prep_phase2_pixel<P2, true>(a, fpx, fpy, f10, f01, lo10, lo01, i0, i1, tv, omt, wu0, wu1, tx, fail);
             if (fail) r = prep_phase2_pixel<P2, false>(a, fpx, fpy, f10, f01, lo10, lo01, i0, i1, tv, omt, wu0, wu1, tx, fail);
+#else
+            PrepP2 r = prep_phase2_pixel<P2, false>(a, fpx, fpy, f10, f01, lo10, lo01, i0, i1, tv, omt, wu0, wu1, tx, fail);
+#endif
             put(6, r.fb0.x); put(7, r.fb0.y); put(8, r.fb1.x); put(9, r.fb1.y);
 #pragma unroll
             for (int c = 0; c < 3; ++c) { put(10 + c, r.im0[c]); put(13 + c, r.im1[c]); }

@@ -138,6 +138,8 @@ class GraphedInterpolator:
         g.replay(join=True)                                       # inputs already written in place (g.frames / g.t / g.pyramid)
     `pyramid=` fixes a prebuilt pyramid as the input instead of the frames (bench.py: pyramids resident in HBM).  One instance per
     stream / slot in flight; capture uses a memory pool of its own (or `pool=`, to share one among the slots of a stream).
+    check=True: the first replay is compared with an eager forward at once; check="defer": the caller does first_replay() (no
+    synchronisation) and verify() later — bench.py replays all its instances back to back right in front of its warm-up that way.
     The pair cache is not captured (model.pair_cache must be off)."""
 
     def __init__(self, model, args, frames, t_value, pyramid=None, stream=None, pool=None, check=True):
@@ -155,13 +157,32 @@ class GraphedInterpolator:
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph, pool=pool, stream=self.stream):
             self.out = interpolate(model, args, self.frames, self.t, pyramid=self.pyramid)
-        if check:                                                    # one replay against the eager frame: the same bits, or no graph
+        self._ref = self._first = None
+        if check == "defer":                                         # the caller replays first (first_replay) and compares later (verify): no
+            self._ref = ref                                          # synchronisation between the capture and the caller's loop
+        elif check:                                                  # one replay against the eager frame: the same bits, or no graph
             with torch.cuda.stream(self.stream):
                 self.graph.replay()
             self.stream.synchronize()
             if not torch.equal(ref, self.out):
                 raise RuntimeError("the replayed frame differs from the eager frame")
         del ref
+
+    def first_replay(self):
+        """check="defer": replay once and keep a copy of the frame (on the instance's stream, no synchronisation) for verify()."""
+        self.replay()
+        with torch.cuda.stream(self.stream):
+            self._first = self.out.clone()
+
+    def verify(self):
+        """check="defer": the kept first replay against the eager frame of the capture — the same bits, or RuntimeError.  Synchronises."""
+        if self._ref is None or self._first is None:
+            raise RuntimeError("verify() needs check='defer' and a first_replay()")
+        self.stream.synchronize()
+        ok = torch.equal(self._ref, self._first)
+        self._ref = self._first = None
+        if not ok:
+            raise RuntimeError("the replayed frame differs from the eager frame")
 
     def replay(self, join=False):
         """Replay on the instance's stream.  join: the caller's current stream waits for it (device-side) before using the output;

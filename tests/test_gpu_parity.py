@@ -1363,6 +1363,51 @@ def test_level0_stages_match_reference_golden(hip, oracle, golden, dev, model, c
     hip.check_range()
 
 
+def test_pairs_in_flight_equal_one_at_a_time(hip, dev, model):
+    """bench.py's loop — forwards of DIFFERENT 3840x2160 pairs kept in flight on three HIP streams, eagerly and as hipGraph replays — against
+    the same forwards run one at a time: every frame the same bits.  Round 6 found that they were not: with another stream's kernels
+    keeping the memory pipeline busy, the last of level0_prep's 24 back-to-back gathers read lanes 48-63 of their offsets from a register
+    the compiler had already reused (profiles/r06_prep_gather_hazard.txt) — 16-pixel runs of zeros in im1_tot, 1-6 wrong frames in 12,
+    never with one forward at a time, which is what every other test runs.  (Full-size frames: the hazard needs the queue depth and the
+    memory traffic of the 4K kernels.)"""
+    import fldr_harness as Hn
+    m, a = model
+    t = torch.tensor([[0.5]], device=dev)
+    NS, NP = 3, 4
+    frames = [Hn.frames_from_uint8(Hn.synthetic_pair(2160, 3840, seed=40 + p)).to(dev) for p in range(NP)]
+    with torch.no_grad():
+        pyrs = [Hn.build_pyramid(Hn.pad_frames(f, a), a) for f in frames]
+        refs = [Hn.interpolate(m, a, frames[k], t, pyramid=pyrs[k]).clone() for k in range(NP)]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+        for rep in range(3):
+            for s in streams:
+                s.wait_stream(torch.cuda.current_stream())
+            outs = []
+            for i in range(12):
+                with torch.cuda.stream(streams[i % NS]):
+                    outs.append((i % NP, Hn.interpolate(m, a, frames[i % NP], t, pyramid=pyrs[i % NP])))
+            torch.cuda.synchronize()
+            bad = [(i, k, float((o - refs[k]).abs().max())) for i, (k, o) in enumerate(outs) if not torch.equal(o, refs[k])]
+            assert not bad, ("eager forwards in flight on 3 streams differ from the one-at-a-time frames", rep, bad)
+            del outs
+    pools = [torch.cuda.graph_pool_handle() for _ in streams]
+    gs = {(s, k): Hn.GraphedInterpolator(m, a, frames[k], t, pyramid=pyrs[k], stream=streams[s], pool=pools[s], check=True) for s in range(NS) for k in range(NP)}
+    torch.cuda.synchronize()
+    for rep in range(3):
+        got = []
+        for i in range(24):
+            sk = (i % NS, i % NP)
+            gs[sk].replay()
+            with torch.cuda.stream(streams[sk[0]]):
+                got.append((sk[1], gs[sk].out.clone()))
+        torch.cuda.synchronize()
+        bad = [(i, k, float((o - refs[k]).abs().max())) for i, (k, o) in enumerate(got) if not torch.equal(o, refs[k])]
+        assert not bad, ("graph replays in flight on 3 streams differ from the one-at-a-time frames", rep, bad)
+        del got
+    hip.check_range()
+
+
 def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
     """Batch of 2 (the PCA min/max is then taken over the batch, as in the reference)."""
     import fldr_harness as Hn
