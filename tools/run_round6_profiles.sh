@@ -9,6 +9,7 @@ bash tools/prof_forward_sq.sh r06_sq > gpurun_out/r6f/sq.log 2>&1; echo "sq done
 bash tools/trace_forward_launches.sh r06_launches > gpurun_out/r6f/launches.log 2>&1; tail -1 gpurun_out/r6f/launches.log
 bash tools/prof_dec23_sq.sh r06_d23sq > gpurun_out/r6f/d23sq.log 2>&1; echo "d23 counters done"
 timeout -k 10 400 bash tools/energy_table.sh r06 4 > gpurun_out/r6f/energy.log 2>&1; tail -22 gpurun_out/r6f/energy.log
+timeout -k 10 600 python tools/concurrency_check.py 6 > gpurun_out/r6f/concurrency.txt 2>&1; tail -1 gpurun_out/r6f/concurrency.txt
 python bench.py > gpurun_out/r6f/bench.json 2> gpurun_out/r6f/bench.err; tail -c 300 gpurun_out/r6f/bench.err
 python - <<'PY'
 import json
