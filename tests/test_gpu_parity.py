@@ -1408,6 +1408,19 @@ def test_pairs_in_flight_equal_one_at_a_time(hip, dev, model):
     hip.check_range()
 
 
+def test_every_stage_beside_every_stage_equals_the_stage_alone(dev, clean_launcher):
+    """tools/pairwise_concurrency.py: each of the 12 stages of the 4K forward as the victim on one HIP stream beside each stage as the partner
+    on a second stream (different frame pairs), 3 runs per cell: every victim result the same bits as the stage alone.  The whole-forward
+    test above samples these overlaps at random; this one walks the matrix (level0_prep beside enc1 / dec1 / dec0 was where round 6's
+    defect lived)."""
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = clean_launcher([sys.executable, os.path.join(root, "tools", "pairwise_concurrency.py"), "1"], env=dict(os.environ), timeout=540)
+    assert r["rc"] == 0, (r["rc"], r["stdout"][-2500:], r["stderr"][-1500:])
+    assert "TOTAL victim results differing from the stage alone: 0" in r["stdout"]
+
+
 def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
     """Batch of 2 (the PCA min/max is then taken over the batch, as in the reference)."""
     import fldr_harness as Hn
