@@ -18,8 +18,15 @@ L = open(orig).read().splitlines()
 i0 = next(i for i, l in enumerate(L) if re.match(r"^(_Z\S+):", l) and pat in l)
 i1 = next(i for i in range(i0, len(L)) if L[i].startswith(".Lfunc_end"))
 out, n = [], 0
+ZERO = os.environ.get("ZERO_INIT")                                      # "v1-69,s5-82": registers cleared at the kernel's entry (uninitialised-read hunt)
 for i, l in enumerate(L):
     out.append(l)
+    if ZERO and i == i0:
+        for part in ZERO.split(","):
+            kind, rng = part[0], part[1:].split("-")
+            for r in range(int(rng[0]), int(rng[1]) + 1):
+                out.append("\t%s_mov_b32 %s%d, 0" % ("v" if kind == "v" else "s", kind, r))
+        out.append("\ts_mov_b64 vcc, 0")
     k = i - i0
     if i0 < i < i1 and lo <= k <= hi and l.startswith("\t") and not l.strip().startswith((";", ".")) and not re.match(r"\s+(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)", l):
         out.append("\ts_nop %d" % imm); n += 1
