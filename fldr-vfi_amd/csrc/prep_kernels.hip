@@ -8,6 +8,12 @@
 // directly plus through L2-friendly gathers, and only the 16 (+2) planes the consumers need are written.
 // Every value is produced by the SAME device functions and operation order as the unfused kernels (fldr_lin_src,
 // fldr_grid_tap, fldr_tap_sample, fldr_tap_mask; contraction off), so the results are bit-identical to them.
+#include <hip/hip_runtime.h>
+// No packed-fp32 instructions (v_pk_add / mul / fma_f32) in this file's device code — see PREP_TAP_WINDOWS below for why; the kernel is bound by its
+// vector-memory address traffic, not by arithmetic, and takes the same time without them.
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
+#endif
 #include "prep_device.h"
 
 struct PrepArgs {
@@ -69,16 +75,19 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 // P2: both scales are exact powers of two (the model's x8 upsampling): integer source-index arithmetic (prep_lin_in).
 // A wave covers 64 pixels of ONE row: everything that depends on the row only (its source rows and weight, its byte offset) is
 // wave-uniform and lives in scalar registers.
-// PREP_TAP_WINDOWS (default 0 since the end of round 6): the 3 x 3 low-resolution neighbourhoods of the two backward-flow taps through the
-// wave's tap windows (round 5: -15 us).  WITH them the kernel wrote wrong im1_tot values — 16-pixel runs, lanes 48-63 of a wave, mostly
-// 0.0 — whenever a kernel of ANOTHER stream had workgroups on the same CUs (enc1: 24 of 24 runs, dec1 23 / 24, dec0 14 / 24; alone or
-// beside kernels that fill the LDS — the 96-channel convolutions, the synthesis kernel — never): 1-6 wrong frames in 12 with three pairs in
-// flight (bench.py's loop), none with one forward at a time, which is all the tests ran.  Found by bench.py's deferred replay check and
-// taken apart in tools/concurrency_check.py / profiles/r06_prep_concurrency.txt: not the stores, not the gathers' queue depth, not the
-// scalar lane masks (each ruled out by a build), not the pixel's own neighbour window (phase 1 keeps it); with the tap windows compiled
-// out 0 of 288 frames differ.  The mechanism inside the tap-window path is NOT established; the path stays in the source for that work.
+// PREP_TAP_WINDOWS (default 1): the 3 x 3 low-resolution neighbourhoods of the two backward-flow taps through the wave's tap windows
+// (round 5: -15 us).  THIS FILE IS COMPILED WITHOUT PACKED-FP32 INSTRUCTIONS (the pragma at its top), and must stay so:
+// with the windows hipcc 7.2 forms `v_pk_add_f32 v[36:37], v[36:37], v[4:5] op_sel:[0,1]` for the taps' y coordinates (fb.y + fpy, the row as the
+// high register of the (fpx, fpy) pair), and on gfx950 that operand form — a packed fp32 add / mul / fma whose first vector-register source is read
+// straight and whose second through op_sel — returns low half = src0 + 0 in lanes 48-63 now and then while waves of ANOTHER kernel issue matrix
+// instructions on the same SIMD: im1_tot came out as runs of 16 zero pixels whenever enc1 / dec1 / dec0 of another stream shared the CUs (1-6 wrong
+// frames in 12 with three pairs in flight).  Found by bench.py's deferred replay check, traced to the instruction with probes edited into the
+// kernel's assembly (tools/asm_pad_variant.py, tools/asm_edits/), reproduced stand-alone (tools/ubench/pk_opsel_probe.hip: 7 of 25 operand forms,
+// only beside matrix instructions, only lanes 48-63, only the low half): profiles/r06_prep_concurrency.txt, profiles/r06_pk_opsel_probe.txt.
+// The kernel is bound by its vector-memory address traffic, not by arithmetic: without packed instructions it takes the same time.
+// tools/check_pk_opsel.py (CPU test) keeps every kernel of the library free of the affected forms.
 #ifndef PREP_TAP_WINDOWS
-#define PREP_TAP_WINDOWS 0
+#define PREP_TAP_WINDOWS 1
 #endif
 #ifndef PREP_WPE
 #define PREP_WPE 7                 // <= 72 registers: seven waves per SIMD (8 spills; 6 measured 2 % slower)
@@ -217,3 +226,6 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
 #undef PREP_LAUNCH
     FLDR_LAUNCH_RET();
 }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang attribute pop
+#endif

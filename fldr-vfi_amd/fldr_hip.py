@@ -169,6 +169,7 @@ _SIGNATURES = {
     "fldr_debug_ring32": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_resident": (ctypes.c_int, [ctypes.c_int]),
     "fldr_debug_ring_timeouts": (ctypes.c_int, []),
+    "fldr_debug_busy_partner": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
     "fldr_sizeof_desc": (ctypes.c_int, [ctypes.c_int]),
     "fldr_synth_tail": (ctypes.c_int, [_c_float_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
                                        _c_float_p, ctypes.c_double, _c_float_p, _c_float_p] + [ctypes.c_int] * 3 + [ctypes.c_void_p]),
@@ -257,6 +258,18 @@ def lib():
     if _lib is None:
         _lib = _load(LIB_PATH, want_hooks=False)
     return _lib
+
+
+def busy_partner(out, workgroups=512, lds_bytes=1024, iters=40000, kind=2):
+    """Concurrency tests / tools only (the TEST build's fldr_debug_busy_partner, whichever library the other calls go to): launch a kernel
+    on the current stream that only occupies the compute units — `workgroups` x 256 threads holding `lds_bytes` of LDS each, looping
+    `iters` times over kind 0 s_sleep, 1 matrix instructions, 2 vector FMAs, 3 scalar adds, 4 LDS reads.  `out`: >= workgroups * 256 floats."""
+    global _hooks_lib
+    if _hooks_lib is None:
+        _hooks_lib = _load(os.environ.get("FLDR_LIB") or TEST_LIB_PATH, want_hooks=True)
+    if out.dtype != torch.float32 or out.numel() < workgroups * 256:
+        raise ValueError("busy_partner: out must hold workgroups * 256 floats")
+    _check(_hooks_lib.fldr_debug_busy_partner(_dev(out, "out"), workgroups, lds_bytes, iters, kind, _stream()), "fldr_debug_busy_partner")
 
 
 class test_hooks:

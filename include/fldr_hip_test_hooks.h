@@ -31,6 +31,7 @@ FLDR_API int fldr_debug_ring_spin_limit(int v);                             /* p
 FLDR_API int64_t fldr_debug_ringrow_pack_floats(int cout, int cin);         /* round-6 experiment (ring item = 32 channels x one kernel row, no pad tap): floats of its weight section, < 0: shape not covered */
 FLDR_API int fldr_debug_ringrow_prepack(const float* weight, const float* wpack, float* wrow, int cout, int cin, fldr_stream_t stream);
 FLDR_API int fldr_debug_conv2d_ringrow(const fldr_spk_conv_desc* desc, const float* wrow, fldr_stream_t stream);
+FLDR_API int fldr_debug_busy_partner(float* out, int workgroups, int lds_bytes, int iters, int kind, fldr_stream_t stream);   /* concurrency tests: `workgroups` x 256 threads that hold `lds_bytes` of LDS each and loop `iters` times over kind 0 s_sleep, 1 matrix instructions, 2 vector FMAs, 3 scalar adds, 4 LDS reads; out: workgroups * 256 floats (csrc/test_partner_kernels.hip) */
 FLDR_API int fldr_debug_ring_timeouts(void);                                /* number of bounded ring waits that expired since load (0 unless a kernel misbehaved); synchronises */
 FLDR_API int fldr_debug_splat_tile_variant(int v);                          /* fldr_softsplat_tile: 1 (default) claim-and-add bands, 0 the LDS-f32-atomic tiles; other: query */
 FLDR_API int fldr_debug_pca_variant(int v);                                 /* fldr_pca_project_pyramid: 0 (default) vector fp64 kernel, 1 fp64 matrix-core kernel; other: query */

@@ -430,6 +430,50 @@ def test_product_kernels_use_no_scratch():
     assert not bad, bad
 
 
+def test_no_packed_fp32_source_read_through_op_sel_behind_another_vector_source():
+    """gfx950: a packed-fp32 add / mul / fma whose first vector-register source is read straight and a LATER one through op_sel = 1 returns a wrong
+    low half in lanes 48-63 now and then while waves of another kernel issue matrix instructions on the same SIMD (stand-alone reproducer:
+    tools/ubench/pk_opsel_probe.hip, profiles/r06_pk_opsel_probe.txt).  hipcc forms such instructions on its own — one in level0_prep's tap-window
+    build wrote runs of 16 wrong pixels whenever a convolution of another frame pair shared the CUs (profiles/r06_prep_concurrency.txt) — so the
+    disassembly of BOTH built libraries is checked (tools/check_pk_opsel.py), and level0_prep, where the form appeared, is compiled without packed
+    fp32 instructions altogether."""
+    import sys
+    libs = [os.path.join(ROOT, "fldr-vfi_amd", n) for n in ("libfldr_hip.so", "libfldr_hip_test.so")]
+    if not all(os.path.exists(l) for l in libs) or not os.path.exists("/opt/rocm/lib/llvm/bin/llvm-objdump"):
+        pytest.skip("libraries not built / no llvm-objdump")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_pk_opsel as C
+    # the rule itself, on the forms the probe measured: affected ...
+    lab = lambda l: None
+    for line in ("v_pk_add_f32 v[36:37], v[36:37], v[4:5] op_sel:[0,1]", "v_pk_mul_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1]", "v_pk_fma_f32 v[0:1], v[2:3], v[4:5], v[6:7] op_sel:[0,1,0]",
+                 "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_fma_f32 v[0:1], v[2:3], 1.0, v[4:5] op_sel:[0,0,1] op_sel_hi:[1,0,1]",
+                 "v_pk_fma_f32 v[0:1], s[2:3], v[4:5], v[6:7] op_sel:[0,0,1]"):
+        assert C.offenders_in_text(["\t" + line], lab), line
+    # ... and not affected (`op_sel:[1,1]` measured clean too; the rule flags it all the same: any later vector source through op_sel)
+    for line in ("v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]", "v_pk_add_f32 v[0:1], v[2:3], v[4:5] op_sel_hi:[1,0]",
+                 "v_pk_fma_f32 v[8:9], s[72:73], v[72:73], v[8:9] op_sel:[0,1,0]", "v_pk_add_f32 v[0:1], v[2:3], s[4:5] op_sel:[0,1]", "v_pk_mul_f32 v[0:1], s[2:3], v[4:5] op_sel:[1,0]",
+                 "v_pk_mul_f32 v[2:3], s[20:21], v[2:3] op_sel:[0,1] op_sel_hi:[1,0]", "v_pk_mov_b32 v[0:1], v[2:3], v[4:5] op_sel:[1,0]", "v_pk_add_f32 v[0:1], v[2:3], v[4:5]"):
+        assert not C.offenders_in_text(["\t" + line], lab), line
+    for l in libs:
+        assert C.offenders(l) == [], (l, C.offenders(l)[:5])
+    # level0_prep: no packed fp32 arithmetic at all (the pragma at the top of prep_kernels.hip)
+    import kernel_resources as K, subprocess, tempfile
+    n_prep = 0
+    for blob in K.code_objects(libs[0]):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(blob); f.flush()
+            txt = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "-d", f.name], capture_output=True, text=True).stdout
+        cur = None
+        for line in txt.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
+            if m:
+                cur = m.group(1)
+                n_prep += "level0_prep_kernel" in cur
+            elif cur and "level0_prep_kernel" in cur:
+                assert not re.search(r"\bv_pk_(add|mul|fma)_f32\b", line), (cur, line)
+    assert n_prep >= 6, n_prep
+
+
 def test_ring_kernels_listing_invariants(tmp_path):
     """What the same-box comparison with the round-5 kernels found in the convolution ring (profiles/r06_ring_wait_ab.txt), kept from
     coming back by a look at the gfx950 listing of the product build — nothing in the source enforces what the compiler emits:

@@ -19,7 +19,13 @@ i0 = next(i for i, l in enumerate(L) if re.match(r"^(_Z\S+):", l) and pat in l)
 i1 = next(i for i in range(i0, len(L)) if L[i].startswith(".Lfunc_end"))
 out, n = [], 0
 ZERO = os.environ.get("ZERO_INIT")                                      # "v1-69,s5-82": registers cleared at the kernel's entry (uninitialised-read hunt)
+VGPRS = os.environ.get("VGPRS")                                       # allocate this many vector registers per lane for the kernel whatever it uses
+kd0 = next(i for i, l in enumerate(L) if l.strip().startswith(".amdhsa_kernel") and pat in l)
 for i, l in enumerate(L):
+    if VGPRS and kd0 < i < kd0 + 80 and ".amdhsa_next_free_vgpr" in l and not any(".end_amdhsa_kernel" in x for x in L[kd0:i]):
+        l = "\t\t.amdhsa_next_free_vgpr %s" % VGPRS
+    if os.environ.get("SGPRS") and kd0 < i < kd0 + 80 and ".amdhsa_next_free_sgpr" in l and not any(".end_amdhsa_kernel" in x for x in L[kd0:i]):
+        l = "\t\t.amdhsa_next_free_sgpr %s" % os.environ["SGPRS"]
     out.append(l)
     if ZERO and i == i0:
         for part in ZERO.split(","):
@@ -30,6 +36,13 @@ for i, l in enumerate(L):
     k = i - i0
     if i0 < i < i1 and lo <= k <= hi and l.startswith("\t") and not l.strip().startswith((";", ".")) and not re.match(r"\s+(s_cbranch|s_branch|s_endpgm|s_setpc|s_swappc)", l):
         out.append("\ts_nop %d" % imm); n += 1
+EDIT = os.environ.get("EDIT")                                         # a python file run with `K` = the kernel's lines (label first), edited in place
+if EDIT:
+    j0 = next(i for i, l in enumerate(out) if re.match(r"^(_Z\S+):", l) and pat in l)
+    j1 = next(i for i in range(j0, len(out)) if out[i].startswith(".Lfunc_end"))
+    K = out[j0:j1]
+    exec(open(os.path.join(ROOT, EDIT)).read(), {"K": K, "re": re})
+    out[j0:j1] = K
 open(dev_s, "w").write("\n".join(out) + "\n")
 for c in (cmds[3], cmds[4], cmds[5], cmds[7], cmds[8], cmds[9]):
     subprocess.run(shlex.split(c), check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)

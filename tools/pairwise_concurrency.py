@@ -65,24 +65,36 @@ def stages_for(seed):
         cands = [wp[0], wp[1], pre["im0_tot"], pre["im1_tot"], I0, I1]
         f_dec23 = lambda: hip.dec23_synth(d1, enc1p, unet.dec2.weight, unet.dec2.bias, unet.dec3.weight, unet.dec3.bias, cands, t4, T)
         f_dec23()
+        # the two-kernel synthesis (FLDR_DEC23=0): dec2 as a ring convolution, then dec3 + softmax + blend
+        d2 = unet.forward_until_dec2(srcs, packed_out=hip.DEC3_MFMA and hip.use_spk())
+        f_dec3 = lambda: hip.dec3_synth(d2, unet.dec3.weight, unet.dec3.bias, cands, t4, T)
+        f_dec3()
         torch.cuda.synchronize()
-    keep = (fr, pyr, pv, pp, feats, flow1, flow0, pre, wp, enc1p, enc2p, e3, d0, d1)
+    keep = (fr, pyr, pv, pp, feats, flow1, flow0, pre, wp, enc1p, enc2p, e3, d0, d1, d2)
     return {"pca": f_pca, "rec_ctx_ds": f_feats, "flow levels 5-1": f_coarse, "flow level 0": f_flow0, "level0_prep": f_prep, "image splats": f_splat,
-            "enc1": f_enc1, "enc2": f_enc2, "enc3": f_enc3, "dec0": f_dec0, "dec1": f_dec1, "dec23_synth": f_dec23}, keep
+            "enc1": f_enc1, "enc2": f_enc2, "enc3": f_enc3, "dec0": f_dec0, "dec1": f_dec1, "dec23_synth": f_dec23, "dec3_synth (two-kernel path)": f_dec3}, keep
 with torch.no_grad():
     A, keepA = stages_for(7)
     B, keepB = stages_for(8)
     alone = {}
     for name, fn in A.items():
         alone[name] = [x.clone() for x in flat(fn())]; torch.cuda.synchronize()
+    # partners that are not stages: kernels that only keep the SIMDs busy (test build: csrc/test_partner_kernels.hip) — two workgroups per CU of
+    # vector FMAs made round 6's defect show in 8 of 8 runs where the forward's own kernels needed dozens
+    hog_out = torch.empty(1024 * 256, device=dev)
+    for label, kind, wgs, lds, iters in (("busy: vector FMAs", 2, 512, 1024, 40000), ("busy: matrix instr.", 1, 512, 1024, 20000), ("busy: scalar adds", 3, 512, 1024, 40000),
+                                         ("busy: LDS reads", 4, 512, 1024, 20000), ("busy: FMAs, 125 KB LDS", 2, 256, 125 * 1024, 40000)):
+        B[label] = (lambda kind=kind, wgs=wgs, lds=lds, iters=iters: hip.busy_partner(hog_out, wgs, lds, iters, kind))
     sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     total = 0
     names = list(A)
-    print("%-18s %s" % ("victim \\ partner", " ".join("%6s" % n[:6] for n in names)))
+    partners = list(B) if not os.environ.get("PARTNERS_BUSY_ONLY") else [n for n in B if n.startswith("busy")]
+    print("%-18s %s" % ("victim \\ partner", " ".join("%6s" % n.replace("busy: ", "b:")[:6] for n in partners)))
     for v in names:
         row = []
-        for p_ in names:
+        for p_ in partners:
             nbad = 0
+            if os.environ.get("VERBOSE_CELLS"): print("    cell: %s beside %s" % (v, p_), flush=True)
             for rep in range(REPS):
                 sA.wait_stream(torch.cuda.current_stream()); sB.wait_stream(torch.cuda.current_stream())
                 outs = []

@@ -43,6 +43,28 @@ with torch.no_grad():
         "dec0 (ring, 125 KB LDS)": lambda: hip.conv2d_spk(e3, unet.dec0.weight, unet.dec0.bias, relu=True, want_f32=False, want_spk=True),
         "image splats": lambda: hip.softsplat_acc64([I0, I1], [pre[0]["flow_t0"], pre[0]["flow_t1"]], [pre[0]["z0"], pre[0]["z1"]], "softmax", bounds_ws=bw),
     }
+    if os.environ.get("HOG"):
+        hog_out = torch.empty(1024 * 256, device=dev)
+        def hog(wgs, lds, iters, kind):
+            return lambda: hip.busy_partner(hog_out, wgs, lds, iters, kind)
+        if os.environ.get("HOG") == "old":                                  # the first experiment's kernel, inside prep_kernels.hip (-DPREP_HOG_EXPERIMENT builds)
+            import ctypes
+            Lh = ctypes.CDLL(os.environ["FLDR_LIB"])
+            Lh.fldr_debug_hog.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+            def hog(wgs, lds, iters, kind):
+                return lambda: Lh.fldr_debug_hog(hog_out.data_ptr(), wgs, lds, iters, kind, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if os.environ.get("HOG") == "footprints":
+            partners = {"busy (matrix instructions, 2 / CU), register footprint %d" % fp: hog(512, 1024, 20000, 1 + 16 * fp) for fp in range(10)}
+        elif os.environ.get("DUMP"): partners = {"hog: 1 KB LDS, matrix instructions, 2 / CU": hog(512, 1024, 20000, 1)}
+        else: partners = {
+            "hog: 125 KB LDS, sleeping": hog(256, 125 * 1024, 20000, 0),
+            "hog: 125 KB LDS, MFMAs": hog(256, 125 * 1024, 20000, 1),
+            "hog: 1 KB LDS, MFMAs, 2 / CU": hog(512, 1024, 20000, 1),
+            "hog: 1 KB LDS, vector FMAs, 2 / CU": hog(512, 1024, 40000, 2),
+            "hog: 1 KB LDS, scalar adds, 2 / CU": hog(512, 1024, 40000, 3),
+            "hog: 1 KB LDS, LDS reads, 2 / CU": hog(512, 1024, 20000, 4),
+                        "hog: 1 KB LDS, MFMAs, 1 wave per SIMD (256 WGs of 256)": hog(256, 1024, 20000, 1),
+        }
     sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     total = 0
     for name, fn in partners.items():
@@ -56,6 +78,38 @@ with torch.no_grad():
                 with torch.cuda.stream(sB): keep2 = fn()
             torch.cuda.synchronize()
             nbad += sum(1 for o in outs if not all(torch.equal(o[kk], pre[1][kk]) for kk in o))
+            if os.environ.get("DUMP") == "hwid":                        # probe5 build: flowback_0 = (HW_ID, XCC_ID) of the pixel's wave
+                import collections
+                o = outs[0]
+                hw = o["flowback_0"][0, 0].view(torch.int32); xc = o["flowback_0"][0, 1].view(torch.int32)
+                bad = (o["im1_tot"][0, 0] != pre[1]["im1_tot"][0, 0])
+                badw = bad.view(bad.shape[0], -1, 64)[:, :, 63]              # per wave (lane 63)
+                hww = hw.view(hw.shape[0], -1, 64)[:, :, 63]; xcw = xc.view(xc.shape[0], -1, 64)[:, :, 63]
+                def field(x, lo, n): return (x >> lo) & ((1 << n) - 1)
+                for nm, val in (("wave_id", field(hww, 0, 4)), ("simd_id", field(hww, 4, 2)), ("pipe_id", field(hww, 6, 2)), ("cu_id", field(hww, 8, 4)), ("sh_id", field(hww, 12, 1)),
+                                ("se_id", field(hww, 13, 3)), ("tg_id", field(hww, 16, 4)), ("queue_id", field(hww, 24, 3)), ("xcc_id", field(xcw, 0, 4))):
+                    allc = collections.Counter(val.flatten().tolist()); badc = collections.Counter(val[badw].flatten().tolist())
+                    print("      %-8s failing / all waves: %s" % (nm, ["%d: %d/%d" % (k, badc.get(k, 0), allc[k]) for k in sorted(allc)]), flush=True)
+                print("      failing waves %d of %d" % (int(badw.sum()), badw.numel()), flush=True)
+            elif os.environ.get("DUMP"):                                  # experiment builds (PREP_DUMP): which plane differs where, first few values
+                for o in outs:
+                    for kk in o:
+                        ne = (o[kk] != pre[1][kk])
+                        if ne.any():
+                            for ch in range(o[kk].shape[1]):
+                                nz = ne[0, ch].nonzero()
+                                if len(nz):
+                                    if os.environ.get("DUMP") == "rows":
+                                        dl = (pre[1][kk][0, ch] - o[kk][0, ch])
+                                        rows = sorted(set(nz[:, 0].tolist()))
+                                        print("      %s[%d] alone - beside by row: %s" % (kk, ch, [(r, sorted(set(dl[r][ne[0, ch, r]].tolist()))[:3]) for r in rows[:6] + rows[len(rows) // 2:len(rows) // 2 + 3]]), flush=True)
+                                        # which waves: (row % 4 = wave of the workgroup, column block)
+                                        import collections
+                                        print("      rows mod 4: %s; differing 16-pixel runs per row (first rows): %s" % (sorted(collections.Counter((nz[:, 0] % 4).tolist()).items()), [(r, int(ne[0, ch, r].sum()) // 16) for r in rows[:8]]), flush=True)
+                                    y, x = int(nz[0, 0]), int(nz[0, 1])
+                                    print("      %s[%d]: %d differ, lanes %s; first (%d,%d): alone %r beside %r" % (kk, ch, len(nz), sorted(set((nz[:, 1] % 64).tolist()))[:4] + ["..."] + sorted(set((nz[:, 1] % 64).tolist()))[-2:],
+                                          y, x, pre[1][kk][0, ch, y, x:x + 3].tolist(), o[kk][0, ch, y, x:x + 3].tolist()), flush=True)
+                    break
             if os.environ.get("VERBOSE"):
                 for o in outs:
                     d = {kk: int((o[kk] != pre[1][kk]).sum()) for kk in o if not torch.equal(o[kk], pre[1][kk])}
