@@ -1409,10 +1409,12 @@ def test_pairs_in_flight_equal_one_at_a_time(hip, dev, model):
 
 
 def test_every_stage_beside_every_stage_equals_the_stage_alone(dev, clean_launcher):
-    """tools/pairwise_concurrency.py: each of the 12 stages of the 4K forward as the victim on one HIP stream beside each stage as the partner
+    """tools/pairwise_concurrency.py: each of the 12 stages of the 4K forward (+ the two-kernel synthesis) as the victim on one HIP stream beside each
+    stage, and beside five busy-partner kernels of the test build (matrix instructions, vector FMAs, scalar adds, LDS reads: csrc/test_partner_kernels.hip),
     on a second stream (different frame pairs), 3 runs per cell: every victim result the same bits as the stage alone.  The whole-forward
     test above samples these overlaps at random; this one walks the matrix (level0_prep beside enc1 / dec1 / dec0 was where round 6's
-    defect lived)."""
+    defect lived: a packed-fp32 instruction that gfx950 executes wrongly beside another kernel's matrix instructions — the matrix-instruction
+    partner made that build fail in 8 of 8 runs)."""
     import os
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,7 @@
 """level0_prep on one HIP stream beside ONE other kernel of the forward on a second stream: does prep's output equal its output when it runs alone?
-(How the concurrency defect of round 6 was narrowed down: profiles/r06_prep_concurrency.txt.)   FLDR_LIB=<variant> python tools/prep_partner_check.py [reps]"""
+(How the concurrency defect of round 6 was narrowed down: profiles/r06_prep_concurrency.txt.)   FLDR_LIB=<variant> python tools/prep_partner_check.py [reps]
+HOG=1: the partners are busy-partner kernels of the test build instead (sleeping / matrix instructions / vector FMAs / scalar adds / LDS reads); HOG=footprints: the
+matrix-instruction partner with ten register footprints; DUMP=1 | rows | hwid with the probe builds of tools/asm_edits/: where the outputs differ."""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_harness as Hn, fldr_hip as hip, pca_comp
@@ -47,12 +49,6 @@ with torch.no_grad():
         hog_out = torch.empty(1024 * 256, device=dev)
         def hog(wgs, lds, iters, kind):
             return lambda: hip.busy_partner(hog_out, wgs, lds, iters, kind)
-        if os.environ.get("HOG") == "old":                                  # the first experiment's kernel, inside prep_kernels.hip (-DPREP_HOG_EXPERIMENT builds)
-            import ctypes
-            Lh = ctypes.CDLL(os.environ["FLDR_LIB"])
-            Lh.fldr_debug_hog.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
-            def hog(wgs, lds, iters, kind):
-                return lambda: Lh.fldr_debug_hog(hog_out.data_ptr(), wgs, lds, iters, kind, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
         if os.environ.get("HOG") == "footprints":
             partners = {"busy (matrix instructions, 2 / CU), register footprint %d" % fp: hog(512, 1024, 20000, 1 + 16 * fp) for fp in range(10)}
         elif os.environ.get("DUMP"): partners = {"hog: 1 KB LDS, matrix instructions, 2 / CU": hog(512, 1024, 20000, 1)}
@@ -63,7 +59,7 @@ with torch.no_grad():
             "hog: 1 KB LDS, vector FMAs, 2 / CU": hog(512, 1024, 40000, 2),
             "hog: 1 KB LDS, scalar adds, 2 / CU": hog(512, 1024, 40000, 3),
             "hog: 1 KB LDS, LDS reads, 2 / CU": hog(512, 1024, 20000, 4),
-                        "hog: 1 KB LDS, MFMAs, 1 wave per SIMD (256 WGs of 256)": hog(256, 1024, 20000, 1),
+            "hog: 1 KB LDS, MFMAs, 1 wave per SIMD (256 WGs of 256)": hog(256, 1024, 20000, 1),
         }
     sA, sB = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
     total = 0
