@@ -1,6 +1,6 @@
 """Forwards of DIFFERENT frame pairs kept in flight on several HIP streams (bench.py's loop, eager and as hipGraph replays) against the same
-forwards run one at a time: every frame must be the same bits.  Found in round 6: level0_prep's last gathers returned data from wrong
-addresses in lanes 48-63 when another stream's kernels kept the memory pipeline busy (DESIGN_LOG).   python tools/concurrency_check.py [reps]"""
+forwards run one at a time: every frame must be the same bits.  Found in round 6: one packed-fp32 instruction of level0_prep that gfx950
+executes wrongly in lanes 48-63 beside another stream's matrix instructions (profiles/r06_prep_concurrency.txt).   FH= FW= frame size, FLDR_CONV_PRECISION=fp16 the fp16 mode.   python tools/concurrency_check.py [reps]"""
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "fldr-vfi_amd"))
 import fldr_harness as Hn
