@@ -11,7 +11,11 @@
 #include <hip/hip_runtime.h>
 // No packed-fp32 instructions (v_pk_add / mul / fma_f32) in this file's device code — see PREP_TAP_WINDOWS below for why; the kernel is bound by its
 // vector-memory address traffic, not by arithmetic, and takes the same time without them.
-#if defined(__HIP_DEVICE_COMPILE__)
+// (-DPREP_ALLOW_PACKED_F32=1: the build that reproduces the defect — tools/asm_variant_setup.sh, tools/prep_partner_check.py; never the product)
+#ifndef PREP_ALLOW_PACKED_F32
+#define PREP_ALLOW_PACKED_F32 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !PREP_ALLOW_PACKED_F32
 #pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
 #endif
 #include "prep_device.h"
@@ -226,6 +230,6 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
 #undef PREP_LAUNCH
     FLDR_LAUNCH_RET();
 }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !PREP_ALLOW_PACKED_F32
 #pragma clang attribute pop
 #endif
