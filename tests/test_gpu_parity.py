@@ -1423,6 +1423,27 @@ def test_every_stage_beside_every_stage_equals_the_stage_alone(dev, clean_launch
     assert "TOTAL victim results differing from the stage alone: 0" in r["stdout"]
 
 
+def test_busy_partner_hook_runs_and_checks_its_arguments(hip, dev):
+    """The concurrency tests' partner kernel (test build only: csrc/test_partner_kernels.hip): every kind and register footprint launches and finishes,
+    bad arguments come back as FLDR_E_ARG instead of a launch."""
+    import ctypes
+    out = torch.full((512 * 256,), float("nan"), device=dev)
+    for kind in range(5):
+        for fp in (0, 1, 5, 9):
+            hip.busy_partner(out, 512, 1024, 50, kind + 16 * fp)
+    hip.busy_partner(out, 256, 125 * 1024, 50, 1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all()
+    with hip.test_hooks() as L:
+        s = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        p = ctypes.c_void_p(out.data_ptr())
+        for args in ((None, 512, 1024, 10, 1), (p, 0, 1024, 10, 1), (p, 5000, 1024, 10, 1), (p, 512, 512, 10, 1), (p, 512, 200 * 1024, 10, 1), (p, 512, 1024, -1, 1),
+                     (p, 512, 1024, 10, 5), (p, 512, 1024, 10, 1 + 16 * 10), (p, 512, 1024, 10, -1)):
+            assert L.fldr_debug_busy_partner(*args, s) == -1, args
+    with pytest.raises(ValueError):
+        hip.busy_partner(out[:100], 512, 1024, 10, 1)
+
+
 def test_model_matches_oracle_b2(hip, oracle, weights, dev, model):
     """Batch of 2 (the PCA min/max is then taken over the batch, as in the reference)."""
     import fldr_harness as Hn
