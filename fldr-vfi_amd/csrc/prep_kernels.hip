@@ -8,16 +8,6 @@
 // directly plus through L2-friendly gathers, and only the 16 (+2) planes the consumers need are written.
 // Every value is produced by the SAME device functions and operation order as the unfused kernels (fldr_lin_src,
 // fldr_grid_tap, fldr_tap_sample, fldr_tap_mask; contraction off), so the results are bit-identical to them.
-#include <hip/hip_runtime.h>
-// No packed-fp32 instructions (v_pk_add / mul / fma_f32) in this file's device code — see PREP_TAP_WINDOWS below for why; the kernel is bound by its
-// vector-memory address traffic, not by arithmetic, and takes the same time without them.
-// (-DPREP_ALLOW_PACKED_F32=1: the build that reproduces the defect — tools/asm_variant_setup.sh, tools/prep_partner_check.py; never the product)
-#ifndef PREP_ALLOW_PACKED_F32
-#define PREP_ALLOW_PACKED_F32 0
-#endif
-#if defined(__HIP_DEVICE_COMPILE__) && !PREP_ALLOW_PACKED_F32
-#pragma clang attribute push(__attribute__((target("no-packed-fp32-ops"))), apply_to = function)
-#endif
 #include "prep_device.h"
 
 struct PrepArgs {
@@ -80,7 +70,7 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 // A wave covers 64 pixels of ONE row: everything that depends on the row only (its source rows and weight, its byte offset) is
 // wave-uniform and lives in scalar registers.
 // PREP_TAP_WINDOWS (default 1): the 3 x 3 low-resolution neighbourhoods of the two backward-flow taps through the wave's tap windows
-// (round 5: -15 us).  THIS FILE IS COMPILED WITHOUT PACKED-FP32 INSTRUCTIONS (the pragma at its top), and must stay so:
+// (round 5: -15 us).  THE LIBRARY IS COMPILED WITHOUT PACKED-FP32 INSTRUCTIONS (csrc/hipcc_flags.rsp: -target-feature -packed-fp32-ops) because of this kernel:
 // with the windows hipcc 7.2 forms `v_pk_add_f32 v[36:37], v[36:37], v[4:5] op_sel:[0,1]` for the taps' y coordinates (fb.y + fpy, the row as the
 // high register of the (fpx, fpy) pair), and on gfx950 that operand form — a packed fp32 add / mul / fma whose first vector-register source is read
 // straight and whose second through op_sel — returns low half = src0 + 0 in lanes 48-63 now and then while waves of ANOTHER kernel issue matrix
@@ -88,7 +78,9 @@ __global__ __launch_bounds__(256) void prep_interleave_kernel(const float* __res
 // frames in 12 with three pairs in flight).  Found by bench.py's deferred replay check, traced to the instruction with probes edited into the
 // kernel's assembly (tools/asm_pad_variant.py, tools/asm_edits/), reproduced stand-alone (tools/ubench/pk_opsel_probe.hip: 7 of 25 operand forms,
 // only beside matrix instructions, only lanes 48-63, only the low half): profiles/r06_prep_concurrency.txt, profiles/r06_pk_opsel_probe.txt.
-// The kernel is bound by its vector-memory address traffic, not by arithmetic: without packed instructions it takes the same time.
+// The kernel is bound by its vector-memory address traffic, not by arithmetic: without packed instructions it takes the same time, and the whole
+// forward is 1.4 % faster without them (same-box A/B).  Appending `-Xclang -target-feature -Xclang +packed-fp32-ops` rebuilds the failing kernel
+// (tools/README.md).
 // tools/check_pk_opsel.py (CPU test) keeps every kernel of the library free of the affected forms.
 #ifndef PREP_TAP_WINDOWS
 #define PREP_TAP_WINDOWS 1
@@ -230,6 +222,3 @@ extern "C" int fldr_level0_prep(const fldr_prep_desc* d, fldr_stream_t stream) {
 #undef PREP_LAUNCH
     FLDR_LAUNCH_RET();
 }
-#if defined(__HIP_DEVICE_COMPILE__) && !PREP_ALLOW_PACKED_F32
-#pragma clang attribute pop
-#endif
