@@ -18,8 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def one(pattern):
-    f = sorted(glob.glob(pattern))
-    return f[0] if f else None
+    """The NEWEST match: gpurun merges every call's files into the same local directories (rocprofv3 names them by process id), so an older run's
+    files lie beside the current one's."""
+    f = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return f[-1] if f else None
 
 
 def pmc_medians(d, substr):

@@ -1,8 +1,8 @@
 """Fold the two PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs as MI355X_MICROARCH.md prescribes) of tools/one_conv_spk.py
 into profiles/r01_conv96_spk_traffic.json.  usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 def per_launch(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = sorted(glob.glob(d + "/*/*counter_collection.csv"), key=os.path.getmtime)[-1]          # the newest: older calls' files are merged into the same directory
     vals = {}
     for r in csv.DictReader(open(f)):
         if "conv3x3_spk_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
